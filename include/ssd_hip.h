@@ -1,0 +1,239 @@
+/*
+ * ssd_hip.h — C ABI of libssd_hip.so: the MI355X (gfx950) implementation of the
+ * per-frame point-cloud path of peter-nebe/stair-step-detector.
+ *
+ * Drop-in boundary (reference file:line each entry point replaces; paths are
+ * relative to the reference tree):
+ *
+ *   ssd_calibration_from_points  GeometricTransformation::GeometricTransformation(worldPoints, cameraPoints)
+ *                                transformation.cpp:196-215 (+ :108-157, :94-106)
+ *   ssd_create / ssd_destroy     Pointcloud::Pointcloud(window, trans)   pointcloud.cpp:602-606, pointcloud.h:32-42
+ *                                + the compile-time Configuration          configuration.h:27-52, pointcloud.cpp:99-106
+ *   ssd_process_host             Pointcloud::process(const Camera::DepthFrame&)   pointcloud.cpp:608-626
+ *                                (the frame's xyz vertices = rs2::pointcloud::calculate output, pointcloud.cpp:138)
+ *   ssd_enqueue / ssd_fetch      the same, for frames already resident in device memory, asynchronous
+ *   ssd_serialize                Stairs::serialize()                     stairs.cpp:55-70 (byte-exact text line)
+ *   ssd_get_debug                integer intermediates for parity tests (hist, peaks, images, scans, lines)
+ *   ssd_synth_*                  frame source replacing Camera::waitForFrames (camera.cpp:46-49): synthetic
+ *                                L515-shaped clouds, bit-identical on host and device
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  All functions return
+ * 0 on success or a negative SSD_E_* code; nothing throws across the boundary.
+ * A handle is bound to one device and is not thread-safe (one host thread per GPU).
+ */
+#ifndef SSD_HIP_H_
+#define SSD_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSD_MAX_BINS 128          /* histogram bins the kernels support (reference default: 121) */
+#define SSD_MAX_PLATEAUS 32       /* filtered histogram peaks per frame */
+#define SSD_MAX_STEP_IMAGES 16    /* plateaus at or above minHeight per frame (each owns a bit image) */
+#define SSD_MAX_STEPS (SSD_MAX_STEP_IMAGES + 1)
+#define SSD_MAX_SCANS 128
+#define SSD_MAX_EDGE_PTS 256
+#define SSD_LINE_CAP 4096
+
+/* error codes */
+#define SSD_OK 0
+#define SSD_E_ARG (-1)
+#define SSD_E_HIP (-2)
+#define SSD_E_NOMEM (-3)
+#define SSD_E_NODEVICE (-4)
+#define SSD_E_CAP (-5)
+
+/* per-frame status bits (ssd_frame_result.status) */
+#define SSD_ST_THROW 1         /* reference would have thrown std::invalid_argument (quadrilateralTest.cpp:283-372): no line */
+#define SSD_ST_OOB_PIXEL 2     /* a point fell on pixel column W / row H (reference quirk Q5); dropped */
+#define SSD_ST_ASSERT 4        /* a reference assert would have fired (segmentation.cpp:549-550, :254) */
+#define SSD_ST_OVERFLOW 8      /* more plateaus than SSD_MAX_PLATEAUS / max_step_plateaus: frame truncated */
+
+/* configuration.h:27-52 plus stream resolution and workspace sizing */
+typedef struct
+{
+  int32_t width, height;
+  double x_min, x_max, y_min, y_max, z_min, z_max;   /* Configuration::MeasuringRange */
+  double height_interval;                            /* 0.01 */
+  double min_height_above_ground;                    /* 0.05 */
+  double min_step_depth;                             /* 0.1 */
+  int32_t max_frames_per_batch;                      /* workspace is sized for this many frames in flight */
+  int32_t max_step_plateaus;                         /* <= SSD_MAX_STEP_IMAGES */
+} ssd_config;
+
+/* the constants of GeometricTransformation (transformation.h:102-126) */
+typedef struct
+{
+  double a[9];    /* camera -> camera-dependent world, row-major rotation */
+  double b[3];    /* translation */
+  double r2[4];   /* ToExternalWorld 2-D rotation, row-major */
+  double t2[2];   /* ToExternalWorld 2-D translation */
+  double world_z; /* ToExternalWorld::_worldZ */
+} ssd_calibration;
+
+/* Stairs::StairStep (stairs.h:32-36), external world coordinates */
+typedef struct
+{
+  double height;
+  double quad[8];   /* quadrilateral[0..3] as x,y pairs: front-left, front-right, back-left, back-right */
+} ssd_step;
+
+typedef struct
+{
+  int32_t n_steps;   /* Stairs::stairSteps.size() */
+  int32_t status;    /* SSD_ST_* bits */
+  ssd_step steps[SSD_MAX_STEPS];
+} ssd_frame_result;
+
+typedef struct ssd_handle ssd_handle;
+
+/* ---- configuration / calibration (host only, no GPU needed) ------------- */
+int ssd_default_config(ssd_config *cfg, int width, int height);
+int ssd_calibration_from_points(const double world_points[9], const double camera_points[9], ssd_calibration *out);
+int ssd_calibration_identity(ssd_calibration *out);   /* GeometricTransformation() default, transformation.h:51-55 */
+
+/* ---- lifetime ------------------------------------------------------------ */
+int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ssd_handle **out);
+int ssd_destroy(ssd_handle *h);
+const char *ssd_last_error(void);
+size_t ssd_workspace_bytes(const ssd_handle *h);
+
+/* ---- processing ------------------------------------------------------------
+ * A frame is width*height points, AoS float x,y,z (rs2::vertex layout), row-major, invalid = (0,0,0).
+ * ssd_process_host:   frames in host memory, contiguous; copies to the device, runs, fills results[n].
+ * ssd_enqueue:        frames already in device memory (frame i at d_xyz + i*frame_stride_bytes); enqueues the
+ *                     whole pipeline on `stream` (a hipStream_t, NULL = default stream) and returns without
+ *                     synchronising. nframes <= max_frames_per_batch.
+ * ssd_fetch:          waits for the last ssd_enqueue on that stream and copies its results to the host.
+ */
+int ssd_process_host(ssd_handle *h, const float *xyz, int nframes, ssd_frame_result *results);
+int ssd_enqueue(ssd_handle *h, const void *d_xyz, size_t frame_stride_bytes, int nframes, void *stream);
+int ssd_fetch(ssd_handle *h, ssd_frame_result *results, int nframes, void *stream);
+
+/* stage selector for profiling / roofline measurement: runs only the chosen stage(s) of the pipeline */
+#define SSD_STAGE_HIST 1       /* K1: transform + crop + bin + histogram */
+#define SSD_STAGE_PEAKS 2
+#define SSD_STAGE_RASTER 4     /* K2 */
+#define SSD_STAGE_OUTLINE 8    /* K3 */
+#define SSD_STAGE_QUADS 16
+#define SSD_STAGE_INQUAD 32    /* K4 */
+#define SSD_STAGE_FINAL 64     /* K5 */
+#define SSD_STAGE_ALL 127
+int ssd_enqueue_stages(ssd_handle *h, const void *d_xyz, size_t frame_stride_bytes, int nframes, void *stream, int stages);
+
+/* Per-stage device time of the last enqueue, measured with HIP events recorded on the stream the kernels
+ * run on: ms[0..6] = hist, peaks, raster, outline, quads, inquad, final.  Enable before enqueueing. */
+int ssd_set_timing(ssd_handle *h, int enable);
+int ssd_get_stage_times(ssd_handle *h, float ms[7]);
+
+/* Stairs::serialize(): returns the text length, or SSD_E_CAP. A frame whose status has SSD_ST_THROW
+ * serialises to the empty string (the reference process terminates instead of printing). */
+int ssd_serialize(const ssd_frame_result *r, char *buf, size_t cap);
+
+/* ---- intermediates for parity tests ---------------------------------------- */
+typedef struct
+{
+  int32_t peak_bin, bin_lo, bin_hi;     /* Plateau::height and the chosen pair */
+  int32_t eff_lo, eff_hi;               /* bins that actually feed this plateau (after earlier plateaus took theirs) */
+  int32_t n_points;
+  int32_t is_step, outline_found, valid;
+  int32_t n_scans_right, n_scans_left;
+  int32_t scans_right[SSD_MAX_SCANS][3];
+  int32_t scans_left[SSD_MAX_SCANS][3];
+  int32_t n_edge_pts[4];
+  int32_t line[4][3];
+  double bounds[4][2][2];
+  double base_line[3];
+  int32_t vedge_found[2];
+  int32_t n_vpts[2];
+  int32_t vpts[2][SSD_MAX_EDGE_PTS][2];
+  int32_t best_pt[2][2];
+  double vline[2][3];
+  int32_t corner_found[4];
+  double quad_img[8];
+  double quad_world[8];
+  int32_t quad_err;
+  int32_t n_in_quad;
+  int64_t sum_z_fix;                    /* sum of round(z * 2^40) over the in-quad points */
+  double mean_z;
+} ssd_debug_plateau;
+
+typedef struct
+{
+  int32_t status;
+  int32_t n_nonzero, n_inrange, n_oob;
+  int32_t n_bins, min_height, min_img_y_extent;
+  uint32_t hist[SSD_MAX_BINS];
+  int32_t n_peaks;
+  int32_t peaks[SSD_MAX_PLATEAUS];
+  int32_t n_plateaus, first_step, ground_ind, first_valid_ind;
+  double ground_quad_world[8];
+  int32_t ground_quad_err;
+  int32_t ground_n_in_quad;
+  double ground_mean_z;
+  int32_t ground_front_valid;
+  int32_t ground_n_pts;
+  int32_t ground_pts[SSD_MAX_SCANS][2];
+  int32_t ground_line[3];
+  double ground_front_img[4];
+  ssd_debug_plateau plateaus[SSD_MAX_PLATEAUS];
+} ssd_debug_frame;
+
+/* Enables debug capture for subsequent enqueues (costs memory and time; off by default). */
+int ssd_set_debug(ssd_handle *h, int enable);
+/* Copies the debug record of frame `frame` of the last batch. */
+int ssd_get_debug(ssd_handle *h, int frame, ssd_debug_frame *out);
+/* Raw (pre-close) and closed plateau images of the last batch as H x W bytes (0 / 0xff), like the
+ * reference's cv::Mat.  step_slot = index among the step plateaus, or -1 for the ground image.
+ * Only valid when debug capture was enabled for the batch. */
+int ssd_get_debug_image(ssd_handle *h, int frame, int step_slot, int closed, uint8_t *out);
+
+/* ---- synthetic frame source ------------------------------------------------- */
+typedef struct
+{
+  int32_t width, height;
+  double fx, fy, cx, cy;            /* pinhole intrinsics, pixels */
+  double cam_height;                /* camera centre above the ground plane, metres */
+  double axis_right[3];             /* camera x axis in scene coordinates (x right, y forward, z up) */
+  double axis_down[3];              /* camera y axis */
+  double axis_fwd[3];               /* camera z axis (optical axis) */
+  int32_t n_steps;
+  double first_riser_y;             /* pivot (0, first_riser_y): the first riser passes through it */
+  double tread, rise, stair_width, landing;
+  double yaw_cos, yaw_sin;          /* stairs rotated about the vertical through the pivot */
+  double sigma;                     /* depth noise standard deviation, metres */
+  double outlier_frac, outlier_min, outlier_max;  /* fraction of pixels replaced by uniform random depth */
+  double invalid_frac;              /* fraction of pixels reported invalid (0,0,0) */
+  double max_range;                 /* hits beyond this camera depth are invalid */
+  uint64_t seed;
+} ssd_scene;
+
+/* One frame per scene. Host version writes nframes*W*H*3 floats to xyz; device version writes to
+ * device memory (frame i at d_xyz + i*frame_stride_bytes) on `stream`. Bit-identical outputs. */
+int ssd_synth_generate_host(const ssd_scene *scenes, int nframes, float *xyz);
+int ssd_synth_generate_device(const ssd_scene *scenes, int nframes, void *d_xyz, size_t frame_stride_bytes,
+                              int device, void *stream);
+/* camera coordinates of a scene point (x right, y forward, z up) */
+int ssd_synth_scene_to_camera(const ssd_scene *scene, const double scene_xyz[3], double camera_xyz[3]);
+
+/* plain device-memory helpers so that hosts without a HIP binding can stage frames */
+int ssd_device_count(void);
+int ssd_device_alloc(int device, size_t bytes, void **d_ptr);
+int ssd_device_free(int device, void *d_ptr);
+int ssd_device_upload(int device, void *d_dst, const void *src, size_t bytes);
+int ssd_device_download(int device, void *dst, const void *d_src, size_t bytes);
+int ssd_device_sync(int device);
+
+/* test hooks: std::hypot as the kernels compute it (glibc 2.35 algorithm restated), host and device */
+double ssd_test_hypot_host(double a, double b);
+int ssd_test_hypot_device(int device, const double *a, const double *b, double *out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SSD_HIP_H_ */

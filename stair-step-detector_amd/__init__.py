@@ -1,0 +1,408 @@
+"""Host-side Python binding of libssd_hip.so (ctypes over the C ABI in include/ssd_hip.h).
+
+The package name carries the reference's name and therefore a hyphen; import it with
+``importlib.import_module("stair-step-detector_amd")``.
+
+Mirrors the reference's interface for the per-frame path:
+
+* ``GeometricTransformation(world_points, camera_points)``  -> reference transformation.h:102-126
+* ``Pointcloud(window, trans).process(frame)``              -> reference pointcloud.h:32-42, pointcloud.cpp:608-626
+* ``Stairs.serialize()``                                    -> reference stairs.cpp:55-70
+
+There is no CPU implementation here: every compute call goes to the HIP library and fails
+loudly (``SsdError``) when the library or a GPU is missing.  The CPU oracle lives under
+``oracle/`` and is never imported by this package.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libssd_hip.so")
+
+MAX_BINS = 128
+MAX_PLATEAUS = 32
+MAX_STEP_IMAGES = 16
+MAX_STEPS = MAX_STEP_IMAGES + 1
+MAX_SCANS = 128
+MAX_EDGE_PTS = 256
+LINE_CAP = 4096
+
+ST_THROW, ST_OOB_PIXEL, ST_ASSERT, ST_OVERFLOW = 1, 2, 4, 8
+STAGE_HIST, STAGE_PEAKS, STAGE_RASTER, STAGE_OUTLINE, STAGE_QUADS, STAGE_INQUAD, STAGE_FINAL = 1, 2, 4, 8, 16, 32, 64
+STAGE_ALL = 127
+STAGE_NAMES = ("hist", "peaks", "raster", "outline", "quads", "inquad", "final")
+E_NODEVICE = -4
+
+
+class SsdError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32),
+                ("x_min", C.c_double), ("x_max", C.c_double), ("y_min", C.c_double), ("y_max", C.c_double),
+                ("z_min", C.c_double), ("z_max", C.c_double),
+                ("height_interval", C.c_double), ("min_height_above_ground", C.c_double), ("min_step_depth", C.c_double),
+                ("max_frames_per_batch", C.c_int32), ("max_step_plateaus", C.c_int32)]
+
+
+class Calibration(C.Structure):
+    _fields_ = [("a", C.c_double * 9), ("b", C.c_double * 3), ("r2", C.c_double * 4), ("t2", C.c_double * 2),
+                ("world_z", C.c_double)]
+
+
+class Step(C.Structure):
+    _fields_ = [("height", C.c_double), ("quad", C.c_double * 8)]
+
+
+class FrameResult(C.Structure):
+    _fields_ = [("n_steps", C.c_int32), ("status", C.c_int32), ("steps", Step * MAX_STEPS)]
+
+
+class DebugPlateau(C.Structure):
+    _fields_ = [("peak_bin", C.c_int32), ("bin_lo", C.c_int32), ("bin_hi", C.c_int32),
+                ("eff_lo", C.c_int32), ("eff_hi", C.c_int32), ("n_points", C.c_int32),
+                ("is_step", C.c_int32), ("outline_found", C.c_int32), ("valid", C.c_int32),
+                ("n_scans_right", C.c_int32), ("n_scans_left", C.c_int32),
+                ("scans_right", (C.c_int32 * 3) * MAX_SCANS), ("scans_left", (C.c_int32 * 3) * MAX_SCANS),
+                ("n_edge_pts", C.c_int32 * 4), ("line", (C.c_int32 * 3) * 4),
+                ("bounds", ((C.c_double * 2) * 2) * 4), ("base_line", C.c_double * 3),
+                ("vedge_found", C.c_int32 * 2), ("n_vpts", C.c_int32 * 2),
+                ("vpts", ((C.c_int32 * 2) * MAX_EDGE_PTS) * 2), ("best_pt", (C.c_int32 * 2) * 2),
+                ("vline", (C.c_double * 3) * 2), ("corner_found", C.c_int32 * 4),
+                ("quad_img", C.c_double * 8), ("quad_world", C.c_double * 8),
+                ("quad_err", C.c_int32), ("n_in_quad", C.c_int32), ("sum_z_fix", C.c_int64), ("mean_z", C.c_double)]
+
+
+class DebugFrame(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_nonzero", C.c_int32), ("n_inrange", C.c_int32), ("n_oob", C.c_int32),
+                ("n_bins", C.c_int32), ("min_height", C.c_int32), ("min_img_y_extent", C.c_int32),
+                ("hist", C.c_uint32 * MAX_BINS), ("n_peaks", C.c_int32), ("peaks", C.c_int32 * MAX_PLATEAUS),
+                ("n_plateaus", C.c_int32), ("first_step", C.c_int32), ("ground_ind", C.c_int32),
+                ("first_valid_ind", C.c_int32),
+                ("ground_quad_world", C.c_double * 8), ("ground_quad_err", C.c_int32),
+                ("ground_n_in_quad", C.c_int32), ("ground_mean_z", C.c_double),
+                ("ground_front_valid", C.c_int32), ("ground_n_pts", C.c_int32),
+                ("ground_pts", (C.c_int32 * 2) * MAX_SCANS), ("ground_line", C.c_int32 * 3),
+                ("ground_front_img", C.c_double * 4),
+                ("plateaus", DebugPlateau * MAX_PLATEAUS)]
+
+
+class Scene(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("cam_height", C.c_double),
+                ("axis_right", C.c_double * 3), ("axis_down", C.c_double * 3), ("axis_fwd", C.c_double * 3),
+                ("n_steps", C.c_int32),
+                ("first_riser_y", C.c_double), ("tread", C.c_double), ("rise", C.c_double),
+                ("stair_width", C.c_double), ("landing", C.c_double),
+                ("yaw_cos", C.c_double), ("yaw_sin", C.c_double),
+                ("sigma", C.c_double),
+                ("outlier_frac", C.c_double), ("outlier_min", C.c_double), ("outlier_max", C.c_double),
+                ("invalid_frac", C.c_double), ("max_range", C.c_double),
+                ("seed", C.c_uint64)]
+
+
+EXPORTS = [
+    "ssd_default_config", "ssd_calibration_from_points", "ssd_calibration_identity",
+    "ssd_create", "ssd_destroy", "ssd_last_error", "ssd_workspace_bytes",
+    "ssd_process_host", "ssd_enqueue", "ssd_fetch", "ssd_enqueue_stages",
+    "ssd_set_timing", "ssd_get_stage_times", "ssd_serialize",
+    "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
+    "ssd_synth_generate_host", "ssd_synth_generate_device", "ssd_synth_scene_to_camera",
+    "ssd_device_count", "ssd_device_alloc", "ssd_device_free", "ssd_device_upload", "ssd_device_download",
+    "ssd_device_sync", "ssd_test_hypot_host", "ssd_test_hypot_device",
+]
+
+_lib = None
+
+
+def lib():
+    """Loads libssd_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SsdError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(or make -C stair-step-detector_amd/csrc); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    L.ssd_last_error.restype = C.c_char_p
+    L.ssd_workspace_bytes.restype = sz
+    L.ssd_workspace_bytes.argtypes = [vp]
+    L.ssd_default_config.argtypes = [C.POINTER(Config), i32, i32]
+    L.ssd_calibration_from_points.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(Calibration)]
+    L.ssd_calibration_identity.argtypes = [C.POINTER(Calibration)]
+    L.ssd_create.argtypes = [C.POINTER(Config), C.POINTER(Calibration), i32, C.POINTER(vp)]
+    L.ssd_destroy.argtypes = [vp]
+    L.ssd_process_host.argtypes = [vp, vp, i32, C.POINTER(FrameResult)]
+    L.ssd_enqueue.argtypes = [vp, vp, sz, i32, vp]
+    L.ssd_enqueue_stages.argtypes = [vp, vp, sz, i32, vp, i32]
+    L.ssd_fetch.argtypes = [vp, C.POINTER(FrameResult), i32, vp]
+    L.ssd_set_timing.argtypes = [vp, i32]
+    L.ssd_get_stage_times.argtypes = [vp, C.POINTER(C.c_float)]
+    L.ssd_serialize.argtypes = [C.POINTER(FrameResult), C.c_char_p, sz]
+    L.ssd_set_debug.argtypes = [vp, i32]
+    L.ssd_get_debug.argtypes = [vp, i32, C.POINTER(DebugFrame)]
+    L.ssd_get_debug_image.argtypes = [vp, i32, i32, i32, vp]
+    L.ssd_synth_generate_host.argtypes = [C.POINTER(Scene), i32, vp]
+    L.ssd_synth_generate_device.argtypes = [C.POINTER(Scene), i32, vp, sz, i32, vp]
+    L.ssd_synth_scene_to_camera.argtypes = [C.POINTER(Scene), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ssd_device_alloc.argtypes = [i32, sz, C.POINTER(vp)]
+    L.ssd_device_free.argtypes = [i32, vp]
+    L.ssd_device_upload.argtypes = [i32, vp, vp, sz]
+    L.ssd_device_download.argtypes = [i32, vp, vp, sz]
+    L.ssd_device_sync.argtypes = [i32]
+    L.ssd_test_hypot_host.restype = C.c_double
+    L.ssd_test_hypot_host.argtypes = [C.c_double, C.c_double]
+    L.ssd_test_hypot_device.argtypes = [i32, vp, vp, vp, i32]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc < 0:
+        raise SsdError("libssd_hip error %d: %s" % (rc, lib().ssd_last_error().decode()))
+    return rc
+
+
+def device_count():
+    return lib().ssd_device_count()
+
+
+def default_config(width, height, max_frames_per_batch=64, max_step_plateaus=MAX_STEP_IMAGES):
+    cfg = Config()
+    _check(lib().ssd_default_config(C.byref(cfg), width, height))
+    cfg.max_frames_per_batch = max_frames_per_batch
+    cfg.max_step_plateaus = max_step_plateaus
+    return cfg
+
+
+# --------------------------------------------------------------------------- reference-shaped classes
+class GeometricTransformation:
+    """reference transformation.h:102-126; constructor transformation.cpp:196-215."""
+
+    def __init__(self, world_points=None, camera_points=None):
+        self.constants = Calibration()
+        if world_points is None:
+            _check(lib().ssd_calibration_identity(C.byref(self.constants)))
+        else:
+            w = (C.c_double * 9)(*np.asarray(world_points, dtype=np.float64).reshape(9))
+            c = (C.c_double * 9)(*np.asarray(camera_points, dtype=np.float64).reshape(9))
+            _check(lib().ssd_calibration_from_points(w, c, C.byref(self.constants)))
+
+
+class Stairs:
+    """reference stairs.h:30-39."""
+
+    def __init__(self, result):
+        self.result = result
+        self.status = result.status
+        self.stair_steps = [(result.steps[i].height, [(result.steps[i].quad[2 * k], result.steps[i].quad[2 * k + 1])
+                                                      for k in range(4)]) for i in range(result.n_steps)]
+
+    def serialize(self):
+        buf = C.create_string_buffer(LINE_CAP)
+        _check(lib().ssd_serialize(C.byref(self.result), buf, LINE_CAP))
+        return buf.value.decode()
+
+
+class Window:
+    """reference window.h: the GL sink; has no effect on results."""
+
+    def __init__(self, name=""):
+        self.name = name
+
+
+class Detector:
+    """One handle = one device = one `Pointcloud` of the reference, plus the batch entry points."""
+
+    def __init__(self, cfg, trans, device=0):
+        self.cfg = cfg
+        self.device = device
+        self._h = C.c_void_p()
+        cal = trans.constants if isinstance(trans, GeometricTransformation) else trans
+        _check(lib().ssd_create(C.byref(cfg), C.byref(cal), device, C.byref(self._h)))
+        self.frame_bytes = cfg.width * cfg.height * 12
+
+    def close(self):
+        if self._h:
+            lib().ssd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self):
+        return lib().ssd_workspace_bytes(self._h)
+
+    def process_host(self, xyz):
+        """xyz: float32 array [n, H, W, 3] (or [H, W, 3]) on the host -> list of FrameResult."""
+        a = np.ascontiguousarray(xyz, dtype=np.float32)
+        n = a.size // (self.cfg.width * self.cfg.height * 3)
+        if n * self.cfg.width * self.cfg.height * 3 != a.size or n < 1:
+            raise SsdError("process_host: array does not hold whole frames")
+        res = (FrameResult * n)()
+        _check(lib().ssd_process_host(self._h, a.ctypes.data_as(C.c_void_p), n, res))
+        return list(res)
+
+    def enqueue(self, d_ptr, nframes, stride_bytes=None, stream=None, stages=STAGE_ALL):
+        _check(lib().ssd_enqueue_stages(self._h, C.c_void_p(d_ptr), stride_bytes or self.frame_bytes, nframes,
+                                        C.c_void_p(stream or 0), stages))
+
+    def fetch(self, nframes, stream=None):
+        res = (FrameResult * nframes)()
+        _check(lib().ssd_fetch(self._h, res, nframes, C.c_void_p(stream or 0)))
+        return list(res)
+
+    def set_timing(self, on=True):
+        _check(lib().ssd_set_timing(self._h, 1 if on else 0))
+
+    def stage_times_ms(self):
+        ms = (C.c_float * 7)()
+        _check(lib().ssd_get_stage_times(self._h, ms))
+        return dict(zip(STAGE_NAMES, [float(x) for x in ms]))
+
+    def set_debug(self, on=True):
+        _check(lib().ssd_set_debug(self._h, 1 if on else 0))
+
+    def debug(self, frame=0):
+        d = DebugFrame()
+        _check(lib().ssd_get_debug(self._h, frame, C.byref(d)))
+        return d
+
+    def debug_image(self, frame, step_slot, closed):
+        out = np.empty((self.cfg.height, self.cfg.width), dtype=np.uint8)
+        _check(lib().ssd_get_debug_image(self._h, frame, step_slot, 1 if closed else 0, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+
+class Pointcloud:
+    """reference pointcloud.h:32-42: ``Pointcloud(window, trans).process(frame)`` prints one line."""
+
+    def __init__(self, window, trans, device=0):
+        self._window, self._trans, self._device = window, trans, device
+        self._det = None
+
+    def detect(self, frame):
+        a = np.asarray(frame, dtype=np.float32)
+        h, w = a.shape[0], a.shape[1]
+        if self._det is None or (self._det.cfg.width, self._det.cfg.height) != (w, h):
+            self._det = Detector(default_config(w, h, max_frames_per_batch=1), self._trans, self._device)
+        st = Stairs(self._det.process_host(a)[0])
+        if st.status & ST_THROW:
+            raise ValueError("Quadrilateral is not usable (reference quadrilateralTest.cpp:283-372 throws)")
+        return st
+
+    def process(self, frame):
+        print(self.detect(frame).serialize(), flush=True)
+
+
+# --------------------------------------------------------------------------- synthetic frame source
+def make_scene(width, height, n_steps=3, seed=12345, cam_height=1.0, pitch_deg=50.0, roll_deg=0.0,
+               first_riser_y=0.45, tread=0.28, rise=0.17, stair_width=0.8, landing=1.0, yaw_deg=0.0,
+               sigma=0.001, outlier_frac=0.0, outlier_min=0.3, outlier_max=3.0, invalid_frac=0.0,
+               max_range=9.0, hfov_deg=70.0, vfov_deg=55.0):
+    """L515-shaped pinhole looking down at a staircase (SURVEY.md section 8(d) recipe)."""
+    s = Scene()
+    s.width, s.height = width, height
+    s.fx = (width / 2.0) / math.tan(math.radians(hfov_deg / 2.0))
+    s.fy = (height / 2.0) / math.tan(math.radians(vfov_deg / 2.0))
+    s.cx, s.cy = (width - 1) / 2.0, (height - 1) / 2.0
+    s.cam_height = cam_height
+    p, r = math.radians(pitch_deg), math.radians(roll_deg)
+    fwd = np.array([0.0, math.cos(p), -math.sin(p)])
+    right0 = np.array([1.0, 0.0, 0.0])
+    down0 = np.cross(fwd, right0)
+    right = math.cos(r) * right0 + math.sin(r) * down0
+    down = np.cross(fwd, right)
+    s.axis_right[:] = list(right)
+    s.axis_down[:] = list(down)
+    s.axis_fwd[:] = list(fwd)
+    s.n_steps = n_steps
+    s.first_riser_y, s.tread, s.rise, s.stair_width, s.landing = first_riser_y, tread, rise, stair_width, landing
+    s.yaw_cos, s.yaw_sin = math.cos(math.radians(yaw_deg)), math.sin(math.radians(yaw_deg))
+    s.sigma = sigma
+    s.outlier_frac, s.outlier_min, s.outlier_max = outlier_frac, outlier_min, outlier_max
+    s.invalid_frac, s.max_range = invalid_frac, max_range
+    s.seed = seed
+    return s
+
+
+def scene_array(scenes):
+    arr = (Scene * len(scenes))()
+    for i, s in enumerate(scenes):
+        C.memmove(C.byref(arr[i]), C.byref(s), C.sizeof(Scene))
+    return arr
+
+
+def synth_host(scenes):
+    """-> float32 [n, H, W, 3]; runs on the host, no GPU needed; bit-identical to the device generator."""
+    arr = scene_array(scenes)
+    h, w = scenes[0].height, scenes[0].width
+    out = np.empty((len(scenes), h, w, 3), dtype=np.float32)
+    _check(lib().ssd_synth_generate_host(arr, len(scenes), out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def synth_device(scenes, d_ptr, stride_bytes=None, device=0, stream=None):
+    arr = scene_array(scenes)
+    stride = stride_bytes or scenes[0].width * scenes[0].height * 12
+    _check(lib().ssd_synth_generate_device(arr, len(scenes), C.c_void_p(d_ptr), stride, device, C.c_void_p(stream or 0)))
+
+
+CALIBRATION_MARKS = ((-0.35, 0.9, 0.0), (0.35, 0.9, 0.0), (0.2, 0.35, 0.0))
+
+
+def calibration_points(scene, marks=CALIBRATION_MARKS, world_offset=(0.0, 0.0, 0.004)):
+    """Three ground marks: (external-world points, camera points) as the calibration files would hold them."""
+    world, cam = [], []
+    for m in marks:
+        p = (C.c_double * 3)(*m)
+        o = (C.c_double * 3)()
+        _check(lib().ssd_synth_scene_to_camera(C.byref(scene), p, o))
+        cam.append([o[0], o[1], o[2]])
+        world.append([m[0] + world_offset[0], m[1] + world_offset[1], m[2] + world_offset[2]])
+    return np.array(world), np.array(cam)
+
+
+def transformation_for_scene(scene):
+    world, cam = calibration_points(scene)
+    return GeometricTransformation(world, cam)
+
+
+class DeviceBuffer:
+    """hipMalloc'd bytes through the C ABI (for hosts without torch)."""
+
+    def __init__(self, nbytes, device=0):
+        self.device, self.nbytes = device, nbytes
+        p = C.c_void_p()
+        _check(lib().ssd_device_alloc(device, nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, array, offset=0):
+        a = np.ascontiguousarray(array)
+        _check(lib().ssd_device_upload(self.device, C.c_void_p(self.ptr + offset), a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def download(self, nbytes, offset=0, dtype=np.uint8):
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        _check(lib().ssd_device_download(self.device, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr + offset), nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().ssd_device_free(self.device, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,96 @@
+/*
+ * detect_stairs.cpp — the detect-stairs main loop (reference detect-stairs.cpp:26-45) with the
+ * camera replaced by the synthetic frame source (or a raw float32 xyz file): one
+ * Stairs::serialize() line per frame on stdout, the wire format the ROS node parses
+ * (ros/stair_step_detector_pkg/.../stair_step_detector.py:32-44).
+ *
+ *   detect-stairs-amd [--width W] [--height H] [--frames N] [--steps K] [--seed S] [--file frames.f32]
+ */
+#include "stairs_api.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <vector>
+using namespace stairs;
+
+static ssd_scene makeScene(int W, int H, int K, uint64_t seed)
+{
+  ssd_scene s{};
+  const double pi = 3.14159265358979323846;
+  s.width = W; s.height = H;
+  s.fx = (W / 2.0) / std::tan(35.0 * pi / 180.0);
+  s.fy = (H / 2.0) / std::tan(27.5 * pi / 180.0);
+  s.cx = (W - 1) / 2.0; s.cy = (H - 1) / 2.0;
+  s.cam_height = 1.0;
+  const double pitch = 50.0 * pi / 180.0;
+  s.axis_right[0] = 1; s.axis_right[1] = 0; s.axis_right[2] = 0;
+  s.axis_down[0] = 0; s.axis_down[1] = -std::sin(pitch); s.axis_down[2] = -std::cos(pitch);
+  s.axis_fwd[0] = 0; s.axis_fwd[1] = std::cos(pitch); s.axis_fwd[2] = -std::sin(pitch);
+  s.n_steps = K;
+  s.first_riser_y = 0.45; s.tread = 0.28; s.rise = 0.17; s.stair_width = 0.8; s.landing = 1.0;
+  s.yaw_cos = 1.0; s.yaw_sin = 0.0;
+  s.sigma = 0.001;
+  s.outlier_frac = 0; s.outlier_min = 0.3; s.outlier_max = 3.0;
+  s.invalid_frac = 0; s.max_range = 9.0;
+  s.seed = seed;
+  return s;
+}
+
+int main(int argc, char **argv)
+{
+  int W = 1024, H = 768, frames = 1, K = 3;
+  uint64_t seed = 12345;
+  const char *file = nullptr;
+  for(int i = 1; i + 1 < argc; i += 2)
+  {
+    if(!std::strcmp(argv[i], "--width")) W = std::atoi(argv[i + 1]);
+    else if(!std::strcmp(argv[i], "--height")) H = std::atoi(argv[i + 1]);
+    else if(!std::strcmp(argv[i], "--frames")) frames = std::atoi(argv[i + 1]);
+    else if(!std::strcmp(argv[i], "--steps")) K = std::atoi(argv[i + 1]);
+    else if(!std::strcmp(argv[i], "--seed")) seed = std::strtoull(argv[i + 1], nullptr, 10);
+    else if(!std::strcmp(argv[i], "--file")) file = argv[i + 1];
+  }
+
+  Window app("stair-step-detector");
+
+  /* calibration: three ground marks seen through the synthetic camera pose (GeometricCalibration::load) */
+  const ssd_scene s0 = makeScene(W, H, K, seed);
+  const double marks[3][3] = { { -0.35, 0.9, 0 }, { 0.35, 0.9, 0 }, { 0.2, 0.35, 0 } };
+  GeometricTransformation::RefPoints wor, cam;
+  for(int i = 0; i < 3; i++)
+  {
+    double c[3];
+    ssd_synth_scene_to_camera(&s0, marks[i], c);
+    wor[i] = Point3{ marks[i][0], marks[i][1], marks[i][2] };
+    cam[i] = Point3{ c[0], c[1], c[2] };
+  }
+  const GeometricTransformation trans(wor, cam);
+  const Pointcloud pointcloud(app, trans);
+
+  std::vector<float> xyz(static_cast<size_t>(W) * H * 3);
+  FILE *fp = file ? std::fopen(file, "rb") : nullptr;
+  if(file && !fp)
+  {
+    std::perror(file);
+    return 1;
+  }
+  for(int f = 0; f < frames && app; f++)
+  {
+    if(fp)
+    {
+      if(std::fread(xyz.data(), sizeof(float), xyz.size(), fp) != xyz.size())
+        break;
+    }
+    else
+    {
+      const ssd_scene s = makeScene(W, H, K, seed + f);
+      ssd_synth_generate_host(&s, 1, xyz.data());
+    }
+    pointcloud.process(Camera::DepthFrame{ xyz.data(), W, H });
+  }
+  if(fp)
+    std::fclose(fp);
+  return 0;
+}

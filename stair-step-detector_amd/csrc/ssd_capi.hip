@@ -1,0 +1,681 @@
+/*
+ * ssd_capi.hip — the C ABI of libssd_hip.so (see include/ssd_hip.h for the
+ * reference interface each entry point replaces).  Owns the device workspace,
+ * sequences the kernels of ssd_kernels.hip on one HIP stream, never touches
+ * the CPU oracle: if no HIP device is present every compute entry fails with
+ * SSD_E_NODEVICE.
+ */
+#include "ssd_launch.h"
+#include "ssd_synth.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ssd;
+
+namespace
+{
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+  do                                                                                                    \
+  {                                                                                                     \
+    const hipError_t e_ = (expr);                                                                       \
+    if(e_ != hipSuccess)                                                                                \
+      return fail(SSD_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+  } while(0)
+
+int env_int(const char *name, int dflt)
+{
+  const char *v = std::getenv(name);
+  return v && *v ? std::atoi(v) : dflt;
+}
+
+} // namespace
+
+struct ssd_handle
+{
+  int device = 0;
+  ssd_config cfg{};
+  Params P{};
+  int F = 0;                      /* max frames per batch */
+  size_t imgWords = 0;            /* 64-bit words per bit image */
+  FrameState *dState = nullptr;
+  unsigned long long *dStepImg = nullptr;
+  unsigned long long *dGroundImg = nullptr;
+  ssd_frame_result *dResults = nullptr;
+  ssd_frame_result *hResults = nullptr;     /* pinned */
+  float *dFrames = nullptr;                 /* staging for ssd_process_host */
+  size_t dFramesCap = 0;                    /* frames */
+  DebugFrame *dDebug = nullptr;
+  unsigned long long *dDebugImg = nullptr;
+  bool debug = false;
+  bool imagesDirty = false;
+  int lastFrames = 0;
+  size_t bytes = 0;
+  /* per-stage timing */
+  bool timing = false;
+  hipEvent_t ev[9]{};
+  bool evCreated = false;
+  bool evValid = false;
+  int evStages = 0;
+};
+
+extern "C"
+{
+
+const char *ssd_last_error(void)
+{
+  return g_err.c_str();
+}
+
+int ssd_default_config(ssd_config *cfg, int width, int height)
+{
+  if(!cfg || width <= 0 || height <= 0)
+    return fail(SSD_E_ARG, "ssd_default_config: bad argument");
+  /* configuration.h:27-52 */
+  cfg->width = width;
+  cfg->height = height;
+  cfg->x_min = -0.6; cfg->x_max = 0.6;
+  cfg->y_min = 0.1; cfg->y_max = 1.3;
+  cfg->z_min = -0.1; cfg->z_max = 1.1;
+  cfg->height_interval = 0.01;
+  cfg->min_height_above_ground = 0.05;
+  cfg->min_step_depth = 0.1;
+  cfg->max_frames_per_batch = 64;
+  cfg->max_step_plateaus = SSD_MAX_STEP_IMAGES;
+  return SSD_OK;
+}
+
+int ssd_calibration_identity(ssd_calibration *out)
+{
+  if(!out)
+    return fail(SSD_E_ARG, "ssd_calibration_identity: null");
+  std::memset(out, 0, sizeof(*out));
+  out->a[0] = out->a[4] = out->a[8] = 1.0;
+  out->r2[0] = out->r2[3] = 1.0;
+  return SSD_OK;
+}
+
+/* GeometricTransformation(worldPoints, cameraPoints), transformation.cpp:196-215.
+ * Vector algebra as Boost.QVM evaluates it: products summed left to right,
+ * normalized(v) = v * (1 / sqrt(dot(v, v))). */
+int ssd_calibration_from_points(const double w[9], const double c[9], ssd_calibration *out)
+{
+  if(!w || !c || !out)
+    return fail(SSD_E_ARG, "ssd_calibration_from_points: null");
+  struct V3 { double x, y, z; };
+  auto sub = [](V3 a, V3 b) { return V3{ a.x - b.x, a.y - b.y, a.z - b.z }; };
+  auto cross = [](V3 a, V3 b) { return V3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; };
+  auto dot = [](V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; };
+  auto norm = [](V3 a)
+  {
+    const double m2 = a.x * a.x + a.y * a.y + a.z * a.z;
+    const double rm = 1.0 / std::sqrt(m2);
+    return V3{ a.x * rm, a.y * rm, a.z * rm };
+  };
+  const V3 c0{ c[0], c[1], c[2] }, c1{ c[3], c[4], c[5] }, c2{ c[6], c[7], c[8] };
+
+  /* Transformation_<3>(triangleInPlane), transformation.cpp:108-157 */
+  const V3 n0 = norm(cross(sub(c1, c0), sub(c2, c0)));
+  const V3 zB{ -n0.x, -n0.y, -n0.z };
+  const V3 yB = norm(V3{ 0.0, -zB.z / zB.y, 1.0 });
+  const V3 xB = cross(yB, zB);
+  const double dist = dot(c0, n0);
+  if(!(dist > 0.0) || !std::isfinite(yB.y) || !std::isfinite(xB.x))
+    return fail(SSD_E_ARG, "ssd_calibration_from_points: degenerate triangle (reference assert, transformation.cpp:153)");
+  out->a[0] = xB.x; out->a[1] = xB.y; out->a[2] = xB.z;
+  out->a[3] = yB.x; out->a[4] = yB.y; out->a[5] = yB.z;
+  out->a[6] = zB.x; out->a[7] = zB.y; out->a[8] = zB.z;
+  out->b[0] = 0.0; out->b[1] = 0.0; out->b[2] = dist;
+
+  /* Transformation_<2>({w0, w1}, {cameraToWorld(c0), cameraToWorld(c1)}), transformation.cpp:65-106 */
+  auto c2w = [&](V3 p)
+  {
+    V3 r;
+    r.x = out->a[0] * p.x + out->a[1] * p.y + out->a[2] * p.z;
+    r.y = out->a[3] * p.x + out->a[4] * p.y + out->a[5] * p.z;
+    r.z = out->a[6] * p.x + out->a[7] * p.y + out->a[8] * p.z;
+    r.x = r.x + out->b[0]; r.y = r.y + out->b[1]; r.z = r.z + out->b[2];
+    return r;
+  };
+  const V3 m0 = c2w(c0), m1 = c2w(c1);
+  auto norm2 = [](double x, double y, double &ox, double &oy)
+  {
+    const double m2 = x * x + y * y;
+    const double rm = 1.0 / std::sqrt(m2);
+    ox = x * rm; oy = y * rm;
+  };
+  double dx, dy, dxm, dym;
+  norm2(w[3] - w[0], w[4] - w[1], dx, dy);
+  norm2(m1.x - m0.x, m1.y - m0.y, dxm, dym);
+  const double xBaseX = dx * dxm + dy * dym;
+  const double xBaseY = dy * dxm - dx * dym;
+  out->r2[0] = xBaseX; out->r2[1] = -xBaseY;
+  out->r2[2] = xBaseY; out->r2[3] = xBaseX;
+  out->t2[0] = w[0] - (out->r2[0] * m0.x + out->r2[1] * m0.y);
+  out->t2[1] = w[1] - (out->r2[2] * m0.x + out->r2[3] * m0.y);
+  out->world_z = w[2];
+  if(!std::isfinite(xBaseX) || !std::isfinite(xBaseY))
+    return fail(SSD_E_ARG, "ssd_calibration_from_points: coincident reference points");
+  return SSD_OK;
+}
+
+int ssd_device_count(void)
+{
+  int n = 0;
+  if(hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+static int make_params(const ssd_config &c, const ssd_calibration &k, Params &P)
+{
+  if(c.width <= 0 || c.height <= 0 || c.width > 8192 || c.height > 8192)
+    return fail(SSD_E_ARG, "config: resolution out of range");
+  if(!(c.x_max > c.x_min) || !(c.y_max > c.y_min) || !(c.z_max > c.z_min) || !(c.height_interval > 0))
+    return fail(SSD_E_ARG, "config: empty measuring range");
+  P.W = c.width; P.H = c.height;
+  P.W64 = (c.width + 63) / 64;
+  P.nPoints = c.width * c.height;
+  for(int i = 0; i < 9; i++) P.a[i] = k.a[i];
+  for(int i = 0; i < 3; i++) P.b[i] = k.b[i];
+  for(int i = 0; i < 4; i++) P.r2[i] = k.r2[i];
+  P.t2[0] = k.t2[0]; P.t2[1] = k.t2[1];
+  P.worldZ = k.world_z;
+  P.xMin = c.x_min; P.xMax = c.x_max; P.yMin = c.y_min; P.yMax = c.y_max; P.zMin = c.z_min; P.zMax = c.z_max;
+  /* ProcessingConfiguration / Projection2D, pointcloud.cpp:60-106 */
+  P.recip = 1.0 / c.height_interval;
+  P.minHeight = static_cast<uint16_t>((c.min_height_above_ground - c.z_min) * P.recip);
+  P.minImgYExtent = static_cast<int>(c.min_step_depth * c.height / (c.y_max - c.y_min));
+  P.xToImage = c.width / (c.x_max - c.x_min);
+  P.yToImage = c.height / (c.y_max - c.y_min);
+  P.xToWorld = 1 / P.xToImage;
+  P.yToWorld = 1 / P.yToImage;
+  P.xyRatio = P.xToImage / P.yToImage;
+  const size_t nBins = static_cast<size_t>((c.z_max - c.z_min) * P.recip) + 1;   /* pointcloud.cpp:196 */
+  if(nBins < 3 || nBins > SSD_MAX_BINS)
+    return fail(SSD_E_ARG, "config: histogram needs 3.." + std::to_string(SSD_MAX_BINS) + " bins");
+  P.nBins = static_cast<int>(nBins);
+  if(c.max_step_plateaus < 1 || c.max_step_plateaus > SSD_MAX_STEP_IMAGES)
+    return fail(SSD_E_ARG, "config: max_step_plateaus out of range");
+  P.maxStepImages = c.max_step_plateaus;
+  if((c.width - 1) / 25 + 2 > SSD_MAX_SCANS)
+    return fail(SSD_E_ARG, "config: width needs more scan columns than SSD_MAX_SCANS");
+  return SSD_OK;
+}
+
+int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ssd_handle **out)
+{
+  if(!cfg || !cal || !out)
+    return fail(SSD_E_ARG, "ssd_create: null argument");
+  *out = nullptr;
+  if(cfg->max_frames_per_batch < 1 || cfg->max_frames_per_batch > 65535)
+    return fail(SSD_E_ARG, "ssd_create: max_frames_per_batch out of range");
+  Params P{};
+  const int rc = make_params(*cfg, *cal, P);
+  if(rc)
+    return rc;
+  const int nDev = ssd_device_count();
+  if(nDev <= 0)
+    return fail(SSD_E_NODEVICE, "ssd_create: no HIP device (the HIP path is mandatory; there is no CPU fallback)");
+  if(device < 0 || device >= nDev)
+    return fail(SSD_E_ARG, "ssd_create: device index out of range");
+  HIP_TRY(hipSetDevice(device));
+
+  ssd_handle *h = new ssd_handle();
+  h->device = device;
+  h->cfg = *cfg;
+  h->P = P;
+  h->F = cfg->max_frames_per_batch;
+  h->imgWords = static_cast<size_t>(P.H) * P.W64;
+  const size_t stepBytes = static_cast<size_t>(h->F) * P.maxStepImages * h->imgWords * 8;
+  const size_t groundBytes = static_cast<size_t>(h->F) * h->imgWords * 8;
+  auto cleanup = [&]() { ssd_destroy(h); };
+#define HIP_TRY_H(expr)                                                                                 \
+  do                                                                                                    \
+  {                                                                                                     \
+    const hipError_t e_ = (expr);                                                                       \
+    if(e_ != hipSuccess)                                                                                \
+    {                                                                                                   \
+      cleanup();                                                                                        \
+      return fail(e_ == hipErrorOutOfMemory ? SSD_E_NOMEM : SSD_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    }                                                                                                   \
+  } while(0)
+  HIP_TRY_H(hipMalloc(&h->dState, sizeof(FrameState) * h->F));
+  HIP_TRY_H(hipMalloc(&h->dStepImg, stepBytes));
+  HIP_TRY_H(hipMalloc(&h->dGroundImg, groundBytes));
+  HIP_TRY_H(hipMalloc(&h->dResults, sizeof(ssd_frame_result) * h->F));
+  HIP_TRY_H(hipHostMalloc(&h->hResults, sizeof(ssd_frame_result) * h->F, hipHostMallocDefault));
+  HIP_TRY_H(hipMemset(h->dState, 0, sizeof(FrameState) * h->F));
+  HIP_TRY_H(hipMemset(h->dStepImg, 0, stepBytes));
+  HIP_TRY_H(hipMemset(h->dGroundImg, 0, groundBytes));
+  HIP_TRY_H(hipMemset(h->dResults, 0, sizeof(ssd_frame_result) * h->F));
+  HIP_TRY_H(hipDeviceSynchronize());
+#undef HIP_TRY_H
+  h->bytes = sizeof(FrameState) * h->F + stepBytes + groundBytes + sizeof(ssd_frame_result) * h->F;
+  *out = h;
+  return SSD_OK;
+}
+
+int ssd_destroy(ssd_handle *h)
+{
+  if(!h)
+    return SSD_OK;
+  (void)hipSetDevice(h->device);
+  if(h->dState) (void)hipFree(h->dState);
+  if(h->dStepImg) (void)hipFree(h->dStepImg);
+  if(h->dGroundImg) (void)hipFree(h->dGroundImg);
+  if(h->dResults) (void)hipFree(h->dResults);
+  if(h->hResults) (void)hipHostFree(h->hResults);
+  if(h->dFrames) (void)hipFree(h->dFrames);
+  if(h->dDebug) (void)hipFree(h->dDebug);
+  if(h->dDebugImg) (void)hipFree(h->dDebugImg);
+  if(h->evCreated)
+    for(hipEvent_t e : h->ev)
+      (void)hipEventDestroy(e);
+  delete h;
+  return SSD_OK;
+}
+
+size_t ssd_workspace_bytes(const ssd_handle *h)
+{
+  return h ? h->bytes : 0;
+}
+
+int ssd_set_debug(ssd_handle *h, int enable)
+{
+  if(!h)
+    return fail(SSD_E_ARG, "ssd_set_debug: null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  if(enable && !h->dDebug)
+  {
+    const size_t imgBytes = static_cast<size_t>(h->F) * (h->P.maxStepImages + 1) * 2 * h->imgWords * 8;
+    HIP_TRY(hipMalloc(&h->dDebug, sizeof(DebugFrame) * h->F));
+    HIP_TRY(hipMalloc(&h->dDebugImg, imgBytes));
+    h->bytes += sizeof(DebugFrame) * h->F + imgBytes;
+  }
+  h->debug = enable != 0;
+  return SSD_OK;
+}
+
+int ssd_set_timing(ssd_handle *h, int enable)
+{
+  if(!h)
+    return fail(SSD_E_ARG, "ssd_set_timing: null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  if(enable && !h->evCreated)
+  {
+    for(hipEvent_t &e : h->ev)
+      HIP_TRY(hipEventCreate(&e));
+    h->evCreated = true;
+  }
+  h->timing = enable != 0;
+  h->evValid = false;
+  return SSD_OK;
+}
+
+static int choose_chunk(int nPoints, int nframes)
+{
+  const int forced = env_int("SSD_CHUNK_POINTS", 0);
+  if(forced > 0)
+    return ((forced + kTileHost - 1) / kTileHost) * kTileHost;
+  const int target = env_int("SSD_TARGET_BLOCKS", 16384);
+  int cpf = (target + nframes - 1) / nframes;
+  const int maxCpf = (nPoints + kTileHost - 1) / kTileHost;
+  if(cpf > maxCpf) cpf = maxCpf;
+  if(cpf < 1) cpf = 1;
+  const int per = (nPoints + cpf - 1) / cpf;
+  return ((per + kTileHost - 1) / kTileHost) * kTileHost;
+}
+
+int ssd_enqueue_stages(ssd_handle *h, const void *d_xyz, size_t frame_stride_bytes, int nframes, void *stream, int stages)
+{
+  if(!h || !d_xyz)
+    return fail(SSD_E_ARG, "ssd_enqueue: null argument");
+  if(nframes < 1 || nframes > h->F)
+    return fail(SSD_E_ARG, "ssd_enqueue: nframes must be 1..max_frames_per_batch");
+  const size_t frameBytes = static_cast<size_t>(h->P.nPoints) * 12;
+  if(frame_stride_bytes < frameBytes || frame_stride_bytes % 4 != 0)
+    return fail(SSD_E_ARG, "ssd_enqueue: frame stride smaller than a frame or not a multiple of 4");
+  if((reinterpret_cast<uintptr_t>(d_xyz) & 3u) != 0)
+    return fail(SSD_E_ARG, "ssd_enqueue: frame pointer must be 4-byte aligned");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const Params &P = h->P;
+  const float *xyz = static_cast<const float *>(d_xyz);
+  const size_t strideFloats = frame_stride_bytes / 4;
+  const int chunk = choose_chunk(P.nPoints, nframes);
+  DebugFrame *dbg = h->debug ? h->dDebug : nullptr;
+  unsigned long long *dbgImg = h->debug ? h->dDebugImg : nullptr;
+  const bool timing = h->timing && h->evCreated;
+  int evi = 0;
+  auto mark = [&]() { if(timing) (void)hipEventRecord(h->ev[evi++], s); };
+
+  if(h->imagesDirty)
+  {
+    HIP_TRY(hipMemsetAsync(h->dStepImg, 0, static_cast<size_t>(h->F) * P.maxStepImages * h->imgWords * 8, s));
+    HIP_TRY(hipMemsetAsync(h->dGroundImg, 0, static_cast<size_t>(h->F) * h->imgWords * 8, s));
+    h->imagesDirty = false;
+  }
+  if(stages & SSD_STAGE_HIST)
+  {
+    HIP_TRY(hipMemsetAsync(h->dState, 0, sizeof(FrameState) * nframes, s));
+    if(dbg)
+      HIP_TRY(hipMemsetAsync(dbg, 0, sizeof(DebugFrame) * nframes, s));
+  }
+  mark();
+  if(stages & SSD_STAGE_HIST)
+    launch_hist(xyz, strideFloats, P, h->dState, nframes, chunk, s);
+  mark();
+  if(stages & SSD_STAGE_PEAKS)
+    launch_peaks(P, h->dState, nframes, dbg, s);
+  mark();
+  if(stages & SSD_STAGE_RASTER)
+    launch_raster(xyz, strideFloats, P, h->dState, reinterpret_cast<unsigned int *>(h->dStepImg), nframes, chunk, s);
+  mark();
+  if(stages & SSD_STAGE_OUTLINE)
+    launch_outline(P, h->dState, h->dStepImg, nframes, dbg, dbgImg, s);
+  mark();
+  if(stages & SSD_STAGE_QUADS)
+    launch_quads(P, h->dState, nframes, dbg, s);
+  mark();
+  if(stages & SSD_STAGE_INQUAD)
+    launch_inquad(xyz, strideFloats, P, h->dState, reinterpret_cast<unsigned int *>(h->dGroundImg), nframes, chunk, s);
+  mark();
+  if(stages & SSD_STAGE_FINAL)
+    launch_final(P, h->dState, h->dGroundImg, h->dResults, nframes, dbg, dbgImg, s);
+  mark();
+  HIP_TRY(hipGetLastError());
+  /* a raster without its consumer leaves bits behind */
+  if(((stages & SSD_STAGE_RASTER) && !(stages & SSD_STAGE_OUTLINE)) || ((stages & SSD_STAGE_INQUAD) && !(stages & SSD_STAGE_FINAL)))
+    h->imagesDirty = true;
+  h->lastFrames = nframes;
+  h->evValid = timing;
+  h->evStages = stages;
+  return SSD_OK;
+}
+
+int ssd_enqueue(ssd_handle *h, const void *d_xyz, size_t frame_stride_bytes, int nframes, void *stream)
+{
+  return ssd_enqueue_stages(h, d_xyz, frame_stride_bytes, nframes, stream, SSD_STAGE_ALL);
+}
+
+/* milliseconds of the 7 stages of the last enqueue (needs ssd_set_timing(h,1)); waits for the stream */
+int ssd_get_stage_times(ssd_handle *h, float ms[7])
+{
+  if(!h || !ms)
+    return fail(SSD_E_ARG, "ssd_get_stage_times: null");
+  if(!h->evValid)
+    return fail(SSD_E_ARG, "ssd_get_stage_times: timing was not enabled for the last enqueue");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipEventSynchronize(h->ev[7]));
+  for(int i = 0; i < 7; i++)
+    HIP_TRY(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+  return SSD_OK;
+}
+
+int ssd_fetch(ssd_handle *h, ssd_frame_result *results, int nframes, void *stream)
+{
+  if(!h || !results)
+    return fail(SSD_E_ARG, "ssd_fetch: null argument");
+  if(nframes < 1 || nframes > h->F)
+    return fail(SSD_E_ARG, "ssd_fetch: nframes out of range");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(h->hResults, h->dResults, sizeof(ssd_frame_result) * nframes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  std::memcpy(results, h->hResults, sizeof(ssd_frame_result) * nframes);
+  return SSD_OK;
+}
+
+int ssd_process_host(ssd_handle *h, const float *xyz, int nframes, ssd_frame_result *results)
+{
+  if(!h || !xyz || !results || nframes < 1)
+    return fail(SSD_E_ARG, "ssd_process_host: bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t frameFloats = static_cast<size_t>(h->P.nPoints) * 3;
+  const size_t need = static_cast<size_t>(nframes < h->F ? nframes : h->F);
+  if(h->dFramesCap < need)
+  {
+    if(h->dFrames) (void)hipFree(h->dFrames);
+    h->dFrames = nullptr;
+    h->dFramesCap = 0;
+    HIP_TRY(hipMalloc(&h->dFrames, need * frameFloats * 4));
+    h->dFramesCap = need;
+  }
+  for(int done = 0; done < nframes; )
+  {
+    const int n = nframes - done < h->F ? nframes - done : h->F;
+    HIP_TRY(hipMemcpyAsync(h->dFrames, xyz + static_cast<size_t>(done) * frameFloats, static_cast<size_t>(n) * frameFloats * 4,
+                           hipMemcpyHostToDevice, nullptr));
+    int rc = ssd_enqueue(h, h->dFrames, frameFloats * 4, n, nullptr);
+    if(rc) return rc;
+    rc = ssd_fetch(h, results + done, n, nullptr);
+    if(rc) return rc;
+    done += n;
+  }
+  return SSD_OK;
+}
+
+/* Stairs::serialize(), stairs.cpp:34-70: ["stairs",["stairSteps",N],[[["height",h],["quadrilateral",[x,y] x4]],...]]
+ * fixed notation, 3 decimals; the third element is omitted when N = 0. */
+int ssd_serialize(const ssd_frame_result *r, char *buf, size_t cap)
+{
+  if(!r || !buf || cap == 0)
+    return fail(SSD_E_ARG, "ssd_serialize: bad argument");
+  if(r->status & SSD_ST_THROW)
+  {
+    buf[0] = 0;
+    return 0;
+  }
+  std::string s;
+  s.reserve(128 + 160 * static_cast<size_t>(r->n_steps > 0 ? r->n_steps : 0));
+  char tmp[64];
+  auto num = [&](double v)
+  {
+    std::snprintf(tmp, sizeof(tmp), "%.3f", v);
+    s += tmp;
+  };
+  s += "[\"stairs\",[\"stairSteps\",";
+  s += std::to_string(r->n_steps);
+  s += ']';
+  if(r->n_steps > 0)
+  {
+    s += ",[";
+    for(int i = 0; i < r->n_steps; i++)
+    {
+      const ssd_step &st = r->steps[i];
+      if(i) s += ',';
+      s += "[[\"height\",";
+      num(st.height);
+      s += "],[\"quadrilateral\",";
+      for(int k = 0; k < 4; k++)
+      {
+        if(k) s += ',';
+        s += '[';
+        num(st.quad[2 * k]);
+        s += ',';
+        num(st.quad[2 * k + 1]);
+        s += ']';
+      }
+      s += "]]";
+    }
+    s += ']';
+  }
+  s += ']';
+  if(s.size() + 1 > cap)
+    return fail(SSD_E_CAP, "ssd_serialize: buffer too small");
+  std::memcpy(buf, s.c_str(), s.size() + 1);
+  return static_cast<int>(s.size());
+}
+
+int ssd_get_debug(ssd_handle *h, int frame, ssd_debug_frame *out)
+{
+  if(!h || !out)
+    return fail(SSD_E_ARG, "ssd_get_debug: null");
+  if(!h->dDebug || frame < 0 || frame >= h->lastFrames)
+    return fail(SSD_E_ARG, "ssd_get_debug: debug capture off or frame out of range");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, &h->dDebug[frame].d, sizeof(ssd_debug_frame), hipMemcpyDeviceToHost));
+  return SSD_OK;
+}
+
+int ssd_get_debug_image(ssd_handle *h, int frame, int step_slot, int closed, uint8_t *out)
+{
+  if(!h || !out)
+    return fail(SSD_E_ARG, "ssd_get_debug_image: null");
+  if(!h->dDebugImg || frame < 0 || frame >= h->lastFrames || step_slot < -1 || step_slot >= h->P.maxStepImages)
+    return fail(SSD_E_ARG, "ssd_get_debug_image: debug capture off or index out of range");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const int slot = step_slot < 0 ? h->P.maxStepImages : step_slot;
+  const unsigned long long *src = h->dDebugImg +
+    ((static_cast<size_t>(frame) * (h->P.maxStepImages + 1) + slot) * 2 + (closed ? 1 : 0)) * h->imgWords;
+  std::vector<unsigned long long> words(h->imgWords);
+  HIP_TRY(hipMemcpy(words.data(), src, h->imgWords * 8, hipMemcpyDeviceToHost));
+  const int W = h->P.W, H = h->P.H, W64 = h->P.W64;
+  for(int y = 0; y < H; y++)
+    for(int x = 0; x < W; x++)
+      out[static_cast<size_t>(y) * W + x] = ((words[static_cast<size_t>(y) * W64 + (x >> 6)] >> (x & 63)) & 1ull) ? 0xff : 0;
+  return SSD_OK;
+}
+
+/* ---- synthetic frame source ------------------------------------------------ */
+
+int ssd_synth_generate_host(const ssd_scene *scenes, int nframes, float *xyz)
+{
+  if(!scenes || !xyz || nframes < 1)
+    return fail(SSD_E_ARG, "ssd_synth_generate_host: bad argument");
+  size_t off = 0;
+  for(int f = 0; f < nframes; f++)
+  {
+    const ssd_scene &s = scenes[f];
+    if(s.width <= 0 || s.height <= 0)
+      return fail(SSD_E_ARG, "ssd_synth_generate_host: bad scene size");
+    const uint64_t key = synth_frame_key(s);
+    for(int v = 0; v < s.height; v++)
+      for(int u = 0; u < s.width; u++)
+      {
+        synth_pixel(s, key, u, v, xyz + off);
+        off += 3;
+      }
+  }
+  return SSD_OK;
+}
+
+int ssd_synth_generate_device(const ssd_scene *scenes, int nframes, void *d_xyz, size_t frame_stride_bytes, int device, void *stream)
+{
+  if(!scenes || !d_xyz || nframes < 1 || nframes > 65535)
+    return fail(SSD_E_ARG, "ssd_synth_generate_device: bad argument");
+  const int nPoints = scenes[0].width * scenes[0].height;
+  for(int f = 0; f < nframes; f++)
+    if(scenes[f].width != scenes[0].width || scenes[f].height != scenes[0].height)
+      return fail(SSD_E_ARG, "ssd_synth_generate_device: all scenes of a batch must share one resolution");
+  if(frame_stride_bytes < static_cast<size_t>(nPoints) * 12 || frame_stride_bytes % 4)
+    return fail(SSD_E_ARG, "ssd_synth_generate_device: bad stride");
+  if(ssd_device_count() <= 0)
+    return fail(SSD_E_NODEVICE, "ssd_synth_generate_device: no HIP device");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ssd_scene *dScenes = nullptr;
+  HIP_TRY(hipMalloc(&dScenes, sizeof(ssd_scene) * nframes));
+  hipError_t e = hipMemcpyAsync(dScenes, scenes, sizeof(ssd_scene) * nframes, hipMemcpyHostToDevice, s);
+  if(e == hipSuccess)
+  {
+    launch_synth(dScenes, static_cast<float *>(d_xyz), frame_stride_bytes / 4, nframes, nPoints, s);
+    e = hipGetLastError();
+  }
+  if(e == hipSuccess)
+    e = hipStreamSynchronize(s);
+  (void)hipFree(dScenes);
+  if(e != hipSuccess)
+    return fail(SSD_E_HIP, std::string("ssd_synth_generate_device: ") + hipGetErrorString(e));
+  return SSD_OK;
+}
+
+int ssd_synth_scene_to_camera(const ssd_scene *s, const double p[3], double out[3])
+{
+  if(!s || !p || !out)
+    return fail(SSD_E_ARG, "ssd_synth_scene_to_camera: null");
+  const double v[3] = { p[0], p[1], p[2] - s->cam_height };
+  out[0] = v[0] * s->axis_right[0] + v[1] * s->axis_right[1] + v[2] * s->axis_right[2];
+  out[1] = v[0] * s->axis_down[0] + v[1] * s->axis_down[1] + v[2] * s->axis_down[2];
+  out[2] = v[0] * s->axis_fwd[0] + v[1] * s->axis_fwd[1] + v[2] * s->axis_fwd[2];
+  return SSD_OK;
+}
+
+/* ---- plain device-memory helpers --------------------------------------------- */
+
+int ssd_device_alloc(int device, size_t bytes, void **d_ptr)
+{
+  if(!d_ptr)
+    return fail(SSD_E_ARG, "ssd_device_alloc: null");
+  if(ssd_device_count() <= 0)
+    return fail(SSD_E_NODEVICE, "ssd_device_alloc: no HIP device");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMalloc(d_ptr, bytes));
+  return SSD_OK;
+}
+int ssd_device_free(int device, void *d_ptr)
+{
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipFree(d_ptr));
+  return SSD_OK;
+}
+int ssd_device_upload(int device, void *d_dst, const void *src, size_t bytes)
+{
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+  return SSD_OK;
+}
+int ssd_device_download(int device, void *dst, const void *d_src, size_t bytes)
+{
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return SSD_OK;
+}
+int ssd_device_sync(int device)
+{
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipDeviceSynchronize());
+  return SSD_OK;
+}
+
+/* ---- test hooks ---------------------------------------------------------------- */
+
+/* hypot as the kernels compute it: on the host (no GPU needed) and on the device */
+double ssd_test_hypot_host(double a, double b)
+{
+  return hypot_ref_host(a, b);
+}
+int ssd_test_hypot_device(int device, const double *a, const double *b, double *out, int n)
+{
+  if(ssd_device_count() <= 0)
+    return fail(SSD_E_NODEVICE, "ssd_test_hypot_device: no HIP device");
+  HIP_TRY(hipSetDevice(device));
+  double *da = nullptr, *db = nullptr, *dout = nullptr;
+  HIP_TRY(hipMalloc(&da, 8 * static_cast<size_t>(n)));
+  HIP_TRY(hipMalloc(&db, 8 * static_cast<size_t>(n)));
+  HIP_TRY(hipMalloc(&dout, 8 * static_cast<size_t>(n)));
+  HIP_TRY(hipMemcpy(da, a, 8 * static_cast<size_t>(n), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, b, 8 * static_cast<size_t>(n), hipMemcpyHostToDevice));
+  launch_hypot(da, db, dout, n, nullptr);
+  HIP_TRY(hipMemcpy(out, dout, 8 * static_cast<size_t>(n), hipMemcpyDeviceToHost));
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+  return SSD_OK;
+}
+
+} // extern "C"

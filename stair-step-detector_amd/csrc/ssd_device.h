@@ -1,0 +1,92 @@
+/*
+ * ssd_device.h — device-side data layout shared by the kernels and the C ABI.
+ *
+ * HBM layout per handle (sized for max_frames_per_batch = F frames, S = max_step_plateaus):
+ *   FrameState  state[F]            per-frame histogram, plateau table, quad tests, accumulators, result
+ *   uint32_t    step_img[F][S][H][W32]   raw top-down bit images of the step plateaus (1 bit / pixel)
+ *   uint32_t    ground_img[F][H][W32]    raw bit image of the ground points inside the ground quadrilateral
+ *   DebugFrame  debug[F]            only when debug capture is on
+ * W32 = ceil(W/64)*2 32-bit words per image row (rows are padded to whole 64-bit words).
+ * Invariant: all bit images are zero between batches (the kernel that consumes an image clears it).
+ */
+#ifndef SSD_DEVICE_H_
+#define SSD_DEVICE_H_
+
+#include "../../include/ssd_hip.h"
+#include <hip/hip_runtime.h>
+
+namespace ssd
+{
+
+constexpr int kMaxBins = SSD_MAX_BINS;
+constexpr int kMaxPlateaus = SSD_MAX_PLATEAUS;
+constexpr int kMaxStepImages = SSD_MAX_STEP_IMAGES;
+constexpr int kGroundAcc = kMaxPlateaus;          /* accumulator slot of the ground quadrilateral */
+constexpr int kZFixShift = 40;                    /* mean z accumulates round(z * 2^40) in int64 */
+
+/* the four horizontal edges of a plateau outline, in this order everywhere (segmentation.cpp:585-589) */
+enum { kFL = 0, kFR = 1, kBL = 2, kBR = 3 };
+
+/* constants of one handle, passed by value as kernel argument */
+struct Params
+{
+  int W, H, W64;                 /* W64 = 64-bit words per image row */
+  int nPoints;
+  double a[9], b[3];
+  double r2[4], t2[2], worldZ;
+  double xMin, xMax, yMin, yMax, zMin, zMax;
+  double recip;                  /* 1 / heightInterval */
+  double xToImage, yToImage, xToWorld, yToWorld, xyRatio;
+  int nBins, minHeight, minImgYExtent;
+  int maxStepImages;
+};
+
+/* strict point-in-quadrilateral test prepared once per quadrilateral
+ * (reference quadrilateralTest.cpp:275-451: 3x3 cell map, <= 2 segments tested per cell) */
+struct QuadTest
+{
+  double bxLo, bxUp, byLo, byUp;
+  double segK[4], segC[4];
+  double yTrans[2];
+  double xTrans[3][2];
+  unsigned char segSteep[4], segLeftIfPositive[4];
+  unsigned char cellMask[3][3];    /* bit s set: segment s decides this cell */
+  unsigned char cellConst[3][3];   /* result of a cell without segments */
+  unsigned char nCells[3];
+  unsigned char nRows, insideIsLeft;
+  int err;                         /* 0 or the negative code of the reference's throw */
+};
+
+struct PlateauState
+{
+  int peakBin, binLo, binHi;       /* Plateau::height, chosen pair */
+  int effLo, effHi;                /* bins that feed this plateau */
+  int nPoints;
+  int isStep, outlineFound, valid;
+  double quadImg[8];
+  double quadWorld[8];
+};
+
+struct FrameState
+{
+  unsigned int hist[kMaxBins];
+  unsigned int nNonZero, nInRange, nOob, status;
+  int nPlateaus, firstStep, nStepImages, groundInd, firstValidInd;
+  int groundFrontValid;
+  unsigned char lut[kMaxBins];     /* bin -> plateau index, 0xff = none */
+  PlateauState pl[kMaxPlateaus];
+  double groundQuadWorld[8];
+  QuadTest qt[kMaxPlateaus + 1];   /* [kGroundAcc] = ground */
+  unsigned char accActive[kMaxPlateaus + 1];
+  long long sumZ[kMaxPlateaus + 1];
+  unsigned int cnt[kMaxPlateaus + 1];
+};
+
+struct DebugFrame
+{
+  ssd_debug_frame d;
+};
+
+} // namespace ssd
+
+#endif /* SSD_DEVICE_H_ */

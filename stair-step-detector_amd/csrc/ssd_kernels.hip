@@ -1,0 +1,1716 @@
+/*
+ * ssd_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the per-frame point-cloud path.
+ *
+ * Pipeline over a batch of F frames resident in HBM (grid.y = frame everywhere):
+ *   K1 k_hist      transform + crop + 1 cm height bin + histogram      (pointcloud.cpp:122-204)
+ *   K1b k_peaks    peaks, filter, plateau pairs, bin->plateau LUT      (pointcloud.cpp:214-343, 399-418)
+ *   K2 k_raster    top-down bit images of the step plateaus            (pointcloud.cpp:458-471)
+ *   K3 k_outline   3x3 close + scans + best lines + corners            (segmentation.cpp:919-971)
+ *   K3b k_quads    ground quadrilateral, point-in-quad tests           (pointcloud.cpp:431-443,489-512; quadrilateralTest.cpp:275-443)
+ *   K4 k_inquad    in-quad filter, z sums, ground image                (pointcloud.cpp:560-581, 530-531)
+ *   K5 k_final     ground front edge, mean z, ToExternalWorld, result  (segmentation.cpp:879-917; pointcloud.cpp:532-547, 370-383)
+ *
+ * All floating-point work is fp64 with contraction off (the file is compiled with
+ * -ffp-contract=off): the reference is built without FMA (CMakeLists.txt:23-28) and one
+ * flipped bin or pixel moves a corner by more than the parity bar.
+ * K1/K2/K4 are HBM-read bound (12 B per raw point); no MFMA anywhere.
+ */
+#include "ssd_device.h"
+#include "ssd_synth.h"
+
+namespace ssd
+{
+
+/* ========================================================================= */
+/* shared per-point arithmetic                                                */
+
+struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+
+/* CameraToWorld (transformation.h:59-64, 79-87): a*x + b, float promoted to double,
+ * row sums left to right, then the translation; followed by the six strict range
+ * compares of getPointsInRange (pointcloud.cpp:150-165). */
+__device__ __forceinline__ bool world_point(const Params &P, const F3 &v, double &wx, double &wy, double &wz)
+{
+  if(!(v.z > 0.0f))                                   /* pointcloud.cpp:143-146 */
+    return false;
+  const double x = v.x, y = v.y, z = v.z;
+  wx = (P.a[0] * x + P.a[1] * y) + P.a[2] * z;
+  wy = (P.a[3] * x + P.a[4] * y) + P.a[5] * z;
+  wz = (P.a[6] * x + P.a[7] * y) + P.a[8] * z;
+  wx = wx + P.b[0];
+  wy = wy + P.b[1];
+  wz = wz + P.b[2];
+  return wx > P.xMin && wx < P.xMax && wy > P.yMin && wy < P.yMax && wz > P.zMin && wz < P.zMax;
+}
+
+/* calcHeights (pointcloud.cpp:175): truncating conversion, value is in [0, nBins) */
+__device__ __forceinline__ int height_bin(const Params &P, double wz)
+{
+  return static_cast<int>((wz - P.zMin) * P.recip);
+}
+
+/* ========================================================================= */
+/* K1: histogram                                                              */
+
+constexpr int kThreads = 256;
+constexpr int kPts = 4;                 /* points per thread per iteration */
+constexpr int kTile = kThreads * kPts;  /* 1024 points per block iteration */
+
+/* Adds one vote per valid lane to a wave-private LDS histogram.  Equal bins inside the wave
+ * (the common case: a camera row sweeps one plateau) are merged with ballots so that one lane
+ * issues one ds_add per distinct bin; after kMaxDistinct rounds the rest falls back to per-lane
+ * LDS atomics. */
+__device__ __forceinline__ void wave_hist_add(unsigned int *h, const int (&bin)[kPts], int lane)
+{
+  constexpr int kMaxDistinct = 12;
+  unsigned long long act[kPts];
+#pragma unroll
+  for(int j = 0; j < kPts; j++)
+    act[j] = __ballot(bin[j] >= 0);
+
+  for(int round = 0; ; round++)
+  {
+    int j0 = -1;
+#pragma unroll
+    for(int j = kPts - 1; j >= 0; j--)
+      if(act[j]) j0 = j;
+    if(j0 < 0)
+      break;
+    if(round == kMaxDistinct)
+    {
+#pragma unroll
+      for(int j = 0; j < kPts; j++)
+        if((act[j] >> lane) & 1ull)
+          atomicAdd(&h[bin[j]], 1u);
+      break;
+    }
+    int src = bin[0];
+    unsigned long long a0 = act[0];
+#pragma unroll
+    for(int j = 1; j < kPts; j++)
+      if(j == j0) { src = bin[j]; a0 = act[j]; }
+    const int leader = __ffsll(static_cast<long long>(a0)) - 1;
+    const int b = __builtin_amdgcn_readlane(src, leader);
+    unsigned int cnt = 0;
+#pragma unroll
+    for(int j = 0; j < kPts; j++)
+    {
+      const unsigned long long m = __ballot(bin[j] == b);
+      cnt += static_cast<unsigned int>(__popcll(m));
+      act[j] &= ~m;
+    }
+    if(lane == 0)
+      atomicAdd(&h[b], cnt);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_hist(const float *__restrict__ xyz, size_t strideFloats, Params P,
+                                                   FrameState *__restrict__ st, int chunkPoints)
+{
+  __shared__ unsigned int lh[kThreads / 64][kMaxBins];
+  __shared__ unsigned int lNonZero;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frame = blockIdx.y;
+  const float *base = xyz + static_cast<size_t>(frame) * strideFloats;
+  const int begin = blockIdx.x * chunkPoints;
+  const int end = min(begin + chunkPoints, P.nPoints);
+
+  for(int i = tid; i < (kThreads / 64) * kMaxBins; i += kThreads)
+    (&lh[0][0])[i] = 0;
+  if(tid == 0)
+    lNonZero = 0;
+  __syncthreads();
+
+  unsigned int nz = 0;
+  for(int i0 = begin; i0 < end; i0 += kTile)
+  {
+    F3 v[kPts];
+#pragma unroll
+    for(int j = 0; j < kPts; j++)
+    {
+      const int idx = i0 + j * kThreads + tid;
+      v[j] = F3{ 0.0f, 0.0f, 0.0f };
+      if(idx < end)
+        v[j] = *reinterpret_cast<const F3 *>(base + 3 * static_cast<size_t>(idx));
+    }
+    int bin[kPts];
+#pragma unroll
+    for(int j = 0; j < kPts; j++)
+    {
+      double wx, wy, wz;
+      nz += v[j].z > 0.0f ? 1u : 0u;
+      bin[j] = world_point(P, v[j], wx, wy, wz) ? height_bin(P, wz) : -1;
+    }
+    wave_hist_add(lh[wave], bin, lane);
+  }
+
+  /* wave-reduce the non-zero count */
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1)
+    nz += __shfl_down(nz, o);
+  if(lane == 0 && nz)
+    atomicAdd(&lNonZero, nz);
+  __syncthreads();
+
+  FrameState &fs = st[frame];
+  for(int b = tid; b < P.nBins; b += kThreads)
+  {
+    unsigned int s = 0;
+#pragma unroll
+    for(int w = 0; w < kThreads / 64; w++)
+      s += lh[w][b];
+    if(s)
+      atomicAdd(&fs.hist[b], s);
+  }
+  if(tid == 0 && lNonZero)
+    atomicAdd(&fs.nNonZero, lNonZero);
+}
+
+/* ========================================================================= */
+/* K1b: peaks, plateaus, LUT — one thread per frame (121 bins: trivial)        */
+
+__global__ void k_peaks(Params P, FrameState *__restrict__ st, int nframes, DebugFrame *__restrict__ dbg)
+{
+  const int frame = blockIdx.x * blockDim.x + threadIdx.x;
+  if(frame >= nframes)
+    return;
+  FrameState &fs = st[frame];
+  const unsigned int *hist = fs.hist;
+  const int nb = P.nBins;
+
+  unsigned int total = 0;
+  for(int i = 0; i < nb; i++)
+    total += hist[i];
+  fs.nInRange = total;
+  for(int i = 0; i < kMaxBins; i++)
+    fs.lut[i] = 0xff;
+
+  /* findPeaks (pointcloud.cpp:214-241) + filterPeaks (:243-256) */
+  int nPl = 0;
+  int consumedUpTo = -1;           /* every bin <= this has already left pointsHt */
+  bool ascending = false, overflow = false;
+  int nPeaksDbg = 0;
+  for(int i = 0; i < nb - 1; i++)
+  {
+    const unsigned int curr = hist[i], succ = hist[i + 1];
+    if(curr < succ)
+    {
+      ascending = true;
+      continue;
+    }
+    if(curr > succ)
+    {
+      if(ascending)
+      {
+        const unsigned int np = curr;
+        if(np >= 2000u && (np * 2u - hist[i - 1] - hist[i + 1]) * 2u > np)
+        {
+          if(dbg && nPeaksDbg < kMaxPlateaus)
+            dbg[frame].d.peaks[nPeaksDbg] = i;
+          nPeaksDbg++;
+          if(nPl >= kMaxPlateaus)
+            overflow = true;
+          else
+          {
+            /* extractPlateauPoints (:300-335): choose the pair, then take what is left of it */
+            PlateauState &pl = fs.pl[nPl];
+            int hMin, hMax;
+            if(hist[i - 1] > hist[i + 1]) { hMin = i - 1; hMax = i; }
+            else { hMin = i; hMax = i + 1; }
+            pl.peakBin = i;
+            pl.binLo = hMin;
+            pl.binHi = hMax;
+            int lo, hi;
+            if(hMin == 0)
+            {
+              /* quirk Q4: Height_t(heightMin - 1) wraps to 65535: everything goes to the remainder */
+              lo = 1; hi = 0;
+              consumedUpTo = nb;
+            }
+            else
+            {
+              lo = max(hMin, consumedUpTo + 1);
+              hi = hMax;
+              consumedUpTo = max(consumedUpTo, hMax);
+            }
+            pl.effLo = lo;
+            pl.effHi = hi;
+            unsigned int cnt = 0;
+            for(int b = lo; b <= hi; b++)
+            {
+              cnt += hist[b];
+              fs.lut[b] = static_cast<unsigned char>(nPl);
+            }
+            pl.nPoints = static_cast<int>(cnt);
+            pl.isStep = i >= P.minHeight ? 1 : 0;
+            pl.outlineFound = 0;
+            pl.valid = 0;
+            for(int k = 0; k < 8; k++) { pl.quadImg[k] = 0.0; pl.quadWorld[k] = 0.0; }
+            nPl++;
+          }
+        }
+      }
+      ascending = false;
+    }
+  }
+  fs.nPlateaus = nPl;
+
+  /* ground = most populous plateau below minHeight (pointcloud.cpp:402-418) */
+  int groundInd = -1, i = 0;
+  unsigned int maxGround = 0;
+  for( ; i < nPl; i++)
+  {
+    if(fs.pl[i].peakBin >= P.minHeight)
+      break;
+    if(maxGround < static_cast<unsigned int>(fs.pl[i].nPoints))
+    {
+      maxGround = static_cast<unsigned int>(fs.pl[i].nPoints);
+      groundInd = i;
+    }
+  }
+  fs.groundInd = groundInd;
+  fs.firstStep = i;
+  int nImg = nPl - i;
+  if(nImg > P.maxStepImages)
+  {
+    nImg = P.maxStepImages;
+    overflow = true;
+  }
+  fs.nStepImages = nImg;
+  fs.firstValidInd = -1;
+  if(overflow)
+    fs.status |= SSD_ST_OVERFLOW;
+
+  if(dbg)
+  {
+    ssd_debug_frame &d = dbg[frame].d;
+    d.n_nonzero = static_cast<int>(fs.nNonZero);
+    d.n_inrange = static_cast<int>(total);
+    d.n_bins = nb;
+    d.min_height = P.minHeight;
+    d.min_img_y_extent = P.minImgYExtent;
+    for(int b = 0; b < kMaxBins; b++)
+      d.hist[b] = b < nb ? hist[b] : 0u;
+    d.n_peaks = nPeaksDbg;
+    d.n_plateaus = nPl;
+    d.first_step = i;
+    d.ground_ind = groundInd;
+    for(int k = 0; k < nPl; k++)
+    {
+      ssd_debug_plateau &p = d.plateaus[k];
+      p.peak_bin = fs.pl[k].peakBin; p.bin_lo = fs.pl[k].binLo; p.bin_hi = fs.pl[k].binHi;
+      p.eff_lo = fs.pl[k].effLo; p.eff_hi = fs.pl[k].effHi;
+      p.n_points = fs.pl[k].nPoints;
+      p.is_step = fs.pl[k].isStep;
+    }
+  }
+}
+
+/* ========================================================================= */
+/* K2: raster the step plateaus into bit images                               */
+
+__global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ xyz, size_t strideFloats, Params P,
+                                                     FrameState *__restrict__ st, unsigned int *__restrict__ stepImg,
+                                                     int chunkPoints)
+{
+  __shared__ unsigned char lut[kMaxBins];
+  __shared__ unsigned int lOob;
+
+  const int tid = threadIdx.x;
+  const int frame = blockIdx.y;
+  FrameState &fs = st[frame];
+  const int nImg = fs.nStepImages;
+  if(nImg == 0)
+    return;
+  const int firstStep = fs.firstStep;
+  if(tid < kMaxBins)
+    lut[tid] = fs.lut[tid];
+  if(tid == 0)
+    lOob = 0;
+  __syncthreads();
+
+  const float *base = xyz + static_cast<size_t>(frame) * strideFloats;
+  const int begin = blockIdx.x * chunkPoints;
+  const int end = min(begin + chunkPoints, P.nPoints);
+  const int W32 = P.W64 * 2;
+  const size_t imgWords = static_cast<size_t>(P.H) * W32;
+  unsigned int *frameImg = stepImg + static_cast<size_t>(frame) * P.maxStepImages * imgWords;
+  unsigned int oob = 0;
+
+  for(int i0 = begin; i0 < end; i0 += kTile)
+  {
+    F3 v[kPts];
+#pragma unroll
+    for(int j = 0; j < kPts; j++)
+    {
+      const int idx = i0 + j * kThreads + tid;
+      v[j] = F3{ 0.0f, 0.0f, 0.0f };
+      if(idx < end)
+        v[j] = *reinterpret_cast<const F3 *>(base + 3 * static_cast<size_t>(idx));
+    }
+#pragma unroll
+    for(int j = 0; j < kPts; j++)
+    {
+      double wx, wy, wz;
+      if(!world_point(P, v[j], wx, wy, wz))
+        continue;
+      const int slot = static_cast<int>(lut[height_bin(P, wz)]) - firstStep;   /* 0xff - firstStep >= nImg */
+      if(slot < 0 || slot >= nImg)
+        continue;
+      /* Projection2D::worldToImage (pointcloud.cpp:79-83) */
+      const int ix = static_cast<int>((wx - P.xMin) * P.xToImage);
+      const int iy = static_cast<int>((P.yMax - wy) * P.yToImage);
+      if(ix < 0 || ix >= P.W || iy < 0 || iy >= P.H)
+      {
+        oob++;                                              /* quirk Q5 */
+        continue;
+      }
+      atomicOr(frameImg + slot * imgWords + static_cast<size_t>(iy) * W32 + (ix >> 5), 1u << (ix & 31));
+    }
+  }
+  if(oob)
+    atomicAdd(&lOob, oob);
+  __syncthreads();
+  if(tid == 0 && lOob)
+  {
+    atomicAdd(&fs.nOob, lOob);
+    atomicOr(&fs.status, static_cast<unsigned int>(SSD_ST_OOB_PIXEL));
+  }
+}
+
+/* ========================================================================= */
+/* bit-image morphology: closed word computed on the fly                      */
+
+struct BitImg
+{
+  const unsigned long long *w;   /* H rows of W64 words; bit i of word c is pixel x = 64c + i */
+  int W, H, W64;
+};
+
+__device__ __forceinline__ unsigned long long raw_word(const BitImg &im, int y, int c)
+{
+  return (y >= 0 && y < im.H && c >= 0 && c < im.W64) ? im.w[static_cast<size_t>(y) * im.W64 + c] : 0ull;
+}
+
+/* word c of row y of the image after cv::morphologyEx(MORPH_CLOSE, 3x3 rect, 1 iteration, default
+ * border): dilation = OR over the in-image 3x3 neighbours, erosion = AND over them (pixels outside
+ * the image never win; segmentation.cpp:888,928).  Needs raw rows y-2..y+2, words c-1..c+1. */
+__device__ unsigned long long closed_word(const BitImg &im, int y, int c)
+{
+  unsigned long long hc[5];
+  unsigned int hl[5], hr[5];
+#pragma unroll
+  for(int r = 0; r < 5; r++)
+  {
+    const int yy = y - 2 + r;
+    const unsigned long long L = raw_word(im, yy, c - 1), w = raw_word(im, yy, c), R = raw_word(im, yy, c + 1);
+    hc[r] = w | (w << 1) | (w >> 1) | (L >> 63) | (R << 63);
+    hl[r] = static_cast<unsigned int>(((L >> 63) | (L >> 62) | w) & 1ull);        /* dilated pixel x = 64c-1 */
+    hr[r] = static_cast<unsigned int>((R | (R >> 1) | (w >> 63)) & 1ull);         /* dilated pixel x = 64c+64 */
+  }
+  const int rem = im.W - 64 * c;
+  const unsigned long long vm = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);        /* pixels of this word inside the image */
+  unsigned long long res = vm;
+#pragma unroll
+  for(int r = 0; r < 3; r++)
+  {
+    const int yy = y - 1 + r;
+    if(yy < 0 || yy >= im.H)
+      continue;                                   /* row outside the image: ignored by the erosion */
+    unsigned long long dc = hc[r] | hc[r + 1] | hc[r + 2];
+    unsigned int dl = hl[r] | hl[r + 1] | hl[r + 2];
+    unsigned int dr = hr[r] | hr[r + 1] | hr[r + 2];
+    dc |= ~vm;
+    if(c == 0) dl = 1u;
+    if(rem <= 64) dr = 1u;
+    res &= dc & ((dc << 1) | dl) & ((dc >> 1) | (static_cast<unsigned long long>(dr) << 63));
+  }
+  return res;
+}
+
+/* ========================================================================= */
+/* small fp64 helpers that must match the host libm bit for bit                */
+
+/* std::hypot as glibc 2.35 computes it without FMA (sysdeps/ieee754/dbl-64/e_hypot.c): the oracle
+ * calls the host's hypot, the device restates the published algorithm; tests/test_oracle.py checks
+ * the two agree on this image. */
+__host__ __device__ inline double hypot_kernel(double ax, double ay)
+{
+  double t1, t2;
+  double h = sqrt(ax * ax + ay * ay);
+  if(h <= 2.0 * ay)
+  {
+    const double delta = h - ay;
+    t1 = ax * (2.0 * delta - ax);
+    t2 = (delta - 2.0 * (ax - ay)) * delta;
+  }
+  else
+  {
+    const double delta = h - ax;
+    t1 = 2.0 * delta * (ax - 2.0 * ay);
+    t2 = (4.0 * delta - ay) * ay + delta * delta;
+  }
+  h -= (t1 + t2) / (2.0 * h);
+  return h;
+}
+
+__host__ __device__ inline double hypot_ref(double x, double y)
+{
+  const double kScale = 0x1p-600, kLarge = 0x1p+511, kTiny = 0x1p-459, kEps = 0x1p-54;
+  x = fabs(x);
+  y = fabs(y);
+  double ax = x < y ? y : x;
+  double ay = x < y ? x : y;
+  if(ax > kLarge)
+  {
+    if(ay <= ax * kEps)
+      return ax + ay;
+    return hypot_kernel(ax * kScale, ay * kScale) / kScale;
+  }
+  if(ay < kTiny)
+  {
+    if(ax >= ay / kEps)
+      return ax + ay;
+    return hypot_kernel(ax / kScale, ay / kScale) * kScale;
+  }
+  if(ax * kEps >= ay)
+    return ax + ay;
+  return hypot_kernel(ax, ay);
+}
+
+struct LineD { double a, b, c; };
+struct LineI { int a, b, c; };
+
+/* LineCoordinates(p, q), types.h:140-158 */
+__device__ __forceinline__ LineI line_through_i(int x1, int y1, int x2, int y2)
+{
+  return { y2 - y1, x1 - x2, x2 * y1 - x1 * y2 };
+}
+__device__ __forceinline__ LineD line_through_d(double x1, double y1, double x2, double y2)
+{
+  return { y2 - y1, x1 - x2, x2 * y1 - x1 * y2 };
+}
+/* Line<double>::normalized, segmentation.cpp:383-387 */
+__device__ __forceinline__ LineD normalized_line(double a, double b, double c)
+{
+  const double h = hypot_ref(a, b);
+  return { a / h, b / h, c / h };
+}
+/* Line<double>::intersection, segmentation.cpp:344-362; returns false for angles <= 60 degrees */
+__device__ __forceinline__ bool intersect60(const LineD &l, const LineD &o, double &x, double &y)
+{
+  const double kTan60 = 1.7320508075688772;       /* std::numbers::sqrt3 */
+  const double numerator = l.a * o.b - o.a * l.b;
+  const double denominator = l.a * o.a + l.b * o.b;
+  if(fabs(numerator) > fabs(denominator) * kTan60)
+  {
+    x = (l.b * o.c - o.b * l.c) / numerator;
+    y = (o.a * l.c - l.a * o.c) / numerator;
+    return true;
+  }
+  return false;
+}
+
+/* ========================================================================= */
+/* BestLine (segmentation.cpp:409-487), one wave per point list                */
+
+/* residual of the line through points p and q: sum of the n smallest |a x + b y + c| of the other
+ * points, over n * hypot(a, b) */
+__device__ double line_residual(const int *px, const int *py, int m, int p, int q, LineI &line)
+{
+  line = line_through_i(px[p], py[p], px[q], py[q]);
+  if(m <= 2)
+    return 0.0;
+  const int nd = m - 2;
+  const int n = nd > 4 ? (nd - 1) / 2 : 1;
+  /* n rounds of "next smallest (distance, index)" — no per-lane storage */
+  int sum = 0;
+  int lastD = -1, lastI = -1;
+  for(int r = 0; r < n; r++)
+  {
+    int bestD = 0x7fffffff, bestI = 0x7fffffff;
+    for(int i = 0; i < m; i++)
+    {
+      if(i == p || i == q)
+        continue;
+      const int d = abs(px[i] * line.a + py[i] * line.b + line.c);
+      const bool after = d > lastD || (d == lastD && i > lastI);
+      const bool better = d < bestD || (d == bestD && i < bestI);
+      if(after && better) { bestD = d; bestI = i; }
+    }
+    sum += bestD;
+    lastD = bestD;
+    lastI = bestI;
+  }
+  return sum / (n * hypot_ref(static_cast<double>(line.a), static_cast<double>(line.b)));
+}
+
+/* all 64 lanes of the calling wave take part; result is returned in every lane */
+__device__ LineI wave_best_line(const int *px, const int *py, int m, int lane)
+{
+  const int nPairs = m * (m - 1) / 2;
+  double bestRes = 1.0e300;
+  int bestT = 0x7fffffff;
+  LineI bestLine{ 0, 0, 0 };
+  for(int t = lane; t < nPairs; t += 64)
+  {
+    /* decode pair t in the order of the reference's double loop (p ascending, q > p ascending) */
+    int p = 0, rem = t;
+    while(rem >= m - 1 - p)
+    {
+      rem -= m - 1 - p;
+      p++;
+    }
+    const int q = p + 1 + rem;
+    LineI l;
+    const double r = line_residual(px, py, m, p, q, l);
+    if(bestT == 0x7fffffff || r < bestRes)     /* min_element: first of equal minima (t ascends per lane) */
+    {
+      bestRes = r;
+      bestT = t;
+      bestLine = l;
+    }
+  }
+  /* butterfly: smallest residual, ties to the smaller pair index */
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1)
+  {
+    const double oRes = __shfl_xor(bestRes, o);
+    const int oT = __shfl_xor(bestT, o);
+    const int oa = __shfl_xor(bestLine.a, o), ob = __shfl_xor(bestLine.b, o), oc = __shfl_xor(bestLine.c, o);
+    const bool mineValid = bestT != 0x7fffffff, otherValid = oT != 0x7fffffff;
+    const bool take = otherValid && (!mineValid || oRes < bestRes || (oRes == bestRes && oT < bestT));
+    if(take)
+    {
+      bestRes = oRes; bestT = oT; bestLine.a = oa; bestLine.b = ob; bestLine.c = oc;
+    }
+  }
+  return bestLine;
+}
+
+/* ========================================================================= */
+/* K3: outline of one step plateau image — one workgroup per (slot, frame)      */
+
+constexpr int kMaxCols = SSD_MAX_SCANS;      /* scan columns per image (W/25 + 1 <= 128) */
+constexpr int kMaxProbe = SSD_MAX_EDGE_PTS;  /* probe rows per vertical edge (H/10 + 1 <= 256) */
+
+struct OutlineShared
+{
+  int yFirst[kMaxCols], ySecond[kMaxCols];
+  int ex[4][kMaxCols], ey[4][kMaxCols];      /* the four point lists: FL, FR, BL, BR */
+  int en[4];
+  LineI line[4];
+  int nRight, nLeft;
+  int found;
+  /* vertical edges */
+  int vActive[2], vLeft[2], vRight[2], vYStart[2], vYEnd[2], vProbe[2];
+  int vx[2][kMaxProbe];
+  int vpx[2][kMaxProbe], vpy[2][kMaxProbe], vn[2];
+  double vdist[2][kMaxProbe];
+  int vBest[2];
+  LineD baseLine;
+  double bounds[4][2][2];
+  unsigned int status;
+};
+
+__global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__restrict__ st,
+                                                      unsigned long long *__restrict__ stepImg,
+                                                      DebugFrame *__restrict__ dbg,
+                                                      unsigned long long *__restrict__ dbgImg)
+{
+  __shared__ OutlineShared S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slot = blockIdx.x, frame = blockIdx.y;
+  FrameState &fs = st[frame];
+  if(slot >= fs.nStepImages)
+    return;
+  const int plIdx = fs.firstStep + slot;
+  PlateauState &pl = fs.pl[plIdx];
+  ssd_debug_plateau *dp = dbg ? &dbg[frame].d.plateaus[plIdx] : nullptr;
+
+  const size_t imgWords = static_cast<size_t>(P.H) * P.W64;
+  unsigned long long *img = stepImg + (static_cast<size_t>(frame) * P.maxStepImages + slot) * imgWords;
+  const BitImg im{ img, P.W, P.H, P.W64 };
+
+  /* scan columns: x_j = xr0 + 25 j; the centre column xc = W/2 is j = jc */
+  const int xStep = 25;
+  const int xc = P.W / 2;
+  const int xr0 = xc % xStep;
+  const int jc = xc / xStep;
+  const int nCols = min(kMaxCols, (P.W - 1 - xr0) / xStep + 1);
+
+  for(int j = tid; j < kMaxCols; j += kThreads)
+  {
+    S.yFirst[j] = 0x7fffffff;
+    S.ySecond[j] = -1;
+  }
+  if(tid == 0)
+  {
+    S.found = 0;
+    S.status = 0;
+    S.nRight = S.nLeft = 0;
+    S.vActive[0] = S.vActive[1] = 0;
+    S.vn[0] = S.vn[1] = 0;
+    S.vProbe[0] = S.vProbe[1] = 0;
+  }
+  __syncthreads();
+
+  /* ---- phase B: closed image, column extents (Scanner::probeVertical, segmentation.cpp:88-111) ---- */
+  unsigned long long *dbgRaw = nullptr, *dbgClosed = nullptr;
+  if(dbgImg)
+  {
+    dbgRaw = dbgImg + ((static_cast<size_t>(frame) * (P.maxStepImages + 1) + slot) * 2) * imgWords;
+    dbgClosed = dbgRaw + imgWords;
+  }
+  for(int idx = tid; idx < P.H * P.W64; idx += kThreads)
+  {
+    const int y = idx / P.W64, c = idx - y * P.W64;
+    const unsigned long long cw = closed_word(im, y, c);
+    if(dbgImg)
+    {
+      dbgRaw[idx] = img[idx];
+      dbgClosed[idx] = cw;
+    }
+    if(cw == 0ull)
+      continue;
+    const int x0 = 64 * c;
+    int j = x0 <= xr0 ? 0 : (x0 - xr0 + xStep - 1) / xStep;
+    for(int x = xr0 + xStep * j; x < x0 + 64 && j < nCols; x += xStep, j++)
+      if((cw >> (x - x0)) & 1ull)
+      {
+        atomicMin(&S.yFirst[j], y);
+        atomicMax(&S.ySecond[j], y);
+      }
+  }
+  __syncthreads();
+
+  /* ---- phase C: scans (Scanner::scan :59-85, HorizontalEdgesDetector::detect :607-620),
+   *      point lists (Scanner::obtainLinePoints :129-156) ---- */
+  if(tid == 0)
+  {
+    int nR = 0, nL = 0;
+    for(int j = jc; j < nCols; j++)
+    {
+      if(S.ySecond[j] < 0) break;
+      if(S.ySecond[j] - S.yFirst[j] < P.minImgYExtent) break;
+      nR++;
+    }
+    if(nR > 0)
+      for(int j = jc - 1; j >= 0; j--)
+      {
+        if(S.ySecond[j] < 0) break;
+        if(S.ySecond[j] - S.yFirst[j] < P.minImgYExtent) break;
+        nL++;
+      }
+    S.nRight = nR;
+    S.nLeft = nL;
+    if(nR > 0 && nR + nL >= 3)
+    {
+      S.found = 1;
+      /* scan s of the right list is column jc + s, of the left list column jc - 1 - s */
+      int n[4] = { 0, 0, 0, 0 };
+      auto push = [&](bool toRight, int j)
+      {
+        const int x = xr0 + xStep * j;
+        const int f = toRight ? kFR : kFL, b = toRight ? kBR : kBL;
+        S.ex[f][n[f]] = x; S.ey[f][n[f]] = S.ySecond[j]; n[f]++;
+        S.ex[b][n[b]] = x; S.ey[b][n[b]] = S.yFirst[j]; n[b]++;
+      };
+      const int total = nR + nL;
+      const int half = total / 2 + 1;
+      int indLeft = 0, indRight = 0;
+      if(nL >= half)
+      {
+        indLeft = nL - half;
+        for(int i = indLeft; i >= 0; i--)
+          push(true, jc - 1 - i);
+      }
+      else
+      {
+        if(nR > half)
+          indRight = nR - half;
+        for(int i = indRight; i >= 0; i--)
+          push(false, jc + i);
+      }
+      for( ; indRight < nR; indRight++)
+        push(true, jc + indRight);
+      for( ; indLeft < nL; indLeft++)
+        push(false, jc - 1 - indLeft);
+      for(int e = 0; e < 4; e++)
+        S.en[e] = n[e];
+    }
+  }
+  __syncthreads();
+
+  if(dp && tid == 0)
+  {
+    dp->n_scans_right = S.nRight;
+    dp->n_scans_left = S.nLeft;
+    for(int s = 0; s < S.nRight; s++)
+    { dp->scans_right[s][0] = xr0 + xStep * (jc + s); dp->scans_right[s][1] = S.yFirst[jc + s]; dp->scans_right[s][2] = S.ySecond[jc + s]; }
+    for(int s = 0; s < S.nLeft; s++)
+    { dp->scans_left[s][0] = xr0 + xStep * (jc - 1 - s); dp->scans_left[s][1] = S.yFirst[jc - 1 - s]; dp->scans_left[s][2] = S.ySecond[jc - 1 - s]; }
+  }
+
+  if(S.found)
+  {
+    /* ---- BestLine per horizontal edge: wave w takes edge w (HorizontalEdges::Edge :570-583) ---- */
+    {
+      const LineI l = wave_best_line(S.ex[wave], S.ey[wave], S.en[wave], lane);
+      if(lane == 0)
+        S.line[wave] = l;
+    }
+    __syncthreads();
+
+    /* ---- BoundaryPoints (:521-552), base line (:672-679), detectEdge windows (:681-697) ---- */
+    if(tid == 0)
+    {
+      for(int e = 0; e < 4; e++)
+      {
+        const LineI l = S.line[e];
+        const double fm = static_cast<double>(-l.a) / l.b;       /* FlatLine :508-511 */
+        const double fn = static_cast<double>(-l.c) / l.b;
+        double in[2] = { -1.0, -1.0 }, out[2] = { -1.0, -1.0 };
+        for(int i = 0; i < S.en[e]; i++)
+        {
+          const double yy = S.ex[e][i] * fm + fn;
+          if(fabs(yy - S.ey[e][i]) < 10)
+          {
+            in[0] = S.ex[e][i]; in[1] = yy;
+            break;
+          }
+        }
+        for(int i = S.en[e] - 1; i >= 0; i--)
+        {
+          const double yy = S.ex[e][i] * fm + fn;
+          if(fabs(yy - S.ey[e][i]) < 10)
+          {
+            out[0] = S.ex[e][i]; out[1] = yy;
+            break;
+          }
+        }
+        if((in[0] == -1.0 && in[1] == -1.0) || (out[0] == -1.0 && out[1] == -1.0))
+          S.status |= SSD_ST_ASSERT;
+        S.bounds[e][0][0] = in[0]; S.bounds[e][0][1] = in[1];
+        S.bounds[e][1][0] = out[0]; S.bounds[e][1][1] = out[1];
+      }
+      /* calcBaseLine: bisectors of (reversed left, right) front and back lines, then of those two;
+       * slope-corrected by xyRatio^2, perpendicular through the first front-left point */
+      const LineI fl = S.line[kFL], frl = S.line[kFR], bl = S.line[kBL], brl = S.line[kBR];
+      const LineD nfl = normalized_line(-fl.a, -fl.b, -fl.c), nfr = normalized_line(frl.a, frl.b, frl.c);
+      const LineD front{ nfl.a + nfr.a, nfl.b + nfr.b, nfl.c + nfr.c };
+      const LineD nbl = normalized_line(-bl.a, -bl.b, -bl.c), nbr = normalized_line(brl.a, brl.b, brl.c);
+      const LineD back{ nbl.a + nbr.a, nbl.b + nbr.b, nbl.c + nbr.c };
+      const LineD nf = normalized_line(front.a, front.b, front.c), nb = normalized_line(back.a, back.b, back.c);
+      const LineD center{ nf.a + nb.a, nf.b + nb.b, nf.c + nb.c };
+      const double corr = P.xyRatio * P.xyRatio;
+      const double sa = center.a * corr, sb = center.b;
+      const int p0x = S.ex[kFL][0], p0y = S.ey[kFL][0];
+      S.baseLine = LineD{ -sb, sa, sb * p0x - sa * p0y };
+
+      for(int side = 0; side < 2; side++)
+      {
+        const int fe = side == 0 ? kFL : kFR, be = side == 0 ? kBL : kBR;
+        const double fx = S.bounds[fe][1][0], fy = S.bounds[fe][1][1];
+        const double bx = S.bounds[be][1][0], by = S.bounds[be][1][1];
+        int lft = static_cast<int>(fmin(fx, bx) - xStep);
+        int rgt = static_cast<int>(fmax(fx, bx) + xStep);
+        int yStart = static_cast<int>(fy - 10);
+        int yEnd = static_cast<int>(by + 10);
+        if(lft < 0) lft = 0;
+        if(rgt >= P.W) rgt = P.W - 1;
+        if(yStart >= P.H) yStart = P.H - 1;
+        if(yEnd < 0) yEnd = 0;
+        if(yStart < yEnd)
+          continue;
+        if(rgt - lft <= 0)
+        {
+          S.status |= SSD_ST_ASSERT;
+          continue;
+        }
+        int np = (yStart - yEnd) / 10 + 1;
+        if(np > kMaxProbe)
+        {
+          np = kMaxProbe;
+          S.status |= SSD_ST_OVERFLOW;
+        }
+        S.vActive[side] = 1;
+        S.vLeft[side] = lft; S.vRight[side] = rgt; S.vYStart[side] = yStart; S.vYEnd[side] = yEnd;
+        S.vProbe[side] = np;
+      }
+    }
+    __syncthreads();
+
+    /* ---- phase D: row probes (VerticalEdgePointsDetector :243-312) on freshly closed rows ---- */
+    {
+      const int np0 = S.vProbe[0], np1 = S.vProbe[1];
+      for(int t = tid; t < np0 + np1; t += kThreads)
+      {
+        const int side = t < np0 ? 0 : 1;
+        const int k = side == 0 ? t : t - np0;
+        const int y = S.vYStart[side] - 10 * k;
+        const int lft = S.vLeft[side], rgt = S.vRight[side];
+        /* left edge: first lit pixel of [lft, rgt-1]; right edge: last lit pixel of [lft+1, rgt] */
+        const int xa = side == 0 ? lft : lft + 1;
+        const int xb = side == 0 ? rgt - 1 : rgt;
+        int found = -1;
+        if(side == 0)
+        {
+          for(int c = xa >> 6; c <= (xb >> 6) && found < 0; c++)
+          {
+            unsigned long long cw = closed_word(im, y, c);
+            if(c == (xa >> 6)) cw &= ~0ull << (xa & 63);
+            if(c == (xb >> 6)) cw &= ~0ull >> (63 - (xb & 63));
+            if(cw)
+              found = 64 * c + __ffsll(static_cast<long long>(cw)) - 1;
+          }
+        }
+        else
+        {
+          for(int c = xb >> 6; c >= (xa >> 6) && found < 0; c--)
+          {
+            unsigned long long cw = closed_word(im, y, c);
+            if(c == (xa >> 6)) cw &= ~0ull << (xa & 63);
+            if(c == (xb >> 6)) cw &= ~0ull >> (63 - (xb & 63));
+            if(cw)
+              found = 64 * c + 63 - __clzll(static_cast<long long>(cw));
+          }
+        }
+        S.vx[side][k] = found;
+      }
+    }
+    __syncthreads();
+
+    /* compact the probe hits in scan order (y descending), distances to the base line (:708-721) */
+    if(tid < 2)
+    {
+      const int side = tid;
+      int n = 0;
+      for(int k = 0; k < S.vProbe[side]; k++)
+        if(S.vx[side][k] >= 0)
+        {
+          const int x = S.vx[side][k], y = S.vYStart[side] - 10 * k;
+          S.vpx[side][n] = x;
+          S.vpy[side][n] = y;
+          S.vdist[side][n] = fabs(x * S.baseLine.a + y * S.baseLine.b + S.baseLine.c);
+          n++;
+        }
+      S.vn[side] = n;
+      S.vBest[side] = -1;
+    }
+    __syncthreads();
+
+    /* findBestPoint: the element of rank 2n/3 by distance (ties broken by scan order) */
+    for(int t = tid; t < S.vn[0] + S.vn[1]; t += kThreads)
+    {
+      const int side = t < S.vn[0] ? 0 : 1;
+      const int i = side == 0 ? t : t - S.vn[0];
+      const int n = S.vn[side];
+      const double di = S.vdist[side][i];
+      int rank = 0;
+      for(int k = 0; k < n; k++)
+      {
+        const double dk = S.vdist[side][k];
+        rank += (dk < di || (dk == di && k < i)) ? 1 : 0;
+      }
+      if(rank == 2 * n / 3)
+        S.vBest[side] = i;
+    }
+    __syncthreads();
+  }
+
+  /* ---- Corners (:731-751), quadrilateral, isConvex (:758-772), imgPointsToWorld (pointcloud.cpp:476-487) ---- */
+  if(tid == 0)
+  {
+    double quad[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    int valid = 0;
+    int cornerFound[4] = { 0, 0, 0, 0 };
+    LineD vl[2] = { { 0, 0, 0 }, { 0, 0, 0 } };
+    int vFound[2] = { 0, 0 };
+    if(S.found)
+    {
+      for(int side = 0; side < 2; side++)
+        if(S.vActive[side] && S.vn[side] > 0 && S.vBest[side] >= 0)
+        {
+          const int bx = S.vpx[side][S.vBest[side]], by = S.vpy[side][S.vBest[side]];
+          vl[side] = LineD{ S.baseLine.a, S.baseLine.b, -S.baseLine.a * bx - S.baseLine.b * by };   /* parallel(), :368-371 */
+          vFound[side] = 1;
+        }
+      for(int e = 0; e < 4; e++)
+      {
+        const int side = (e == kFL || e == kBL) ? 0 : 1;
+        double x = S.bounds[e][1][0], y = S.bounds[e][1][1];         /* value_or(bounds.outer) :947-953 */
+        if(vFound[side])
+        {
+          const LineD hl{ static_cast<double>(S.line[e].a), static_cast<double>(S.line[e].b), static_cast<double>(S.line[e].c) };
+          double ix, iy;
+          if(intersect60(vl[side], hl, ix, iy))
+          {
+            x = ix; y = iy;
+            cornerFound[e] = 1;
+          }
+        }
+        quad[2 * e] = x;
+        quad[2 * e + 1] = y;
+      }
+      /* isConvex: edge vectors q0->q1, q1->q3, q3->q2, q2->q0 must all turn the same way */
+      const double vx[4] = { quad[2] - quad[0], quad[6] - quad[2], quad[4] - quad[6], quad[0] - quad[4] };
+      const double vy[4] = { quad[3] - quad[1], quad[7] - quad[3], quad[5] - quad[7], quad[1] - quad[5] };
+      auto pos = [&](int i, int k) { return vx[i] * vy[k] - vx[k] * vy[i] > 0; };
+      const bool positive = pos(0, 1);
+      valid = (positive == pos(1, 2) && positive == pos(2, 3) && positive == pos(3, 0)) ? 1 : 0;
+    }
+    pl.outlineFound = S.found;
+    pl.valid = valid;
+    for(int k = 0; k < 4; k++)
+    {
+      pl.quadImg[2 * k] = quad[2 * k];
+      pl.quadImg[2 * k + 1] = quad[2 * k + 1];
+      pl.quadWorld[2 * k] = P.xMin + quad[2 * k] * P.xToWorld;            /* Projection2D::imageToWorld :84-88 */
+      pl.quadWorld[2 * k + 1] = P.yMax - quad[2 * k + 1] * P.yToWorld;
+    }
+    if(S.status)
+      atomicOr(&fs.status, S.status);
+
+    if(dp)
+    {
+      dp->outline_found = S.found;
+      dp->valid = valid;
+      for(int k = 0; k < 8; k++) { dp->quad_img[k] = pl.quadImg[k]; dp->quad_world[k] = pl.quadWorld[k]; }
+      if(S.found)
+      {
+        for(int e = 0; e < 4; e++)
+        {
+          dp->n_edge_pts[e] = S.en[e];
+          dp->line[e][0] = S.line[e].a; dp->line[e][1] = S.line[e].b; dp->line[e][2] = S.line[e].c;
+          for(int io = 0; io < 2; io++) { dp->bounds[e][io][0] = S.bounds[e][io][0]; dp->bounds[e][io][1] = S.bounds[e][io][1]; }
+          dp->corner_found[e] = cornerFound[e];
+        }
+        dp->base_line[0] = S.baseLine.a; dp->base_line[1] = S.baseLine.b; dp->base_line[2] = S.baseLine.c;
+        for(int side = 0; side < 2; side++)
+        {
+          dp->vedge_found[side] = vFound[side];
+          dp->n_vpts[side] = S.vn[side];
+          for(int k = 0; k < S.vn[side]; k++) { dp->vpts[side][k][0] = S.vpx[side][k]; dp->vpts[side][k][1] = S.vpy[side][k]; }
+          if(vFound[side])
+          {
+            dp->best_pt[side][0] = S.vpx[side][S.vBest[side]]; dp->best_pt[side][1] = S.vpy[side][S.vBest[side]];
+            dp->vline[side][0] = vl[side].a; dp->vline[side][1] = vl[side].b; dp->vline[side][2] = vl[side].c;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  /* leave the raw image zeroed for the next batch */
+  for(int idx = tid; idx < P.H * P.W64; idx += kThreads)
+    if(img[idx])
+      img[idx] = 0ull;
+}
+
+/* ========================================================================= */
+/* K3b: ground quadrilateral and the prepared quadrilateral tests              */
+
+struct SegTmp { double bxLo, bxUp, byLo, byUp; };
+
+__device__ __forceinline__ void sector_init(double a, double b, double &lo, double &up)
+{
+  lo = a; up = a;                       /* Sector(a, b): quadrilateralTest.cpp:28-40 */
+  if(lo > b) lo = b;
+  else if(up < b) up = b;
+}
+__device__ __forceinline__ void sector_expand(double c, double &lo, double &up)
+{
+  if(lo > c) lo = c;
+  else if(up < c) up = c;
+}
+__device__ __forceinline__ bool sector_overlaps(double lo, double up, double olo, double oup)
+{
+  return lo < oup && up > olo;
+}
+
+/* QuadrilateralTest::QuadrilateralTest (quadrilateralTest.cpp:275-443) flattened into tables */
+__device__ void build_quad_test(const double *q /* 4 x (x,y) */, QuadTest &t)
+{
+  t.err = 0;
+  sector_init(q[0], q[2], t.bxLo, t.bxUp);
+  sector_init(q[1], q[3], t.byLo, t.byUp);
+  sector_expand(q[4], t.bxLo, t.bxUp); sector_expand(q[5], t.byLo, t.byUp);
+  sector_expand(q[6], t.bxLo, t.bxUp); sector_expand(q[7], t.byLo, t.byUp);
+
+  /* segments counterclockwise: 0->1, 1->3, 3->2, 2->0 */
+  const int sp[4] = { 0, 1, 3, 2 }, sq[4] = { 1, 3, 2, 0 };
+  SegTmp box[4];
+  for(int s = 0; s < 4; s++)
+  {
+    const double px = q[2 * sp[s]], py = q[2 * sp[s] + 1], qx = q[2 * sq[s]], qy = q[2 * sq[s] + 1];
+    sector_init(px, qx, box[s].bxLo, box[s].bxUp);
+    sector_init(py, qy, box[s].byLo, box[s].byUp);
+    const double dx = qx - px, dy = qy - py;
+    const LineD l = line_through_d(px, py, qx, qy);
+    if(fabs(dx) < fabs(dy))
+    {
+      t.segSteep[s] = 1;                      /* SteepLine :145-166 */
+      t.segK[s] = l.b / l.a;
+      t.segC[s] = l.c / l.a;
+      t.segLeftIfPositive[s] = dy > 0 ? 0 : 1;
+    }
+    else
+    {
+      t.segSteep[s] = 0;                      /* FlatLine :124-143 */
+      t.segK[s] = l.a / l.b;
+      t.segC[s] = l.c / l.b;
+      t.segLeftIfPositive[s] = dx > 0 ? 1 : 0;
+    }
+  }
+  auto isLeft = [&](int s, double x, double y)
+  {
+    const bool positive = t.segSteep[s] ? (x + y * t.segK[s] + t.segC[s] > 0) : (x * t.segK[s] + y + t.segC[s] > 0);
+    return t.segLeftIfPositive[s] ? positive : !positive;
+  };
+  const bool inside = isLeft(0, q[6], q[7]);
+  t.insideIsLeft = inside ? 1 : 0;
+  if(inside != isLeft(1, q[4], q[5]) || inside != isLeft(2, q[0], q[1]) || inside != isLeft(3, q[2], q[3]))
+  {
+    t.err = -1;
+    return;
+  }
+
+  double xs[4] = { q[0], q[2], q[4], q[6] }, ys[4] = { q[1], q[3], q[5], q[7] };
+  for(int i = 1; i < 4; i++)                 /* insertion sort of 4 */
+  {
+    const double vx = xs[i], vy = ys[i];
+    int k = i - 1;
+    while(k >= 0 && xs[k] > vx) { xs[k + 1] = xs[k]; k--; }
+    xs[k + 1] = vx;
+    k = i - 1;
+    while(k >= 0 && ys[k] > vy) { ys[k + 1] = ys[k]; k--; }
+    ys[k + 1] = vy;
+  }
+
+  int nRows = 0;
+  double rowUpper[3];
+  int nCells[3];
+  double cellUpper[3][3];
+  unsigned char cellMask[3][3], cellCnt[3][3], cellConst[3][3];
+  double lowerY = ys[0];
+  for(int yi = 1; yi < 4; yi++)
+  {
+    if(!(lowerY < ys[yi]))
+      continue;
+    const int r = nRows++;
+    rowUpper[r] = ys[yi];
+    nCells[r] = 0;
+    double lowerX = xs[0];
+    for(int xi = 1; xi < 4; xi++)
+    {
+      if(!(lowerX < xs[xi]))
+        continue;
+      const int c = nCells[r]++;
+      cellUpper[r][c] = xs[xi];
+      double cxLo, cxUp, cyLo, cyUp;
+      sector_init(lowerX, xs[xi], cxLo, cxUp);
+      sector_init(lowerY, ys[yi], cyLo, cyUp);
+      unsigned char mask = 0, cnt = 0;
+      bool nb[5] = { false, false, false, false, false };
+      for(int s = 0; s < 4; s++)
+      {
+        const bool xo = sector_overlaps(cxLo, cxUp, box[s].bxLo, box[s].bxUp);
+        const bool yo = sector_overlaps(cyLo, cyUp, box[s].byLo, box[s].byUp);
+        if(xo && yo)
+        {
+          mask |= static_cast<unsigned char>(1u << s);
+          cnt++;
+        }
+        if(cnt == 0)
+        {
+          /* BBox::getRelativePosition :93-110 */
+          int rel = 0;
+          const double mx = (cxLo + cxUp) / 2, my = (cyLo + cyUp) / 2;
+          if(yo && mx < box[s].bxLo) rel = 1;
+          else if(yo && mx > box[s].bxUp) rel = 2;
+          else if(xo && my < box[s].byLo) rel = 3;
+          else if(xo && my > box[s].byUp) rel = 4;
+          nb[rel] = true;
+        }
+      }
+      cellMask[r][c] = mask;
+      cellCnt[r][c] = cnt;
+      cellConst[r][c] = (nb[1] && nb[2] && nb[3] && nb[4]) ? 1 : 0;
+      lowerX = xs[xi];
+    }
+    lowerY = ys[yi];
+  }
+  if(nRows == 0) { t.err = -2; return; }
+  for(int r = 0; r < nRows; r++)
+  {
+    if(nCells[r] == 0) { t.err = -3; return; }
+    for(int c = 0; c < nCells[r]; c++)
+      if(cellCnt[r][c] > 2) { t.err = -4; return; }
+  }
+  /* merge equal neighbours (:377-394) */
+  for(int r = 0; r < nRows; r++)
+  {
+    int c = 0;
+    while(c + 1 < nCells[r])
+    {
+      const unsigned char cur = cellMask[r][c], nxt = cellMask[r][c + 1];
+      if(cur == 0 && nxt == 0) { t.err = -5; return; }
+      if(cellCnt[r][c] > 1 && cellCnt[r][c + 1] > 1) { t.err = -6; return; }
+      if(cur == nxt)
+      {
+        for(int k = c; k + 1 < nCells[r]; k++)
+        {
+          cellUpper[r][k] = cellUpper[r][k + 1];
+          cellMask[r][k] = cellMask[r][k + 1];
+          cellCnt[r][k] = cellCnt[r][k + 1];
+          cellConst[r][k] = cellConst[r][k + 1];
+        }
+        nCells[r]--;
+      }
+      else
+        c++;
+    }
+  }
+  t.nRows = static_cast<unsigned char>(nRows);
+  for(int r = 0; r < 3; r++)
+  {
+    t.nCells[r] = r < nRows ? static_cast<unsigned char>(nCells[r]) : 0;
+    for(int c = 0; c < 3; c++)
+    {
+      const bool live = r < nRows && c < nCells[r];
+      t.cellMask[r][c] = live ? cellMask[r][c] : 0;
+      t.cellConst[r][c] = live ? cellConst[r][c] : 0;
+    }
+    t.xTrans[r][0] = r < nRows && nCells[r] > 1 ? cellUpper[r][0] : 0.0;
+    t.xTrans[r][1] = r < nRows && nCells[r] > 2 ? cellUpper[r][1] : 0.0;
+  }
+  t.yTrans[0] = nRows > 1 ? rowUpper[0] : 0.0;
+  t.yTrans[1] = nRows > 2 ? rowUpper[1] : 0.0;
+}
+
+/* QuadrilateralTest::isPointWithin (quadrilateralTest.cpp:445-451 and the selector lambdas :487-571) */
+__device__ __forceinline__ bool quad_test(const QuadTest &t, double x, double y)
+{
+  if(!(t.bxLo < x && x < t.bxUp && t.byLo < y && y < t.byUp))
+    return false;
+  int r = 0;
+  if(t.nRows > 1 && !(y < t.yTrans[0]))
+    r = (t.nRows == 2 || y < t.yTrans[1]) ? 1 : 2;
+  const int nc = t.nCells[r];
+  int c = 0;
+  if(nc > 1 && !(x < t.xTrans[r][0]))
+    c = (nc == 2 || x < t.xTrans[r][1]) ? 1 : 2;
+  const unsigned int mask = t.cellMask[r][c];
+  if(mask == 0)
+    return t.cellConst[r][c] != 0;
+  bool ok = true;
+#pragma unroll
+  for(int s = 0; s < 4; s++)
+  {
+    const bool positive = t.segSteep[s] ? (x + y * t.segK[s] + t.segC[s] > 0) : (x * t.segK[s] + y + t.segC[s] > 0);
+    const bool left = t.segLeftIfPositive[s] ? positive : !positive;
+    if((mask >> s) & 1u)
+      ok = ok && (left == (t.insideIsLeft != 0));
+  }
+  return ok;
+}
+
+__global__ void k_quads(Params P, FrameState *__restrict__ st, int nframes, DebugFrame *__restrict__ dbg)
+{
+  const int frame = blockIdx.x * blockDim.x + threadIdx.x;
+  if(frame >= nframes)
+    return;
+  FrameState &fs = st[frame];
+  for(int k = 0; k <= kMaxPlateaus; k++)
+  {
+    fs.accActive[k] = 0;
+    fs.sumZ[k] = 0;
+    fs.cnt[k] = 0;
+  }
+  const int first = fs.firstStep, last = fs.firstStep + fs.nStepImages;
+  int firstValid = -1;
+  for(int k = first; k < last; k++)
+    if(fs.pl[k].valid)
+    {
+      firstValid = k;
+      break;
+    }
+  fs.firstValidInd = firstValid;
+  bool threw = false;
+  if(firstValid >= 0)
+  {
+    if(fs.groundInd >= 0)
+    {
+      /* calcGroundQuadrilateral (pointcloud.cpp:489-512) */
+      const double *q = fs.pl[firstValid].quadWorld;
+      const double yMin = P.yMin;
+      double *g = fs.groundQuadWorld;
+      if(q[1] < q[3])
+      {
+        g[0] = q[0]; g[1] = yMin;
+        g[2] = q[2] + (q[3] - yMin) * (q[3] - q[1]) / (q[2] - q[0]); g[3] = yMin;
+      }
+      else
+      {
+        g[0] = q[0] + (q[1] - yMin) * (q[1] - q[3]) / (q[0] - q[2]); g[1] = yMin;
+        g[2] = q[2]; g[3] = yMin;
+      }
+      g[4] = q[0]; g[5] = q[1];
+      g[6] = q[2]; g[7] = q[3];
+      build_quad_test(g, fs.qt[kGroundAcc]);
+      if(fs.qt[kGroundAcc].err)
+        threw = true;
+      else
+        fs.accActive[kGroundAcc] = 1;
+    }
+    for(int k = firstValid; k < last; k++)
+    {
+      if(!fs.pl[k].valid)
+        continue;
+      build_quad_test(fs.pl[k].quadWorld, fs.qt[k]);
+      if(fs.qt[k].err)
+        threw = true;
+      else
+        fs.accActive[k] = 1;
+    }
+  }
+  if(threw)
+  {
+    fs.status |= SSD_ST_THROW;
+    for(int k = 0; k <= kMaxPlateaus; k++)
+      fs.accActive[k] = 0;
+  }
+  if(dbg)
+  {
+    ssd_debug_frame &d = dbg[frame].d;
+    d.first_valid_ind = firstValid;
+    for(int k = 0; k < 8; k++)
+      d.ground_quad_world[k] = (firstValid >= 0 && fs.groundInd >= 0) ? fs.groundQuadWorld[k] : 0.0;
+    d.ground_quad_err = (firstValid >= 0 && fs.groundInd >= 0) ? fs.qt[kGroundAcc].err : 0;
+    for(int k = first; k < last; k++)
+      d.plateaus[k].quad_err = (firstValid >= 0 && k >= firstValid && fs.pl[k].valid) ? fs.qt[k].err : 0;
+  }
+}
+
+/* ========================================================================= */
+/* K4: in-quadrilateral filter, z sums, ground image                           */
+
+__global__ __launch_bounds__(kThreads) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, Params P,
+                                                     FrameState *__restrict__ st, unsigned int *__restrict__ groundImg,
+                                                     int chunkPoints)
+{
+  __shared__ QuadTest qts[kMaxPlateaus + 1];
+  __shared__ unsigned char lut[kMaxBins];
+  __shared__ unsigned char active[kMaxPlateaus + 1];
+  __shared__ unsigned long long lsum[kMaxPlateaus + 1][8];
+  __shared__ unsigned int lcnt[kMaxPlateaus + 1][8];
+  __shared__ int anyActive;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int frame = blockIdx.y;
+  FrameState &fs = st[frame];
+  if(tid == 0)
+  {
+    int a = 0;
+    for(int k = 0; k <= kMaxPlateaus; k++)
+      a |= fs.accActive[k];
+    anyActive = a;
+  }
+  __syncthreads();
+  if(!anyActive)
+    return;
+
+  if(tid < kMaxBins)
+    lut[tid] = fs.lut[tid];
+  if(tid <= kMaxPlateaus)
+    active[tid] = fs.accActive[tid];
+  for(int i = tid; i < (kMaxPlateaus + 1) * 8; i += kThreads)
+  {
+    (&lsum[0][0])[i] = 0ull;
+    (&lcnt[0][0])[i] = 0u;
+  }
+  {
+    /* copy the live quadrilateral tests as 32-bit words */
+    const unsigned int *src = reinterpret_cast<const unsigned int *>(fs.qt);
+    unsigned int *dst = reinterpret_cast<unsigned int *>(qts);
+    constexpr int wordsPer = sizeof(QuadTest) / 4;
+    for(int i = tid; i < (kMaxPlateaus + 1) * wordsPer; i += kThreads)
+      if(fs.accActive[i / wordsPer])
+        dst[i] = src[i];
+  }
+  __syncthreads();
+
+  const int groundInd = fs.groundInd;
+  const float *base = xyz + static_cast<size_t>(frame) * strideFloats;
+  const int begin = blockIdx.x * chunkPoints;
+  const int end = min(begin + chunkPoints, P.nPoints);
+  const int W32 = P.W64 * 2;
+  unsigned int *gimg = groundImg + static_cast<size_t>(frame) * P.H * W32;
+  const int copy = lane & 7;
+
+  for(int i0 = begin; i0 < end; i0 += kTile)
+  {
+    F3 v[kPts];
+#pragma unroll
+    for(int j = 0; j < kPts; j++)
+    {
+      const int idx = i0 + j * kThreads + tid;
+      v[j] = F3{ 0.0f, 0.0f, 0.0f };
+      if(idx < end)
+        v[j] = *reinterpret_cast<const F3 *>(base + 3 * static_cast<size_t>(idx));
+    }
+#pragma unroll
+    for(int j = 0; j < kPts; j++)
+    {
+      double wx, wy, wz;
+      if(!world_point(P, v[j], wx, wy, wz))
+        continue;
+      const int p = lut[height_bin(P, wz)];
+      if(p == 0xff)
+        continue;
+      const int q = p == groundInd ? kGroundAcc : p;
+      if(!active[q])
+        continue;
+      if(!quad_test(qts[q], wx, wy))
+        continue;
+      /* calcAverageZ (pointcloud.cpp:574-581) as an order-independent fixed-point sum */
+      const long long zf = __double2ll_rn(wz * static_cast<double>(1ll << kZFixShift));
+      atomicAdd(&lsum[q][copy], static_cast<unsigned long long>(zf));
+      atomicAdd(&lcnt[q][copy], 1u);
+      if(q == kGroundAcc)
+      {
+        /* projectToBinaryImage(pointsInQuadri) (pointcloud.cpp:531) */
+        const int ix = static_cast<int>((wx - P.xMin) * P.xToImage);
+        const int iy = static_cast<int>((P.yMax - wy) * P.yToImage);
+        if(ix < 0 || ix >= P.W || iy < 0 || iy >= P.H)
+        {
+          atomicOr(&fs.status, static_cast<unsigned int>(SSD_ST_OOB_PIXEL));
+          atomicAdd(&fs.nOob, 1u);
+        }
+        else
+          atomicOr(gimg + static_cast<size_t>(iy) * W32 + (ix >> 5), 1u << (ix & 31));
+      }
+    }
+  }
+  __syncthreads();
+  if(tid <= kMaxPlateaus && active[tid])
+  {
+    unsigned long long s = 0;
+    unsigned int c = 0;
+    for(int k = 0; k < 8; k++)
+    {
+      s += lsum[tid][k];
+      c += lcnt[tid][k];
+    }
+    if(c)
+    {
+      atomicAdd(reinterpret_cast<unsigned long long *>(&fs.sumZ[tid]), s);
+      atomicAdd(&fs.cnt[tid], c);
+    }
+  }
+}
+
+/* ========================================================================= */
+/* K5: ground front edge and the per-frame result — one workgroup per frame     */
+
+struct FinalShared
+{
+  int yEdge[kMaxCols];
+  int px[kMaxCols], py[kMaxCols];
+  int n;
+  LineI line;
+};
+
+__global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__restrict__ st,
+                                                    unsigned long long *__restrict__ groundImg,
+                                                    ssd_frame_result *__restrict__ results,
+                                                    DebugFrame *__restrict__ dbg,
+                                                    unsigned long long *__restrict__ dbgImg)
+{
+  __shared__ FinalShared S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frame = blockIdx.x;
+  FrameState &fs = st[frame];
+  ssd_frame_result &res = results[frame];
+  const bool threw = (fs.status & SSD_ST_THROW) != 0;
+  const bool haveGround = !threw && fs.firstValidInd >= 0 && fs.groundInd >= 0;
+
+  const size_t imgWords = static_cast<size_t>(P.H) * P.W64;
+  unsigned long long *img = groundImg + static_cast<size_t>(frame) * imgWords;
+  const BitImg im{ img, P.W, P.H, P.W64 };
+
+  /* bottom-scan columns: x_j = xr0 + 50 j, centre column j = jc */
+  const int xStep = 50;
+  const int xc = P.W / 2;
+  const int xr0 = xc % xStep;
+  const int jc = xc / xStep;
+  const int nCols = min(kMaxCols, (P.W - 1 - xr0) / xStep + 1);
+
+  for(int j = tid; j < kMaxCols; j += kThreads)
+    S.yEdge[j] = -1;
+  if(tid == 0)
+    S.n = 0;
+  __syncthreads();
+
+  if(haveGround)
+  {
+    /* BottomScanner::probeBottomUp (segmentation.cpp:225-241): lowest lit pixel with y > H/2 */
+    const int yStop = P.H / 2;
+    unsigned long long *dbgRaw = nullptr, *dbgClosed = nullptr;
+    if(dbgImg)
+    {
+      dbgRaw = dbgImg + ((static_cast<size_t>(frame) * (P.maxStepImages + 1) + P.maxStepImages) * 2) * imgWords;
+      dbgClosed = dbgRaw + imgWords;
+    }
+    const int firstRow = dbgImg ? 0 : yStop + 1;
+    for(int idx = tid + firstRow * P.W64; idx < P.H * P.W64; idx += kThreads)
+    {
+      const int y = idx / P.W64, c = idx - y * P.W64;
+      const unsigned long long cw = closed_word(im, y, c);
+      if(dbgImg)
+      {
+        dbgRaw[idx] = img[idx];
+        dbgClosed[idx] = cw;
+      }
+      if(cw == 0ull || y <= yStop)
+        continue;
+      const int x0 = 64 * c;
+      int j = x0 <= xr0 ? 0 : (x0 - xr0 + xStep - 1) / xStep;
+      for(int x = xr0 + xStep * j; x < x0 + 64 && j < nCols; x += xStep, j++)
+        if((cw >> (x - x0)) & 1ull)
+          atomicMax(&S.yEdge[j], y);
+    }
+    __syncthreads();
+
+    /* BottomScanner::scan (:170-222): first hit rightwards from the centre (else leftwards), then
+     * contiguous hits to the right of it, then to the left of it */
+    if(tid == 0)
+    {
+      int n = 0, j = jc;
+      bool got = false;
+      for( ; j < nCols; j++)
+        if(S.yEdge[j] >= 0) { got = true; break; }
+      if(!got)
+        for(j = jc - 1; j >= 0; j--)
+          if(S.yEdge[j] >= 0) { got = true; break; }
+      if(got)
+      {
+        const int jStart = j;
+        S.px[n] = xr0 + xStep * j; S.py[n] = S.yEdge[j]; n++;
+        for(j = jStart + 1; j < nCols && S.yEdge[j] >= 0; j++)
+        { S.px[n] = xr0 + xStep * j; S.py[n] = S.yEdge[j]; n++; }
+        for(j = jStart - 1; j >= 0 && S.yEdge[j] >= 0; j--)
+        { S.px[n] = xr0 + xStep * j; S.py[n] = S.yEdge[j]; n++; }
+      }
+      S.n = n;
+    }
+    __syncthreads();
+    if(S.n >= 2 && wave == 0)
+    {
+      const LineI l = wave_best_line(S.px, S.py, S.n, lane);
+      if(lane == 0)
+        S.line = l;
+    }
+    __syncthreads();
+  }
+
+  if(tid == 0)
+  {
+    int n = 0;
+    double stepsWorld[SSD_MAX_STEPS][9];       /* z, 4 x (x,y) in camera-dependent world coordinates */
+    if(!threw && fs.firstValidInd >= 0)
+    {
+      if(fs.groundInd >= 0)
+      {
+        /* calcGround (pointcloud.cpp:528-547) */
+        double *s = stepsWorld[n];
+        for(int k = 0; k < 9; k++) s[k] = 0.0;       /* "return {}" when no front edge is found (quirk Q6) */
+        const bool valid = S.n >= 2;
+        fs.groundFrontValid = valid ? 1 : 0;
+        const double meanZ = (static_cast<double>(fs.sumZ[kGroundAcc]) / static_cast<double>(1ll << kZFixShift)) / fs.cnt[kGroundAcc];
+        double fimg[4] = { 0, 0, 0, 0 };
+        if(valid)
+        {
+          /* detectFrontEdge tail (segmentation.cpp:896-906) */
+          const LineI l = S.line;
+          const double fm = static_cast<double>(-l.a) / l.b, fn = static_cast<double>(-l.c) / l.b;
+          int xl = S.px[0], xr = S.px[0];
+          for(int k = 1; k < S.n; k++) { xl = min(xl, S.px[k]); xr = max(xr, S.px[k]); }
+          fimg[0] = xl; fimg[1] = xl * fm + fn;
+          fimg[2] = xr; fimg[3] = xr * fm + fn;
+          const double flx = P.xMin + fimg[0] * P.xToWorld, fly = P.yMax - fimg[1] * P.yToWorld;
+          const double frx = P.xMin + fimg[2] * P.xToWorld, fry = P.yMax - fimg[3] * P.yToWorld;
+          const LineD frontLine = line_through_d(flx, fly, frx, fry);
+          const double *g = fs.groundQuadWorld;
+          const LineD leftSide = line_through_d(g[0], g[1], g[4], g[5]);
+          const LineD rightSide = line_through_d(g[2], g[3], g[6], g[7]);
+          /* StairsDetector::Line::intersection (pointcloud.cpp:520-525) */
+          const double dl = frontLine.a * leftSide.b - leftSide.a * frontLine.b;
+          const double dr = frontLine.a * rightSide.b - rightSide.a * frontLine.b;
+          s[0] = meanZ;
+          s[1] = (frontLine.b * leftSide.c - leftSide.b * frontLine.c) / dl;
+          s[2] = (leftSide.a * frontLine.c - frontLine.a * leftSide.c) / dl;
+          s[3] = (frontLine.b * rightSide.c - rightSide.b * frontLine.c) / dr;
+          s[4] = (rightSide.a * frontLine.c - frontLine.a * rightSide.c) / dr;
+          s[5] = g[4]; s[6] = g[5];
+          s[7] = g[6]; s[8] = g[7];
+        }
+        n++;
+        if(dbg)
+        {
+          ssd_debug_frame &d = dbg[frame].d;
+          d.ground_front_valid = valid ? 1 : 0;
+          d.ground_n_in_quad = static_cast<int>(fs.cnt[kGroundAcc]);
+          d.ground_mean_z = meanZ;
+          d.ground_n_pts = S.n;
+          for(int k = 0; k < S.n; k++) { d.ground_pts[k][0] = S.px[k]; d.ground_pts[k][1] = S.py[k]; }
+          if(valid)
+          {
+            d.ground_line[0] = S.line.a; d.ground_line[1] = S.line.b; d.ground_line[2] = S.line.c;
+            for(int k = 0; k < 4; k++) d.ground_front_img[k] = fimg[k];
+          }
+        }
+      }
+      /* calcStairStep (pointcloud.cpp:549-558) */
+      const int last = fs.firstStep + fs.nStepImages;
+      for(int k = fs.firstValidInd; k < last && n < SSD_MAX_STEPS; k++)
+      {
+        if(!fs.pl[k].valid)
+          continue;
+        const double meanZ = (static_cast<double>(fs.sumZ[k]) / static_cast<double>(1ll << kZFixShift)) / fs.cnt[k];
+        double *s = stepsWorld[n];
+        s[0] = meanZ;
+        for(int c = 0; c < 8; c++) s[1 + c] = fs.pl[k].quadWorld[c];
+        n++;
+        if(dbg)
+        {
+          ssd_debug_plateau &p = dbg[frame].d.plateaus[k];
+          p.n_in_quad = static_cast<int>(fs.cnt[k]);
+          p.sum_z_fix = fs.sumZ[k];
+          p.mean_z = meanZ;
+        }
+      }
+    }
+    /* detectStairs tail (pointcloud.cpp:370-383): ToExternalWorld (transformation.cpp:190-194) */
+    res.n_steps = n;
+    res.status = static_cast<int>(fs.status);
+    for(int i = 0; i < n; i++)
+    {
+      const double *s = stepsWorld[i];
+      res.steps[i].height = P.worldZ + s[0];
+      for(int c = 0; c < 4; c++)
+      {
+        const double x = s[1 + 2 * c], y = s[2 + 2 * c];
+        double ex = P.r2[0] * x + P.r2[1] * y;
+        double ey = P.r2[2] * x + P.r2[3] * y;
+        ex = ex + P.t2[0];
+        ey = ey + P.t2[1];
+        res.steps[i].quad[2 * c] = ex;
+        res.steps[i].quad[2 * c + 1] = ey;
+      }
+    }
+    if(dbg)
+    {
+      dbg[frame].d.status = static_cast<int>(fs.status);
+      dbg[frame].d.n_oob = static_cast<int>(fs.nOob);
+    }
+  }
+  __syncthreads();
+
+  /* leave the ground image zeroed for the next batch (written only when a ground accumulator was live) */
+  if(fs.firstValidInd >= 0 && fs.groundInd >= 0)
+    for(int idx = tid; idx < P.H * P.W64; idx += kThreads)
+      if(img[idx])
+        img[idx] = 0ull;
+}
+
+/* ========================================================================= */
+/* synthetic frame source                                                      */
+
+__global__ __launch_bounds__(kThreads) void k_synth(const ssd_scene *__restrict__ scenes, float *__restrict__ xyz,
+                                                    size_t strideFloats)
+{
+  const int frame = blockIdx.y;
+  const ssd_scene s = scenes[frame];
+  const int n = s.width * s.height;
+  const uint64_t key = synth_frame_key(s);
+  float *out = xyz + static_cast<size_t>(frame) * strideFloats;
+  for(int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
+  {
+    const int v = i / s.width, u = i - v * s.width;
+    float p[3];
+    synth_pixel(s, key, u, v, p);
+    out[3 * static_cast<size_t>(i)] = p[0];
+    out[3 * static_cast<size_t>(i) + 1] = p[1];
+    out[3 * static_cast<size_t>(i) + 2] = p[2];
+  }
+}
+
+/* test hook: hypot_ref on the device */
+__global__ void k_hypot(const double *a, const double *b, double *out, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    out[i] = hypot_ref(a[i], b[i]);
+}
+
+} // namespace ssd
+
+/* ========================================================================= */
+/* launchers (declared in ssd_launch.h)                                        */
+#include "ssd_launch.h"
+
+namespace ssd
+{
+
+static inline int chunks_for(int nPoints, int chunkPoints) { return (nPoints + chunkPoints - 1) / chunkPoints; }
+
+void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, int nframes, int chunkPoints, hipStream_t s)
+{
+  dim3 grid(chunks_for(P.nPoints, chunkPoints), nframes);
+  hipLaunchKernelGGL(k_hist, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, chunkPoints);
+}
+void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_peaks, dim3((nframes + 63) / 64), dim3(64), 0, s, P, st, nframes, dbg);
+}
+void launch_raster(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned int *stepImg, int nframes, int chunkPoints, hipStream_t s)
+{
+  dim3 grid(chunks_for(P.nPoints, chunkPoints), nframes);
+  hipLaunchKernelGGL(k_raster, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, stepImg, chunkPoints);
+}
+void launch_outline(const Params &P, FrameState *st, unsigned long long *stepImg, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
+{
+  dim3 grid(P.maxStepImages, nframes);
+  hipLaunchKernelGGL(k_outline, grid, dim3(kThreads), 0, s, P, st, stepImg, dbg, dbgImg);
+}
+void launch_quads(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_quads, dim3((nframes + 63) / 64), dim3(64), 0, s, P, st, nframes, dbg);
+}
+void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned int *groundImg, int nframes, int chunkPoints, hipStream_t s)
+{
+  dim3 grid(chunks_for(P.nPoints, chunkPoints), nframes);
+  hipLaunchKernelGGL(k_inquad, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, groundImg, chunkPoints);
+}
+void launch_final(const Params &P, FrameState *st, unsigned long long *groundImg, ssd_frame_result *results, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_final, dim3(nframes), dim3(kThreads), 0, s, P, st, groundImg, results, dbg, dbgImg);
+}
+void launch_synth(const ssd_scene *dScenes, float *xyz, size_t strideFloats, int nframes, int nPoints, hipStream_t s)
+{
+  int bx = (nPoints + kThreads * 4 - 1) / (kThreads * 4);
+  if(bx > 2048) bx = 2048;
+  if(bx < 1) bx = 1;
+  hipLaunchKernelGGL(k_synth, dim3(bx, nframes), dim3(kThreads), 0, s, dScenes, xyz, strideFloats);
+}
+void launch_hypot(const double *a, const double *b, double *out, int n, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_hypot, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, n);
+}
+double hypot_ref_host(double a, double b) { return hypot_ref(a, b); }
+
+} // namespace ssd

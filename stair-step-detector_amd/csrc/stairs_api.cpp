@@ -1,0 +1,88 @@
+/* stairs_api.cpp — see stairs_api.h */
+#include "stairs_api.h"
+#include <iostream>
+#include <stdexcept>
+
+namespace stairs
+{
+
+std::string Stairs::serialize() const
+{
+  ssd_frame_result r{};
+  r.n_steps = static_cast<int>(stairSteps.size() < SSD_MAX_STEPS ? stairSteps.size() : SSD_MAX_STEPS);
+  for(int i = 0; i < r.n_steps; i++)
+  {
+    r.steps[i].height = stairSteps[i].height;
+    for(int k = 0; k < 4; k++)
+    {
+      r.steps[i].quad[2 * k] = stairSteps[i].quadrilateral[k].x;
+      r.steps[i].quad[2 * k + 1] = stairSteps[i].quadrilateral[k].y;
+    }
+  }
+  std::string buf(SSD_LINE_CAP, '\0');
+  const int n = ssd_serialize(&r, buf.data(), buf.size());
+  buf.resize(n > 0 ? n : 0);
+  return buf;
+}
+
+GeometricTransformation::GeometricTransformation()
+{
+  ssd_calibration_identity(&_cal);
+}
+
+GeometricTransformation::GeometricTransformation(const RefPoints &w, const RefPoints &c)
+{
+  const double wp[9] = { w[0].x, w[0].y, w[0].z, w[1].x, w[1].y, w[1].z, w[2].x, w[2].y, w[2].z };
+  const double cp[9] = { c[0].x, c[0].y, c[0].z, c[1].x, c[1].y, c[1].z, c[2].x, c[2].y, c[2].z };
+  if(ssd_calibration_from_points(wp, cp, &_cal) != SSD_OK)
+    throw std::invalid_argument(ssd_last_error());
+}
+
+Pointcloud::Pointcloud(const Window &window, const GeometricTransformation &trans)
+: _window(window),
+  _transformation(trans)
+{
+}
+
+Pointcloud::~Pointcloud()
+{
+  ssd_destroy(_handle);
+}
+
+Stairs Pointcloud::detect(const Camera::DepthFrame &frame) const
+{
+  if(!_handle || frame.width != _width || frame.height != _height)
+  {
+    ssd_destroy(_handle);
+    _handle = nullptr;
+    ssd_config cfg;
+    if(ssd_default_config(&cfg, frame.width, frame.height) != SSD_OK)
+      throw std::runtime_error(ssd_last_error());
+    cfg.max_frames_per_batch = 1;
+    if(ssd_create(&cfg, &_transformation.constants(), 0, &_handle) != SSD_OK)
+      throw std::runtime_error(ssd_last_error());
+    _width = frame.width;
+    _height = frame.height;
+  }
+  ssd_frame_result r;
+  if(ssd_process_host(_handle, frame.vertices, 1, &r) != SSD_OK)
+    throw std::runtime_error(ssd_last_error());
+  if(r.status & SSD_ST_THROW)
+    throw std::invalid_argument("Quadrilateral is not usable (quadrilateralTest.cpp:283-372)");   /* as the reference does */
+  Stairs s;
+  s.stairSteps.resize(r.n_steps);
+  for(int i = 0; i < r.n_steps; i++)
+  {
+    s.stairSteps[i].height = r.steps[i].height;
+    for(int k = 0; k < 4; k++)
+      s.stairSteps[i].quadrilateral[k] = Point2{ r.steps[i].quad[2 * k], r.steps[i].quad[2 * k + 1] };
+  }
+  return s;
+}
+
+void Pointcloud::process(const Camera::DepthFrame &frame) const
+{
+  std::cout << detect(frame).serialize() << std::endl;     /* pointcloud.cpp:625 */
+}
+
+} // namespace stairs
