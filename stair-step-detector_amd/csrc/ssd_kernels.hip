@@ -1597,6 +1597,11 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
     /* detectStairs tail (pointcloud.cpp:370-383): ToExternalWorld (transformation.cpp:190-194) */
     res.n_steps = n;
     res.status = static_cast<int>(fs.status);
+    for(int i = n; i < SSD_MAX_STEPS; i++)        /* unused slots are zero, so results compare bytewise */
+    {
+      res.steps[i].height = 0.0;
+      for(int c = 0; c < 8; c++) res.steps[i].quad[c] = 0.0;
+    }
     for(int i = 0; i < n; i++)
     {
       const double *s = stepsWorld[i];

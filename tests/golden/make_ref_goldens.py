@@ -1,0 +1,96 @@
+"""Generates tests/golden/ref_serialize.json and ref_quadtest.json by running the REAL reference code
+(oracle/_ref/libssd_ref.so = /root/reference/stairs.cpp + quadrilateralTest.cpp compiled in place by
+oracle/Makefile) on seeded inputs.  Run in the build container (needs /root/reference):
+
+    make -C oracle && python tests/golden/make_ref_goldens.py
+
+The fixtures are data only (inputs + the reference's outputs); doubles are stored as hex strings so
+that they round-trip bit-exactly.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_binding as ob  # noqa: E402
+
+
+def hexlist(a):
+    return [float(x).hex() for x in np.asarray(a, dtype=np.float64).reshape(-1)]
+
+
+def random_quad(rng, kind):
+    if kind == 0:      # near-rectangular tread, small yaw, metres
+        cx, cy = rng.uniform(-0.2, 0.2), rng.uniform(0.3, 1.1)
+        w, d, a = rng.uniform(0.2, 0.5), rng.uniform(0.08, 0.2), rng.uniform(-0.3, 0.3)
+        c, s = np.cos(a), np.sin(a)
+        base = np.array([[-w, -d], [w, -d], [-w, d], [w, d]]) + rng.normal(0, 0.01, (4, 2))
+        return base @ np.array([[c, s], [-s, c]]) + [cx, cy]
+    if kind == 1:      # arbitrary quads (many non-convex -> the constructor throws)
+        return rng.uniform(-1, 1, (4, 2))
+    if kind == 2:      # axis-aligned rectangles (degenerate cell maps)
+        x0, x1 = sorted(rng.uniform(-1, 1, 2))
+        y0, y1 = sorted(rng.uniform(-1, 1, 2))
+        return np.array([[x0, y0], [x1, y0], [x0, y1], [x1, y1]])
+    # strongly rotated convex quads (diamonds, slivers)
+    a = rng.uniform(0, np.pi)
+    c, s = np.cos(a), np.sin(a)
+    w, d = rng.uniform(0.05, 0.8), rng.uniform(0.05, 0.8)
+    base = np.array([[-w, -d], [w, -d], [-w, d], [w, d]]) * (1 + rng.normal(0, 0.05, (4, 2)))
+    return base @ np.array([[c, s], [-s, c]])
+
+
+def main():
+    ref = ob.load_ref()
+    if ref is None:
+        raise SystemExit("oracle/_ref/libssd_ref.so missing: run `make -C oracle` where /root/reference exists")
+    rng = np.random.default_rng(20211)
+
+    ser = []
+    specials = [0.0, -0.0, 0.0005, -0.0005, 0.0015, 0.0025, -0.0004999, 1e-9, -1e-9, 123456.789, -99999.9995,
+                float("nan"), float("inf"), -float("inf"), 0.17005879162516252, -0.40078125000000003]
+    for n in (0, 1, 2, 4, 9, 17):
+        steps = rng.normal(0, 1, (n, 9))
+        ser.append(steps)
+    sp = np.array(specials + specials[:2])[:18].reshape(2, 9)
+    ser.append(sp)
+    ser.append(rng.choice(specials, (3, 9)))
+    ser.append(np.round(rng.normal(0, 2, (5, 9)), 3) + 0.0005)     # ties of the 3-decimal rounding
+    out_ser = [{"n": int(len(s)), "steps": hexlist(s), "line": ref.serialize(s)} for s in ser]
+    with open(os.path.join(HERE, "ref_serialize.json"), "w") as f:
+        json.dump(out_ser, f, indent=0)
+
+    out_q = []
+    degenerate = [
+        [[0, 0], [1, 0], [0, 0], [1, 0]],             # no extent along Y
+        [[0, 0], [0, 0], [0, 1], [0, 1]],             # no extent along X
+        [[0, 0], [1, 0], [0, 1], [0, 1]],             # duplicate vertex (triangle)
+        [[0, 0], [1, 1], [2, 2], [3, 3]],             # collinear
+        [[0, 0], [1, 0], [1, 1], [0, 1]],             # bow-tie in the default vertex order
+        [[0, 0], [0, 0], [0, 0], [0, 0]],             # a point
+        [[-0.6, 1.3], [-0.6, 1.3], [-0.6, 1.3], [-0.6, 1.3]],
+    ]
+    for i in range(72 + len(degenerate)):
+        q = np.array(degenerate[i - 72], dtype=np.float64) if i >= 72 else random_quad(rng, i % 4)
+        lo, hi = q.min(0), q.max(0)
+        ext = (hi - lo) * 0.25 + 1e-3
+        pts = rng.uniform(lo - ext, hi + ext, (40, 2))
+        # points on and next to vertices / edges / bbox sides
+        t = rng.uniform(0, 1, (8, 1))
+        e = [(0, 1), (1, 3), (3, 2), (2, 0)]
+        on_edges = np.concatenate([q[a] + t[2 * k:2 * k + 2] * (q[b] - q[a]) for k, (a, b) in enumerate(e)])
+        near = on_edges + rng.normal(0, 1e-12, on_edges.shape)
+        pts = np.concatenate([pts, q, on_edges, near, np.nextafter(q, np.inf), np.nextafter(q, -np.inf)])
+        rc, inside = ref.quad_test(q, pts)
+        out_q.append({"quad": hexlist(q), "pts": hexlist(pts), "rc": int(rc), "inside": "".join(str(int(v)) for v in inside) if rc == 0 else ""})
+    with open(os.path.join(HERE, "ref_quadtest.json"), "w") as f:
+        json.dump(out_q, f, indent=0)
+    print("serialize cases:", len(out_ser), "quad cases:", len(out_q), "throwing:", sum(1 for c in out_q if c["rc"] != 0),
+          {c["rc"] for c in out_q})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,51 @@
+"""Named synthetic scenes shared by the CPU and GPU tests (SURVEY.md section 8(c) fixture set, BASELINE.json configs)."""
+
+RES = {"vga": (640, 480), "xga": (1024, 768), "fhd": (1920, 1080)}
+
+
+def scene_params():
+    """name -> (resolution key, make_scene kwargs)."""
+    p = {}
+    for r in ("vga", "xga", "fhd"):
+        p["%s_3steps_clean" % r] = (r, dict(n_steps=3, sigma=0.0, seed=1))
+        p["%s_3steps_noise2mm" % r] = (r, dict(n_steps=3, sigma=0.002, seed=2))
+    # BASELINE.json config 1/2: one XGA frame, 3 steps, sigma 1 mm
+    p["xga_config1"] = ("xga", dict(n_steps=3, sigma=0.001, seed=12345))
+    # BASELINE.json config 5: FHD, 8 noisy steps + 5 % outliers
+    p["fhd_config5"] = ("fhd", dict(n_steps=8, sigma=0.002, seed=5, outlier_frac=0.05, tread=0.14, rise=0.12,
+                                    first_riser_y=0.15, cam_height=1.4, pitch_deg=55.0))
+    p["xga_8steps_outliers"] = ("xga", dict(n_steps=8, sigma=0.002, seed=6, outlier_frac=0.05, tread=0.14, rise=0.12,
+                                            first_riser_y=0.15, cam_height=1.4, pitch_deg=55.0))
+    p["vga_8steps_outliers"] = ("vga", dict(n_steps=8, sigma=0.002, seed=7, outlier_frac=0.05, tread=0.14, rise=0.12,
+                                            first_riser_y=0.15, cam_height=1.4, pitch_deg=55.0))
+    p["xga_no_stairs"] = ("xga", dict(n_steps=0, sigma=0.001, seed=8))
+    p["vga_empty"] = ("vga", dict(n_steps=3, sigma=0.001, seed=9, invalid_frac=1.0))
+    p["xga_bin_boundary"] = ("xga", dict(n_steps=3, sigma=0.0005, seed=10, rise=0.2, tread=0.25))
+    p["xga_narrow"] = ("xga", dict(n_steps=3, sigma=0.001, seed=11, stair_width=0.5))
+    p["xga_wide"] = ("xga", dict(n_steps=3, sigma=0.001, seed=12, stair_width=1.6))
+    p["xga_yaw_p8"] = ("xga", dict(n_steps=3, sigma=0.001, seed=13, yaw_deg=8.0))
+    p["xga_yaw_m10"] = ("xga", dict(n_steps=3, sigma=0.0015, seed=14, yaw_deg=-10.0))
+    p["xga_roll3"] = ("xga", dict(n_steps=3, sigma=0.001, seed=15, roll_deg=3.0))
+    p["xga_invalid10"] = ("xga", dict(n_steps=3, sigma=0.001, seed=16, invalid_frac=0.10))
+    p["vga_yaw_outliers"] = ("vga", dict(n_steps=4, sigma=0.003, seed=17, yaw_deg=6.0, outlier_frac=0.02, rise=0.15, tread=0.26))
+    p["xga_low_camera"] = ("xga", dict(n_steps=2, sigma=0.001, seed=18, cam_height=0.8, pitch_deg=40.0, first_riser_y=0.6))
+    p["xga_2steps_deep"] = ("xga", dict(n_steps=2, sigma=0.002, seed=19, tread=0.4, rise=0.19, first_riser_y=0.35))
+    return p
+
+
+def make(ssd, name):
+    r, kw = scene_params()[name]
+    w, h = RES[r]
+    return ssd.make_scene(w, h, **kw)
+
+
+def batch_scenes(ssd, width, height, n, base_seed=1000, rng_seed=7):
+    """BASELINE.json config 3: randomised rise / tread / yaw / noise, K = 3."""
+    import numpy as np
+    rng = np.random.default_rng(rng_seed)
+    out = []
+    for i in range(n):
+        out.append(ssd.make_scene(width, height, n_steps=3, seed=base_seed + i,
+                                  rise=float(rng.uniform(0.14, 0.20)), tread=float(rng.uniform(0.25, 0.32)),
+                                  yaw_deg=float(rng.uniform(-10.0, 10.0)), sigma=float(rng.uniform(0.0005, 0.003))))
+    return out

@@ -1,0 +1,165 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol include/ssd_hip.h declares, its host-only
+entry points (configuration, calibration, serialisation, synthetic frame source) behave like the
+reference / oracle, and the compute entry points fail loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(ssd):
+    header = open(os.path.join(ROOT, "include", "ssd_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(ssd_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 25
+    L = ssd.lib()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert set(ssd.EXPORTS) <= declared
+
+
+def test_struct_layouts_match_the_header(ssd):
+    """ctypes mirrors must have the C sizes (computed from the header's constants)."""
+    assert C.sizeof(ssd.Step) == 72
+    assert C.sizeof(ssd.FrameResult) == 8 + 72 * ssd.MAX_STEPS
+    assert C.sizeof(ssd.Calibration) == 19 * 8
+    assert C.sizeof(ssd.Config) == 8 + 9 * 8 + 8
+    assert C.sizeof(ssd.Scene) % 8 == 0
+
+
+def test_default_config_is_the_reference_configuration(ssd):
+    cfg = ssd.default_config(640, 480)   # configuration.h:27-52
+    assert (cfg.x_min, cfg.x_max, cfg.y_min, cfg.y_max, cfg.z_min, cfg.z_max) == (-0.6, 0.6, 0.1, 1.3, -0.1, 1.1)
+    assert (cfg.height_interval, cfg.min_height_above_ground, cfg.min_step_depth) == (0.01, 0.05, 0.1)
+
+
+def test_compute_entry_points_fail_loudly_without_gpu(ssd):
+    if ssd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    cfg = ssd.default_config(640, 480)
+    with pytest.raises(ssd.SsdError, match="no HIP device"):
+        ssd.Detector(cfg, ssd.GeometricTransformation())
+    with pytest.raises(ssd.SsdError):
+        ssd.Pointcloud(ssd.Window("w"), ssd.GeometricTransformation()).process(np.zeros((480, 640, 3), np.float32))
+
+
+def test_create_rejects_bad_arguments(ssd):
+    L = ssd.lib()
+    cfg = ssd.default_config(640, 480)
+    cal = ssd.GeometricTransformation().constants
+    h = C.c_void_p()
+    assert L.ssd_create(None, C.byref(cal), 0, C.byref(h)) == -1
+    cfg.height_interval = 0.001           # 1201 bins > SSD_MAX_BINS
+    assert L.ssd_create(C.byref(cfg), C.byref(cal), 0, C.byref(h)) == -1
+    assert b"bins" in L.ssd_last_error()
+    cfg = ssd.default_config(640, 480)
+    cfg.max_step_plateaus = 99
+    assert L.ssd_create(C.byref(cfg), C.byref(cal), 0, C.byref(h)) == -1
+
+
+def test_calibration_matches_oracle_bitwise(ssd, oracle):
+    rng = np.random.default_rng(21)
+    for trial in range(20):
+        sc = ssd.make_scene(640, 480, cam_height=float(rng.uniform(0.6, 1.6)), pitch_deg=float(rng.uniform(30, 70)),
+                            roll_deg=float(rng.uniform(-5, 5)))
+        marks = [(float(rng.uniform(-0.5, -0.1)), float(rng.uniform(0.7, 1.2)), 0.0),
+                 (float(rng.uniform(0.1, 0.5)), float(rng.uniform(0.7, 1.2)), 0.0),
+                 (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(0.2, 0.5)), 0.0)]
+        world, cam = ssd.calibration_points(sc, marks)
+        t = ssd.GeometricTransformation(world, cam)
+        rc, cal = oracle.calibration(world, cam)
+        assert rc == 0
+        assert bytes(t.constants) == bytes(cal)
+        a = np.array(t.constants.a).reshape(3, 3)
+        assert np.allclose(a @ a.T, np.eye(3), atol=1e-14) and abs(np.linalg.det(a) - 1) < 1e-14
+        # the three marks lie on the ground: their world z is 0
+        z = (a @ cam.T).T[:, 2] + t.constants.b[2]
+        assert np.all(np.abs(z) < 1e-12)
+    with pytest.raises(ssd.SsdError):
+        ssd.GeometricTransformation(np.zeros((3, 3)), np.zeros((3, 3)))
+
+
+def test_reference_calibration_triangle_world_points(ssd, oracle):
+    """The shipped calibration-triangle world points (reference calibration-triangle:2-4)."""
+    world = np.array([[-1.121, 1.79826, 0.004], [1.121, 1.79826, 0.004], [0.769229, 0.3, 0.004]])
+    sc = ssd.make_scene(640, 480, cam_height=1.2, pitch_deg=45.0)
+    _, cam = ssd.calibration_points(sc, [tuple(w[:2]) + (0.0,) for w in world])
+    t = ssd.GeometricTransformation(world, cam)
+    rc, cal = oracle.calibration(world, cam)
+    assert rc == 0 and bytes(t.constants) == bytes(cal)
+    assert t.constants.world_z == 0.004
+    # external world = camera-dependent world here (marks given in the same frame): R2 = I, t2 = 0
+    assert np.allclose(np.array(t.constants.r2), [1, 0, 0, 1], atol=1e-12)
+    assert np.allclose(np.array(t.constants.t2), [0, 0], atol=1e-12)
+
+
+def test_serialize_cabi_matches_oracle_and_reference_goldens(ssd, oracle):
+    import json
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_serialize.json")))
+    for c in cases:
+        n = c["n"]
+        if n > ssd.MAX_STEPS:
+            continue
+        steps = np.array([float.fromhex(x) for x in c["steps"]]).reshape(n, 9)
+        fr = ssd.FrameResult()
+        fr.n_steps = n
+        for i in range(n):
+            fr.steps[i].height = steps[i][0]
+            for k in range(8):
+                fr.steps[i].quad[k] = steps[i][1 + k]
+        assert ssd.Stairs(fr).serialize() == c["line"]
+    fr = ssd.FrameResult()
+    fr.status = ssd.ST_THROW
+    assert ssd.Stairs(fr).serialize() == ""
+
+
+def test_wire_format_parses_like_the_ros_node(ssd, oracle):
+    """ros/stair_step_detector_pkg/.../stair_step_detector.py:34-61 and print-stairs.py:55-71 index the line like this."""
+    import json
+    fr = ssd.FrameResult()
+    fr.n_steps = 2
+    for i in range(2):
+        fr.steps[i].height = 0.17 * i
+        for k in range(8):
+            fr.steps[i].quad[k] = 0.1 * k - 0.35
+    jdata = json.loads(ssd.Stairs(fr).serialize())
+    assert jdata[0] == "stairs" and jdata[1][1] == 2
+    assert jdata[2][1][0][1] == pytest.approx(0.17)
+    assert [len(jdata[2][0][1][k]) for k in range(1, 5)] == [2, 2, 2, 2]
+    fr.n_steps = 0
+    assert json.loads(ssd.Stairs(fr).serialize()) == ["stairs", ["stairSteps", 0]]
+
+
+def test_host_generator_is_deterministic_and_plausible(ssd):
+    sc = scenes.make(ssd, "vga_3steps_noise2mm")
+    a, b = ssd.synth_host([sc])[0], ssd.synth_host([sc])[0]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    sc.seed += 1
+    assert not np.array_equal(a, ssd.synth_host([sc])[0])
+    assert (a[..., 2] > 0).mean() > 0.95 and a[..., 2].max() < 9.0
+
+
+def test_oracle_runs_the_config1_frame(ssd, oracle):
+    """BASELINE.json config 1: one XGA frame, 3 steps, on the CPU path: ground + 3 treads at 0.17 m pitch."""
+    sc = scenes.make(ssd, "xga_config1")
+    t = ssd.transformation_for_scene(sc)
+    cfg = ssd.default_config(1024, 768)
+    xyz = ssd.synth_host([sc])[0]
+    res, *_ = oracle.process(ob.to_oracle_config(cfg), ob.to_oracle_calibration(t.constants), xyz)
+    assert res.n_steps == 4 and res.status == 0
+    heights = [res.steps_ext[i][0] for i in range(4)]
+    assert np.allclose(heights, [0.004, 0.174, 0.344, 0.514], atol=2e-3)
+    # pixel-pitch quantisation of corners: 1.2 m / 1024 px (SURVEY.md appendix A observed -0.40078125 on this scene type)
+    x0 = res.steps_ext[1][1]
+    assert abs(x0 - (-0.6 + 170 * 1.2 / 1024)) < 2 * 1.2 / 1024
+    line = res.line.decode()
+    assert line.startswith('["stairs",["stairSteps",4],[[["height",0.004],')
+    n, steps, status = oracle.process_lean(ob.to_oracle_config(cfg), ob.to_oracle_calibration(t.constants), xyz)
+    assert n == 4 and np.array_equal(steps, np.array([list(res.steps_ext[i]) for i in range(4)]))

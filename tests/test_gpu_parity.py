@@ -1,0 +1,139 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import parity
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+SCENES = sorted(scenes.scene_params().keys())
+
+
+def _setup(ssd, name, frames=1):
+    sc = scenes.make(ssd, name)
+    trans = ssd.transformation_for_scene(sc)
+    cfg = ssd.default_config(sc.width, sc.height, max_frames_per_batch=frames)
+    return sc, trans, cfg
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_frame_parity_all_intermediates(ssd, oracle, gpu_device, name):
+    """Every intermediate (histogram, peaks, plateau table, raw + closed images, scans, lines, probe points,
+    corners, in-quad counts, mean z) and the serialized line, frame by frame."""
+    sc, trans, cfg = _setup(ssd, name)
+    xyz = ssd.synth_host([sc])[0]
+    det = ssd.Detector(cfg, trans, gpu_device)
+    rep = parity.check_frame(ssd, oracle, det, cfg, trans.constants, xyz, images=True)
+    det.close()
+    assert rep.get("max_height_err", 0.0) <= parity.TOL_HEIGHT
+    assert rep.get("max_corner_err", 0.0) <= 1e-9
+
+
+def test_scene_set_covers_the_interesting_outcomes(ssd, oracle):
+    """Guards the fixture set itself (oracle only): it must contain N=0 lines, ground+steps, invalid plateaus."""
+    outcomes = set()
+    for name in ("xga_config1", "xga_no_stairs", "vga_empty", "xga_wide", "vga_8steps_outliers"):
+        sc, trans, cfg = _setup(ssd, name)
+        xyz = ssd.synth_host([sc])[0]
+        n, steps, status = oracle.process_lean(ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants), xyz)
+        outcomes.add((name, n))
+    d = dict(outcomes)
+    assert d["xga_config1"] == 4
+    assert d["xga_no_stairs"] == 0 and d["vga_empty"] == 0
+
+
+def test_device_generator_matches_host_generator(ssd, gpu_device):
+    sc_list = [scenes.make(ssd, "vga_yaw_outliers"), scenes.make(ssd, "vga_3steps_noise2mm"), scenes.make(ssd, "vga_8steps_outliers")]
+    host = ssd.synth_host(sc_list)
+    buf = ssd.DeviceBuffer(host.nbytes, gpu_device)
+    ssd.synth_device(sc_list, buf.ptr, device=gpu_device)
+    dev = buf.download(host.nbytes, dtype=np.float32).reshape(host.shape)
+    buf.free()
+    assert np.array_equal(host.view(np.uint32), dev.view(np.uint32))
+
+
+def test_batch_equals_single_frames_and_workspace_is_clean(ssd, oracle, gpu_device):
+    """A batch gives, frame by frame, what single-frame calls give; running it twice (images must have been
+    cleared by their consumers) gives the same again; results equal the oracle's."""
+    names = ["vga_3steps_clean", "vga_3steps_noise2mm", "vga_8steps_outliers", "vga_empty", "vga_yaw_outliers", "vga_3steps_clean"]
+    sc_list = [scenes.make(ssd, n) for n in names]
+    trans = ssd.transformation_for_scene(sc_list[0])
+    cfg = ssd.default_config(640, 480, max_frames_per_batch=4)      # 6 frames -> two chunks (4 + 2)
+    xyz = ssd.synth_host(sc_list)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    r1 = det.process_host(xyz)
+    r2 = det.process_host(xyz)
+    singles = [det.process_host(xyz[i])[0] for i in range(len(names))]
+    for i in range(len(names)):
+        assert bytes(r1[i]) == bytes(r2[i]), "second batch differs: workspace not clean (frame %d)" % i
+        assert bytes(r1[i]) == bytes(singles[i]), "batch differs from single-frame call (frame %d)" % i
+        parity.check_results_only(ssd, oracle, cfg, trans.constants, xyz[i], r1[i])
+    det.close()
+
+
+def test_device_resident_enqueue_fetch(ssd, oracle, gpu_device):
+    """The asynchronous entry points on frames generated in HBM, with a padded frame stride."""
+    sc_list = scenes.batch_scenes(ssd, 640, 480, 5)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    cfg = ssd.default_config(640, 480, max_frames_per_batch=8)
+    frame_bytes = 640 * 480 * 12
+    stride = frame_bytes + 256
+    buf = ssd.DeviceBuffer(stride * 5, gpu_device)
+    ssd.synth_device(sc_list, buf.ptr, stride_bytes=stride, device=gpu_device)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    det.set_timing(True)
+    det.enqueue(buf.ptr, 5, stride_bytes=stride)
+    res = det.fetch(5)
+    times = det.stage_times_ms()
+    assert all(t >= 0.0 for t in times.values()) and times["hist"] > 0.0
+    host = ssd.synth_host(sc_list)
+    for i in range(5):
+        parity.check_results_only(ssd, oracle, cfg, trans.constants, host[i], res[i])
+    det.close()
+    buf.free()
+
+
+def test_device_hypot_matches_libm(ssd, oracle, gpu_device):
+    rng = np.random.default_rng(3)
+    a = np.concatenate([rng.integers(-2000, 2000, 4000).astype(np.float64), rng.standard_normal(4000), rng.standard_normal(2000) * 1e-3])
+    b = np.concatenate([rng.integers(-2000, 2000, 4000).astype(np.float64), rng.standard_normal(4000), rng.standard_normal(2000) * 1e3])
+    out = np.zeros_like(a)
+    rc = ssd.lib().ssd_test_hypot_device(gpu_device, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                         out.ctypes.data_as(C.c_void_p), len(a))
+    assert rc == 0
+    want = np.array([oracle.hypot(float(x), float(y)) for x, y in zip(a, b)])
+    assert np.array_equal(out, want)
+
+
+def test_full_size_properties_xga_batch(ssd, oracle, gpu_device):
+    """BASELINE.json config 3 shape at reduced count: size-independent properties on XGA frames in HBM —
+    determinism (bitwise), permutation equivariance over frames, histogram mass = in-range count, and an
+    oracle spot check of every 8th frame."""
+    n = 24
+    sc_list = scenes.batch_scenes(ssd, 1024, 768, n, base_seed=5000)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    cfg = ssd.default_config(1024, 768, max_frames_per_batch=n)
+    frame_bytes = 1024 * 768 * 12
+    buf = ssd.DeviceBuffer(frame_bytes * n, gpu_device)
+    ssd.synth_device(sc_list, buf.ptr, device=gpu_device)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    det.enqueue(buf.ptr, n)
+    r1 = det.fetch(n)
+    det.enqueue(buf.ptr, n)
+    r2 = det.fetch(n)
+    assert [bytes(x) for x in r1] == [bytes(x) for x in r2]
+    perm = list(reversed(range(n)))
+    ssd.synth_device([sc_list[i] for i in perm], buf.ptr, device=gpu_device)
+    det.enqueue(buf.ptr, n)
+    r3 = det.fetch(n)
+    assert [bytes(r3[j]) for j in range(n)] == [bytes(r1[perm[j]]) for j in range(n)]
+    assert sum(1 for r in r1 if r.n_steps >= 3) >= n // 2
+    host = ssd.synth_host([sc_list[i] for i in range(0, n, 8)])
+    for k, i in enumerate(range(0, n, 8)):
+        parity.check_results_only(ssd, oracle, cfg, trans.constants, host[k], r1[i])
+    det.close()
+    buf.free()
