@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of the per-frame point-cloud path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (N = 1: BASELINE.json configs[2]): a batch of F = 1024 synthetic 1024x768 frames (3-step staircases
+with randomised rise / tread / yaw / noise), resident in HBM when the timed region starts.  One "step" = one
+pass of the whole path (K1 hist .. K5 final + results to the host) over the batch.  For N > 1 every rank owns
+its own F frames on its own GPU (frames are independent: no collective on the data path; weak scaling) and
+value = N * F * K / max-over-ranks time.
+
+PyTorch is plumbing here: device memory, the stream, the barrier and the max-reduce.  The hot path is
+libssd_hip.so through its C ABI.  The CPU oracle is used only for the cpu_baseline leg and the parity
+spot check, both outside the timed region.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec; ~6.3 TB/s achievable by a float4 copy)
+METRIC = "point-cloud frames/sec (1024×768 pts) at 1/2/4/8 GPUs; step height/corner max-abs err"
+
+
+def shard(total, world, rank):
+    """Contiguous frame range of `rank`: frame i -> rank i*world//total."""
+    lo = (total * rank + world - 1) // world
+    hi = (total * (rank + 1) + world - 1) // world
+    return lo, hi
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=1024, help="frames per GPU per step")
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=768)
+    ap.add_argument("--cpu-frames", type=int, default=192, help="bounded CPU-baseline sample (frames)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1) and world > 1:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible; the HIP path is mandatory (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    ssd = importlib.import_module("stair-step-detector_amd")
+    import scenes
+
+    W, H, F = args.width, args.height, args.frames
+    frame_bytes = W * H * 12
+    # frames of this rank: a contiguous range of the global frame index space (no overlap between ranks)
+    lo, hi = shard(F * world, world, rank)
+    assert hi - lo == F
+    sc_list = scenes.batch_scenes(ssd, W, H, F, base_seed=100000 + lo, rng_seed=1000 + rank)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    cfg = ssd.default_config(W, H, max_frames_per_batch=F)
+    frames = torch.empty(F * frame_bytes, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    ssd.synth_device(sc_list, frames.data_ptr(), device=local_rank, stream=stream)
+    det = ssd.Detector(cfg, trans, local_rank)
+    det.set_timing(True)
+
+    def step():
+        det.enqueue(frames.data_ptr(), F, stream=stream)
+        return det.fetch(F, stream=stream)
+
+    for _ in range(args.warmup):
+        res = step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+
+    # per-stage device times of the timed steps (HIP events recorded on the kernels' stream)
+    n_timed = min(args.steps, 63)
+    stage = {k: 0.0 for k in ssd.STAGE_NAMES}
+    for b in range(n_timed):
+        for k, v in det.stage_times_ms(b).items():
+            stage[k] += v / n_timed
+
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+
+    if rank == 0:
+        value = world * F * args.steps / dt_max
+        k1_ms = stage["hist"]
+        alg_bytes = 12.0 * W * H * F                       # 12 B per raw point, read once
+        achieved = alg_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_k_hist.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch_at_%dx%dx%d" % (W, H, F))
+            except Exception:
+                traffic = None
+        out = {
+            "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: batch of %d synthetic %dx%d frames (3-step staircases, randomised rise/"
+                                   "tread/yaw/noise) resident in HBM, streamed through the whole per-frame path; per GPU" % (F, W, H),
+                       "frames_per_gpu_per_step": F, "width": W, "height": H, "parallelism": "frame-sharded x%d, no collective" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_hist (K1: transform+crop+bin+histogram)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms},
+            "stage_ms": stage,
+            "pipeline_bytes_algorithmic_frac_of_peak": (alg_bytes * args.steps / dt_max / 1e9) / HBM_PEAK_GBS,
+        }
+        steps_hist = [r.n_steps for r in res]
+        out["frames_with_ground_and_3_steps"] = int(sum(1 for n in steps_hist if n == 4))
+
+        if not args.no_cpu:
+            import oracle_binding as ob
+            import parity
+            oracle = ob.load_oracle()
+            ocfg, ocal = ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants)
+            n_cpu = max(1, min(args.cpu_frames, F))
+            idx = [int(i) for i in np.linspace(0, F - 1, n_cpu)]
+            host = [frames[i * frame_bytes:(i + 1) * frame_bytes].cpu().numpy().view(np.float32) for i in idx]
+            rep = {}
+            c0 = time.perf_counter()
+            cpu_out = [oracle.process_lean(ocfg, ocal, x) for x in host]
+            cdt = time.perf_counter() - c0
+            checked = 0
+            for i, x in zip(idx, host):
+                if i % 64 == 0 or i == idx[-1]:
+                    parity.check_results_only(ssd, oracle, cfg, trans.constants, x, res[i], rep)
+                    checked += 1
+            out["cpu_baseline"] = {"value": n_cpu / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": "%d of the %d frames of rank 0's batch (evenly spaced), whole path incl. naive-free "
+                                             "separable 3x3 close, oracle/ssd_oracle.cpp single thread, %.1f s" % (n_cpu, F, cdt)}
+            out["parity"] = {"frames_checked_against_oracle": checked, "max_abs_height_err_m": rep.get("max_height_err", 0.0),
+                             "max_abs_corner_err_m": rep.get("max_corner_err", 0.0), "bar_m": 1e-4}
+        print(json.dumps(out), flush=True)
+
+    det.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -127,8 +127,12 @@ int ssd_enqueue_stages(ssd_handle *h, const void *d_xyz, size_t frame_stride_byt
 
 /* Per-stage device time of the last enqueue, measured with HIP events recorded on the stream the kernels
  * run on: ms[0..6] = hist, peaks, raster, outline, quads, inquad, final.  Enable before enqueueing. */
+#define SSD_TIMING_SLOTS 64
 int ssd_set_timing(ssd_handle *h, int enable);
 int ssd_get_stage_times(ssd_handle *h, float ms[7]);
+/* the same for an earlier enqueue: back = 0 is the last, 1 the one before, ... (< SSD_TIMING_SLOTS),
+ * so a timed loop can read all its steps after one final synchronisation */
+int ssd_get_stage_times_back(ssd_handle *h, int back, float ms[7]);
 
 /* Stairs::serialize(): returns the text length, or SSD_E_CAP. A frame whose status has SSD_ST_THROW
  * serialises to the empty string (the reference process terminates instead of printing). */

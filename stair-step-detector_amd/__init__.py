@@ -110,7 +110,7 @@ EXPORTS = [
     "ssd_default_config", "ssd_calibration_from_points", "ssd_calibration_identity",
     "ssd_create", "ssd_destroy", "ssd_last_error", "ssd_workspace_bytes",
     "ssd_process_host", "ssd_enqueue", "ssd_fetch", "ssd_enqueue_stages",
-    "ssd_set_timing", "ssd_get_stage_times", "ssd_serialize",
+    "ssd_set_timing", "ssd_get_stage_times", "ssd_get_stage_times_back", "ssd_serialize",
     "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
     "ssd_synth_generate_host", "ssd_synth_generate_device", "ssd_synth_scene_to_camera",
     "ssd_device_count", "ssd_device_alloc", "ssd_device_free", "ssd_device_upload", "ssd_device_download",
@@ -144,6 +144,7 @@ def lib():
     L.ssd_fetch.argtypes = [vp, C.POINTER(FrameResult), i32, vp]
     L.ssd_set_timing.argtypes = [vp, i32]
     L.ssd_get_stage_times.argtypes = [vp, C.POINTER(C.c_float)]
+    L.ssd_get_stage_times_back.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.ssd_serialize.argtypes = [C.POINTER(FrameResult), C.c_char_p, sz]
     L.ssd_set_debug.argtypes = [vp, i32]
     L.ssd_get_debug.argtypes = [vp, i32, C.POINTER(DebugFrame)]
@@ -265,9 +266,10 @@ class Detector:
     def set_timing(self, on=True):
         _check(lib().ssd_set_timing(self._h, 1 if on else 0))
 
-    def stage_times_ms(self):
+    def stage_times_ms(self, back=0):
+        """Device time per stage of the enqueue `back` calls ago (HIP events on the kernels' stream)."""
         ms = (C.c_float * 7)()
-        _check(lib().ssd_get_stage_times(self._h, ms))
+        _check(lib().ssd_get_stage_times_back(self._h, back, ms))
         return dict(zip(STAGE_NAMES, [float(x) for x in ms]))
 
     def set_debug(self, on=True):

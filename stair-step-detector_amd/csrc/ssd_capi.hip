@@ -64,12 +64,11 @@ struct ssd_handle
   bool imagesDirty = false;
   int lastFrames = 0;
   size_t bytes = 0;
-  /* per-stage timing */
+  /* per-stage timing: a ring of event sets, one per enqueue, so that a timed loop never has to synchronise */
   bool timing = false;
-  hipEvent_t ev[9]{};
-  bool evCreated = false;
-  bool evValid = false;
-  int evStages = 0;
+  std::vector<hipEvent_t> ev;     /* kTimingSlots x 8 */
+  unsigned long long enqueueCount = 0;
+  unsigned long long timedFrom = 0;
 };
 
 extern "C"
@@ -282,9 +281,8 @@ int ssd_destroy(ssd_handle *h)
   if(h->dFrames) (void)hipFree(h->dFrames);
   if(h->dDebug) (void)hipFree(h->dDebug);
   if(h->dDebugImg) (void)hipFree(h->dDebugImg);
-  if(h->evCreated)
-    for(hipEvent_t e : h->ev)
-      (void)hipEventDestroy(e);
+  for(hipEvent_t e : h->ev)
+    (void)hipEventDestroy(e);
   delete h;
   return SSD_OK;
 }
@@ -315,14 +313,14 @@ int ssd_set_timing(ssd_handle *h, int enable)
   if(!h)
     return fail(SSD_E_ARG, "ssd_set_timing: null handle");
   HIP_TRY(hipSetDevice(h->device));
-  if(enable && !h->evCreated)
+  if(enable && h->ev.empty())
   {
+    h->ev.resize(static_cast<size_t>(SSD_TIMING_SLOTS) * 8);
     for(hipEvent_t &e : h->ev)
       HIP_TRY(hipEventCreate(&e));
-    h->evCreated = true;
   }
   h->timing = enable != 0;
-  h->evValid = false;
+  h->timedFrom = h->enqueueCount;
   return SSD_OK;
 }
 
@@ -359,8 +357,8 @@ int ssd_enqueue_stages(ssd_handle *h, const void *d_xyz, size_t frame_stride_byt
   const int chunk = choose_chunk(P.nPoints, nframes);
   DebugFrame *dbg = h->debug ? h->dDebug : nullptr;
   unsigned long long *dbgImg = h->debug ? h->dDebugImg : nullptr;
-  const bool timing = h->timing && h->evCreated;
-  int evi = 0;
+  const bool timing = h->timing && !h->ev.empty();
+  int evi = static_cast<int>(h->enqueueCount % SSD_TIMING_SLOTS) * 8;
   auto mark = [&]() { if(timing) (void)hipEventRecord(h->ev[evi++], s); };
 
   if(h->imagesDirty)
@@ -402,8 +400,7 @@ int ssd_enqueue_stages(ssd_handle *h, const void *d_xyz, size_t frame_stride_byt
   if(((stages & SSD_STAGE_RASTER) && !(stages & SSD_STAGE_OUTLINE)) || ((stages & SSD_STAGE_INQUAD) && !(stages & SSD_STAGE_FINAL)))
     h->imagesDirty = true;
   h->lastFrames = nframes;
-  h->evValid = timing;
-  h->evStages = stages;
+  h->enqueueCount++;
   return SSD_OK;
 }
 
@@ -412,18 +409,26 @@ int ssd_enqueue(ssd_handle *h, const void *d_xyz, size_t frame_stride_bytes, int
   return ssd_enqueue_stages(h, d_xyz, frame_stride_bytes, nframes, stream, SSD_STAGE_ALL);
 }
 
-/* milliseconds of the 7 stages of the last enqueue (needs ssd_set_timing(h,1)); waits for the stream */
-int ssd_get_stage_times(ssd_handle *h, float ms[7])
+/* milliseconds of the 7 stages of a timed enqueue; `back` = 0 is the last one, 1 the one before, ...
+ * (at most SSD_TIMING_SLOTS - 1 back, and not before timing was switched on); waits for that enqueue */
+int ssd_get_stage_times_back(ssd_handle *h, int back, float ms[7])
 {
   if(!h || !ms)
     return fail(SSD_E_ARG, "ssd_get_stage_times: null");
-  if(!h->evValid)
-    return fail(SSD_E_ARG, "ssd_get_stage_times: timing was not enabled for the last enqueue");
+  if(!h->timing || h->ev.empty() || back < 0 || back >= SSD_TIMING_SLOTS ||
+     h->enqueueCount < static_cast<unsigned long long>(back) + 1 || h->enqueueCount - 1 - back < h->timedFrom)
+    return fail(SSD_E_ARG, "ssd_get_stage_times: no timed enqueue at that position");
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipEventSynchronize(h->ev[7]));
+  const int base = static_cast<int>((h->enqueueCount - 1 - back) % SSD_TIMING_SLOTS) * 8;
+  HIP_TRY(hipEventSynchronize(h->ev[base + 7]));
   for(int i = 0; i < 7; i++)
-    HIP_TRY(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    HIP_TRY(hipEventElapsedTime(&ms[i], h->ev[base + i], h->ev[base + i + 1]));
   return SSD_OK;
+}
+
+int ssd_get_stage_times(ssd_handle *h, float ms[7])
+{
+  return ssd_get_stage_times_back(h, 0, ms);
 }
 
 int ssd_fetch(ssd_handle *h, ssd_frame_result *results, int nframes, void *stream)
