@@ -74,6 +74,10 @@ struct FrameState
   int nPlateaus, firstStep, nStepImages, groundInd, firstValidInd;
   int groundFrontValid;
   unsigned char lut[kMaxBins];     /* bin -> plateau index, 0xff = none */
+  /* bounding box of the raw bits of each step image ([kMaxStepImages] = ground image): rows and 32-bit
+   * word columns, written by the rasterising kernels, read by the kernels that close and scan the image */
+  int imgYMin[kMaxStepImages + 1], imgYMax[kMaxStepImages + 1];
+  int imgXMin[kMaxStepImages + 1], imgXMax[kMaxStepImages + 1];
   PlateauState pl[kMaxPlateaus];
   double groundQuadWorld[8];
   QuadTest qt[kMaxPlateaus + 1];   /* [kGroundAcc] = ground */

@@ -53,96 +53,72 @@ __device__ __forceinline__ int height_bin(const Params &P, double wz)
 /* K1: histogram                                                              */
 
 constexpr int kThreads = 256;
-constexpr int kPts = 4;                 /* points per thread per iteration */
+constexpr int kPts = 4;                 /* points per thread per iteration: four CONSECUTIVE points (48 B) */
 constexpr int kTile = kThreads * kPts;  /* 1024 points per block iteration */
+constexpr int kHistCopies = 32;         /* LDS histogram privatised by lane & 31: bank = copy, no conflicts */
 
-/* Adds one vote per valid lane to a wave-private LDS histogram.  Equal bins inside the wave
- * (the common case: a camera row sweeps one plateau) are merged with ballots so that one lane
- * issues one ds_add per distinct bin; after kMaxDistinct rounds the rest falls back to per-lane
- * LDS atomics. */
-__device__ __forceinline__ void wave_hist_add(unsigned int *h, const int (&bin)[kPts], int lane)
+/* Four consecutive points of one lane.  ALIGNED: three 16-byte loads (lanes 48 B apart; the three
+ * instructions of a wave together cover 3 KiB contiguously — measured 6.2-6.3 TB/s on MI355X, the same as
+ * a plain float4 stream, tools/loadbench.hip).  Otherwise (frame base/stride not 16-byte aligned, or the
+ * tail of a frame whose point count is not a multiple of 4): 12-byte loads. */
+template<bool ALIGNED>
+__device__ __forceinline__ void load_points(const float *__restrict__ base, int idx0, int end, F3 (&v)[kPts])
 {
-  constexpr int kMaxDistinct = 12;
-  unsigned long long act[kPts];
+  if(ALIGNED && idx0 + kPts <= end)
+  {
+    const float4 *q = reinterpret_cast<const float4 *>(base + 3 * static_cast<size_t>(idx0));
+    const float4 a = q[0], b = q[1], c = q[2];
+    v[0] = F3{ a.x, a.y, a.z };
+    v[1] = F3{ a.w, b.x, b.y };
+    v[2] = F3{ b.z, b.w, c.x };
+    v[3] = F3{ c.y, c.z, c.w };
+    return;
+  }
 #pragma unroll
   for(int j = 0; j < kPts; j++)
-    act[j] = __ballot(bin[j] >= 0);
-
-  for(int round = 0; ; round++)
   {
-    int j0 = -1;
-#pragma unroll
-    for(int j = kPts - 1; j >= 0; j--)
-      if(act[j]) j0 = j;
-    if(j0 < 0)
-      break;
-    if(round == kMaxDistinct)
-    {
-#pragma unroll
-      for(int j = 0; j < kPts; j++)
-        if((act[j] >> lane) & 1ull)
-          atomicAdd(&h[bin[j]], 1u);
-      break;
-    }
-    int src = bin[0];
-    unsigned long long a0 = act[0];
-#pragma unroll
-    for(int j = 1; j < kPts; j++)
-      if(j == j0) { src = bin[j]; a0 = act[j]; }
-    const int leader = __ffsll(static_cast<long long>(a0)) - 1;
-    const int b = __builtin_amdgcn_readlane(src, leader);
-    unsigned int cnt = 0;
-#pragma unroll
-    for(int j = 0; j < kPts; j++)
-    {
-      const unsigned long long m = __ballot(bin[j] == b);
-      cnt += static_cast<unsigned int>(__popcll(m));
-      act[j] &= ~m;
-    }
-    if(lane == 0)
-      atomicAdd(&h[b], cnt);
+    const int idx = idx0 + j;
+    v[j] = F3{ 0.0f, 0.0f, 0.0f };
+    if(idx < end)
+      v[j] = *reinterpret_cast<const F3 *>(base + 3 * static_cast<size_t>(idx));
   }
 }
 
+template<bool ALIGNED>
 __global__ __launch_bounds__(kThreads) void k_hist(const float *__restrict__ xyz, size_t strideFloats, Params P,
                                                    FrameState *__restrict__ st, int chunkPoints)
 {
-  __shared__ unsigned int lh[kThreads / 64][kMaxBins];
+  /* [bin][copy]: a vote goes to copy = lane & 31, i.e. LDS bank = copy: the 32 lanes the LDS serves per
+   * cycle never collide, whatever their bins (a camera row sweeping one plateau puts all 64 lanes in one bin) */
+  __shared__ unsigned int lh[kMaxBins * kHistCopies];
   __shared__ unsigned int lNonZero;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int frame = blockIdx.y;
   const float *base = xyz + static_cast<size_t>(frame) * strideFloats;
   const int begin = blockIdx.x * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
 
-  for(int i = tid; i < (kThreads / 64) * kMaxBins; i += kThreads)
-    (&lh[0][0])[i] = 0;
+  for(int i = tid; i < kMaxBins * kHistCopies; i += kThreads)
+    lh[i] = 0;
   if(tid == 0)
     lNonZero = 0;
   __syncthreads();
 
+  unsigned int *mine = lh + (lane & (kHistCopies - 1));
   unsigned int nz = 0;
   for(int i0 = begin; i0 < end; i0 += kTile)
   {
     F3 v[kPts];
-#pragma unroll
-    for(int j = 0; j < kPts; j++)
-    {
-      const int idx = i0 + j * kThreads + tid;
-      v[j] = F3{ 0.0f, 0.0f, 0.0f };
-      if(idx < end)
-        v[j] = *reinterpret_cast<const F3 *>(base + 3 * static_cast<size_t>(idx));
-    }
-    int bin[kPts];
+    load_points<ALIGNED>(base, i0 + kPts * tid, end, v);
 #pragma unroll
     for(int j = 0; j < kPts; j++)
     {
       double wx, wy, wz;
       nz += v[j].z > 0.0f ? 1u : 0u;
-      bin[j] = world_point(P, v[j], wx, wy, wz) ? height_bin(P, wz) : -1;
+      if(world_point(P, v[j], wx, wy, wz))
+        atomicAdd(mine + height_bin(P, wz) * kHistCopies, 1u);          /* ++hist[bin], pointcloud.cpp:199-202 */
     }
-    wave_hist_add(lh[wave], bin, lane);
   }
 
   /* wave-reduce the non-zero count */
@@ -158,8 +134,8 @@ __global__ __launch_bounds__(kThreads) void k_hist(const float *__restrict__ xyz
   {
     unsigned int s = 0;
 #pragma unroll
-    for(int w = 0; w < kThreads / 64; w++)
-      s += lh[w][b];
+    for(int k = 0; k < kHistCopies; k++)
+      s += lh[b * kHistCopies + ((k + tid) & (kHistCopies - 1))];      /* rotated: conflict-free */
     if(s)
       atomicAdd(&fs.hist[b], s);
   }
@@ -279,6 +255,11 @@ __global__ void k_peaks(Params P, FrameState *__restrict__ st, int nframes, Debu
   }
   fs.nStepImages = nImg;
   fs.firstValidInd = -1;
+  for(int k = 0; k <= kMaxStepImages; k++)          /* [kMaxStepImages] = the ground image */
+  {
+    fs.imgYMin[k] = 0x7fffffff; fs.imgYMax[k] = -1;
+    fs.imgXMin[k] = 0x7fffffff; fs.imgXMax[k] = -1;
+  }
   if(overflow)
     fs.status |= SSD_ST_OVERFLOW;
 
@@ -310,14 +291,45 @@ __global__ void k_peaks(Params P, FrameState *__restrict__ st, int nframes, Debu
 /* ========================================================================= */
 /* K2: raster the step plateaus into bit images                               */
 
+constexpr unsigned int kNoKey = 0xffffffffu;
+
+/* ORs `mask` into word `key` of a bit-image array for every lane with key != kNoKey, after merging the
+ * lanes of a wave that hit the same word: neighbouring camera pixels land on neighbouring image pixels, so
+ * runs of equal keys are contiguous in the lane order.  Segmented inclusive OR-scan over the run (6 steps),
+ * then the last lane of each run issues one global atomic.  Must be called by all 64 lanes. */
+__device__ __forceinline__ void wave_merged_or(unsigned int *__restrict__ words, unsigned int key, unsigned int mask, int lane)
+{
+#pragma unroll
+  for(int d = 1; d < 64; d <<= 1)
+  {
+    const unsigned int k2 = __shfl_up(key, d);
+    const unsigned int m2 = __shfl_up(mask, d);
+    if(lane >= d && k2 == key)
+      mask |= m2;
+  }
+  const unsigned int kn = __shfl_down(key, 1);
+  if(key != kNoKey && (lane == 63 || kn != key))
+    atomicOr(words + key, mask);
+}
+
+/* Projection2D::worldToImage (pointcloud.cpp:79-83); false = outside the image (quirk Q5) */
+__device__ __forceinline__ bool image_pixel(const Params &P, double wx, double wy, int &ix, int &iy)
+{
+  ix = static_cast<int>((wx - P.xMin) * P.xToImage);
+  iy = static_cast<int>((P.yMax - wy) * P.yToImage);
+  return ix >= 0 && ix < P.W && iy >= 0 && iy < P.H;
+}
+
+template<bool ALIGNED>
 __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ xyz, size_t strideFloats, Params P,
                                                      FrameState *__restrict__ st, unsigned int *__restrict__ stepImg,
                                                      int chunkPoints)
 {
   __shared__ unsigned char lut[kMaxBins];
   __shared__ unsigned int lOob;
+  __shared__ int lYMin[kMaxStepImages], lYMax[kMaxStepImages], lXMin[kMaxStepImages], lXMax[kMaxStepImages];
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int frame = blockIdx.y;
   FrameState &fs = st[frame];
   const int nImg = fs.nStepImages;
@@ -326,6 +338,11 @@ __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ x
   const int firstStep = fs.firstStep;
   if(tid < kMaxBins)
     lut[tid] = fs.lut[tid];
+  if(tid < kMaxStepImages)
+  {
+    lYMin[tid] = 0x7fffffff; lYMax[tid] = -1;
+    lXMin[tid] = 0x7fffffff; lXMax[tid] = -1;
+  }
   if(tid == 0)
     lOob = 0;
   __syncthreads();
@@ -334,21 +351,41 @@ __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ x
   const int begin = blockIdx.x * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
   const int W32 = P.W64 * 2;
-  const size_t imgWords = static_cast<size_t>(P.H) * W32;
+  const unsigned int imgWords = static_cast<unsigned int>(P.H) * W32;
   unsigned int *frameImg = stepImg + static_cast<size_t>(frame) * P.maxStepImages * imgWords;
   unsigned int oob = 0;
+  /* bounding box (rows, 32-bit word columns) of the bits this thread sets, kept in registers per image and
+   * flushed to LDS only when the thread moves on to another image (a thread walks down a camera column) */
+  int bSlot = -1, bY0 = 0, bY1 = 0, bX0 = 0, bX1 = 0;
+  auto flushBox = [&]()
+  {
+    if(bSlot >= 0)
+    {
+      atomicMin(&lYMin[bSlot], bY0); atomicMax(&lYMax[bSlot], bY1);
+      atomicMin(&lXMin[bSlot], bX0); atomicMax(&lXMax[bSlot], bX1);
+    }
+  };
+  auto noteBox = [&](int slot, int iy, int xw)
+  {
+    if(slot != bSlot)
+    {
+      flushBox();
+      bSlot = slot; bY0 = bY1 = iy; bX0 = bX1 = xw;
+    }
+    else
+    {
+      bY0 = min(bY0, iy); bY1 = max(bY1, iy);
+      bX0 = min(bX0, xw); bX1 = max(bX1, xw);
+    }
+  };
 
   for(int i0 = begin; i0 < end; i0 += kTile)
   {
     F3 v[kPts];
-#pragma unroll
-    for(int j = 0; j < kPts; j++)
-    {
-      const int idx = i0 + j * kThreads + tid;
-      v[j] = F3{ 0.0f, 0.0f, 0.0f };
-      if(idx < end)
-        v[j] = *reinterpret_cast<const F3 *>(base + 3 * static_cast<size_t>(idx));
-    }
+    load_points<ALIGNED>(base, i0 + kPts * tid, end, v);
+    /* the lane's four neighbouring pixels: merge those that share a word, keep one primary word for
+     * the cross-lane merge, send the (rare) others straight to memory */
+    unsigned int pKey = kNoKey, pMask = 0;
 #pragma unroll
     for(int j = 0; j < kPts; j++)
     {
@@ -358,20 +395,35 @@ __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ x
       const int slot = static_cast<int>(lut[height_bin(P, wz)]) - firstStep;   /* 0xff - firstStep >= nImg */
       if(slot < 0 || slot >= nImg)
         continue;
-      /* Projection2D::worldToImage (pointcloud.cpp:79-83) */
-      const int ix = static_cast<int>((wx - P.xMin) * P.xToImage);
-      const int iy = static_cast<int>((P.yMax - wy) * P.yToImage);
-      if(ix < 0 || ix >= P.W || iy < 0 || iy >= P.H)
+      int ix, iy;
+      if(!image_pixel(P, wx, wy, ix, iy))
       {
         oob++;                                              /* quirk Q5 */
         continue;
       }
-      atomicOr(frameImg + slot * imgWords + static_cast<size_t>(iy) * W32 + (ix >> 5), 1u << (ix & 31));
+      const unsigned int key = static_cast<unsigned int>(slot) * imgWords + static_cast<unsigned int>(iy) * W32 + (ix >> 5);
+      const unsigned int bit = 1u << (ix & 31);
+      if(key != pKey)
+        noteBox(slot, iy, ix >> 5);
+      if(pKey == kNoKey || key == pKey)
+      {
+        pKey = key;
+        pMask |= bit;
+      }
+      else
+        atomicOr(frameImg + key, bit);
     }
+    wave_merged_or(frameImg, pKey, pMask, lane);
   }
+  flushBox();
   if(oob)
     atomicAdd(&lOob, oob);
   __syncthreads();
+  if(tid < nImg && lYMax[tid] >= 0)
+  {
+    atomicMin(&fs.imgYMin[tid], lYMin[tid]); atomicMax(&fs.imgYMax[tid], lYMax[tid]);
+    atomicMin(&fs.imgXMin[tid], lXMin[tid]); atomicMax(&fs.imgXMax[tid], lXMax[tid]);
+  }
   if(tid == 0 && lOob)
   {
     atomicAdd(&fs.nOob, lOob);
@@ -663,14 +715,24 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
     dbgRaw = dbgImg + ((static_cast<size_t>(frame) * (P.maxStepImages + 1) + slot) * 2) * imgWords;
     dbgClosed = dbgRaw + imgWords;
   }
-  for(int idx = tid; idx < P.H * P.W64; idx += kThreads)
+  /* the closing of a set never leaves the bounding box of the set: only that window is visited
+   * (with debug capture on, the whole image, so that the captured images are complete) */
+  int by0 = fs.imgYMin[slot], by1 = fs.imgYMax[slot], bc0 = fs.imgXMin[slot] >> 1, bc1 = fs.imgXMax[slot] >> 1;
+  const bool emptyImg = by1 < by0;
+  if(dbgImg)
   {
-    const int y = idx / P.W64, c = idx - y * P.W64;
+    by0 = 0; by1 = P.H - 1; bc0 = 0; bc1 = P.W64 - 1;
+  }
+  const int bw = emptyImg && !dbgImg ? 0 : bc1 - bc0 + 1, bh = emptyImg && !dbgImg ? 0 : by1 - by0 + 1;
+  for(int idx = tid; idx < bw * bh; idx += kThreads)
+  {
+    const int ry = idx / bw;
+    const int y = by0 + ry, c = bc0 + (idx - ry * bw);
     const unsigned long long cw = closed_word(im, y, c);
     if(dbgImg)
     {
-      dbgRaw[idx] = img[idx];
-      dbgClosed[idx] = cw;
+      dbgRaw[y * P.W64 + c] = img[y * P.W64 + c];
+      dbgClosed[y * P.W64 + c] = cw;
     }
     if(cw == 0ull)
       continue;
@@ -1004,10 +1066,19 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
   }
   __syncthreads();
 
-  /* leave the raw image zeroed for the next batch */
-  for(int idx = tid; idx < P.H * P.W64; idx += kThreads)
-    if(img[idx])
-      img[idx] = 0ull;
+  /* leave the raw image zeroed for the next batch (all its bits lie inside the bounding box) */
+  if(!emptyImg)
+  {
+    const int cy0 = fs.imgYMin[slot], cc0 = fs.imgXMin[slot] >> 1;
+    const int cw = (fs.imgXMax[slot] >> 1) - cc0 + 1, ch = fs.imgYMax[slot] - cy0 + 1;
+    for(int idx = tid; idx < cw * ch; idx += kThreads)
+    {
+      const int ry = idx / cw;
+      const size_t o = static_cast<size_t>(cy0 + ry) * P.W64 + cc0 + (idx - ry * cw);
+      if(img[o])
+        img[o] = 0ull;
+    }
+  }
 }
 
 /* ========================================================================= */
@@ -1298,6 +1369,7 @@ __global__ void k_quads(Params P, FrameState *__restrict__ st, int nframes, Debu
 /* ========================================================================= */
 /* K4: in-quadrilateral filter, z sums, ground image                           */
 
+template<bool ALIGNED>
 __global__ __launch_bounds__(kThreads) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, Params P,
                                                      FrameState *__restrict__ st, unsigned int *__restrict__ groundImg,
                                                      int chunkPoints)
@@ -1307,6 +1379,8 @@ __global__ __launch_bounds__(kThreads) void k_inquad(const float *__restrict__ x
   __shared__ unsigned char active[kMaxPlateaus + 1];
   __shared__ unsigned long long lsum[kMaxPlateaus + 1][8];
   __shared__ unsigned int lcnt[kMaxPlateaus + 1][8];
+  __shared__ int lBox[4];
+  __shared__ unsigned int lOob;
   __shared__ int anyActive;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1318,6 +1392,8 @@ __global__ __launch_bounds__(kThreads) void k_inquad(const float *__restrict__ x
     for(int k = 0; k <= kMaxPlateaus; k++)
       a |= fs.accActive[k];
     anyActive = a;
+    lBox[0] = 0x7fffffff; lBox[1] = -1; lBox[2] = 0x7fffffff; lBox[3] = -1;
+    lOob = 0;
   }
   __syncthreads();
   if(!anyActive)
@@ -1351,17 +1427,27 @@ __global__ __launch_bounds__(kThreads) void k_inquad(const float *__restrict__ x
   unsigned int *gimg = groundImg + static_cast<size_t>(frame) * P.H * W32;
   const int copy = lane & 7;
 
+  /* calcAverageZ (pointcloud.cpp:574-581) as an order-independent fixed-point sum: a thread walks down a
+   * camera column, so consecutive hits nearly always belong to the same quadrilateral — the running sum
+   * stays in registers and goes to LDS only when the quadrilateral changes */
+  int curQ = -1;
+  long long accZ = 0;
+  unsigned int accN = 0, oob = 0;
+  auto flushAcc = [&]()
+  {
+    if(curQ >= 0 && accN)
+    {
+      atomicAdd(&lsum[curQ][copy], static_cast<unsigned long long>(accZ));
+      atomicAdd(&lcnt[curQ][copy], accN);
+    }
+  };
+  int bY0 = 0x7fffffff, bY1 = -1, bX0 = 0x7fffffff, bX1 = -1;     /* bounding box of this thread's ground bits */
+
   for(int i0 = begin; i0 < end; i0 += kTile)
   {
     F3 v[kPts];
-#pragma unroll
-    for(int j = 0; j < kPts; j++)
-    {
-      const int idx = i0 + j * kThreads + tid;
-      v[j] = F3{ 0.0f, 0.0f, 0.0f };
-      if(idx < end)
-        v[j] = *reinterpret_cast<const F3 *>(base + 3 * static_cast<size_t>(idx));
-    }
+    load_points<ALIGNED>(base, i0 + kPts * tid, end, v);
+    unsigned int pKey = kNoKey, pMask = 0;
 #pragma unroll
     for(int j = 0; j < kPts; j++)
     {
@@ -1376,25 +1462,45 @@ __global__ __launch_bounds__(kThreads) void k_inquad(const float *__restrict__ x
         continue;
       if(!quad_test(qts[q], wx, wy))
         continue;
-      /* calcAverageZ (pointcloud.cpp:574-581) as an order-independent fixed-point sum */
-      const long long zf = __double2ll_rn(wz * static_cast<double>(1ll << kZFixShift));
-      atomicAdd(&lsum[q][copy], static_cast<unsigned long long>(zf));
-      atomicAdd(&lcnt[q][copy], 1u);
+      if(q != curQ)
+      {
+        flushAcc();
+        curQ = q; accZ = 0; accN = 0;
+      }
+      accZ += __double2ll_rn(wz * static_cast<double>(1ll << kZFixShift));
+      accN++;
       if(q == kGroundAcc)
       {
         /* projectToBinaryImage(pointsInQuadri) (pointcloud.cpp:531) */
-        const int ix = static_cast<int>((wx - P.xMin) * P.xToImage);
-        const int iy = static_cast<int>((P.yMax - wy) * P.yToImage);
-        if(ix < 0 || ix >= P.W || iy < 0 || iy >= P.H)
+        int ix, iy;
+        if(!image_pixel(P, wx, wy, ix, iy))
         {
-          atomicOr(&fs.status, static_cast<unsigned int>(SSD_ST_OOB_PIXEL));
-          atomicAdd(&fs.nOob, 1u);
+          oob++;
+          continue;
+        }
+        const unsigned int key = static_cast<unsigned int>(iy) * W32 + (ix >> 5);
+        const unsigned int bit = 1u << (ix & 31);
+        bY0 = min(bY0, iy); bY1 = max(bY1, iy);
+        bX0 = min(bX0, ix >> 5); bX1 = max(bX1, ix >> 5);
+        if(pKey == kNoKey || key == pKey)
+        {
+          pKey = key;
+          pMask |= bit;
         }
         else
-          atomicOr(gimg + static_cast<size_t>(iy) * W32 + (ix >> 5), 1u << (ix & 31));
+          atomicOr(gimg + key, bit);
       }
     }
+    wave_merged_or(gimg, pKey, pMask, lane);
   }
+  flushAcc();
+  if(bY1 >= 0)
+  {
+    atomicMin(&lBox[0], bY0); atomicMax(&lBox[1], bY1);
+    atomicMin(&lBox[2], bX0); atomicMax(&lBox[3], bX1);
+  }
+  if(oob)
+    atomicAdd(&lOob, oob);
   __syncthreads();
   if(tid <= kMaxPlateaus && active[tid])
   {
@@ -1409,6 +1515,19 @@ __global__ __launch_bounds__(kThreads) void k_inquad(const float *__restrict__ x
     {
       atomicAdd(reinterpret_cast<unsigned long long *>(&fs.sumZ[tid]), s);
       atomicAdd(&fs.cnt[tid], c);
+    }
+  }
+  if(tid == 0)
+  {
+    if(lBox[1] >= 0)
+    {
+      atomicMin(&fs.imgYMin[kMaxStepImages], lBox[0]); atomicMax(&fs.imgYMax[kMaxStepImages], lBox[1]);
+      atomicMin(&fs.imgXMin[kMaxStepImages], lBox[2]); atomicMax(&fs.imgXMax[kMaxStepImages], lBox[3]);
+    }
+    if(lOob)
+    {
+      atomicAdd(&fs.nOob, lOob);
+      atomicOr(&fs.status, static_cast<unsigned int>(SSD_ST_OOB_PIXEL));
     }
   }
 }
@@ -1465,15 +1584,25 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
       dbgRaw = dbgImg + ((static_cast<size_t>(frame) * (P.maxStepImages + 1) + P.maxStepImages) * 2) * imgWords;
       dbgClosed = dbgRaw + imgWords;
     }
-    const int firstRow = dbgImg ? 0 : yStop + 1;
-    for(int idx = tid + firstRow * P.W64; idx < P.H * P.W64; idx += kThreads)
+    int by0 = fs.imgYMin[kMaxStepImages], by1 = fs.imgYMax[kMaxStepImages];
+    int bc0 = fs.imgXMin[kMaxStepImages] >> 1, bc1 = fs.imgXMax[kMaxStepImages] >> 1;
+    const bool emptyImg = by1 < by0;
+    if(dbgImg)
     {
-      const int y = idx / P.W64, c = idx - y * P.W64;
+      by0 = 0; by1 = P.H - 1; bc0 = 0; bc1 = P.W64 - 1;
+    }
+    else if(by0 <= yStop)
+      by0 = yStop + 1;                               /* only rows below the image centre are probed */
+    const int bw = (emptyImg && !dbgImg) || by1 < by0 ? 0 : bc1 - bc0 + 1, bh = by1 - by0 + 1;
+    for(int idx = tid; idx < bw * bh; idx += kThreads)
+    {
+      const int ry = idx / bw;
+      const int y = by0 + ry, c = bc0 + (idx - ry * bw);
       const unsigned long long cw = closed_word(im, y, c);
       if(dbgImg)
       {
-        dbgRaw[idx] = img[idx];
-        dbgClosed[idx] = cw;
+        dbgRaw[y * P.W64 + c] = img[y * P.W64 + c];
+        dbgClosed[y * P.W64 + c] = cw;
       }
       if(cw == 0ull || y <= yStop)
         continue;
@@ -1625,11 +1754,19 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
   }
   __syncthreads();
 
-  /* leave the ground image zeroed for the next batch (written only when a ground accumulator was live) */
-  if(fs.firstValidInd >= 0 && fs.groundInd >= 0)
-    for(int idx = tid; idx < P.H * P.W64; idx += kThreads)
-      if(img[idx])
-        img[idx] = 0ull;
+  /* leave the ground image zeroed for the next batch (all its bits lie inside the bounding box) */
+  if(fs.imgYMax[kMaxStepImages] >= fs.imgYMin[kMaxStepImages])
+  {
+    const int cy0 = fs.imgYMin[kMaxStepImages], cc0 = fs.imgXMin[kMaxStepImages] >> 1;
+    const int cw = (fs.imgXMax[kMaxStepImages] >> 1) - cc0 + 1, ch = fs.imgYMax[kMaxStepImages] - cy0 + 1;
+    for(int idx = tid; idx < cw * ch; idx += kThreads)
+    {
+      const int ry = idx / cw;
+      const size_t o = static_cast<size_t>(cy0 + ry) * P.W64 + cc0 + (idx - ry * cw);
+      if(img[o])
+        img[o] = 0ull;
+    }
+  }
 }
 
 /* ========================================================================= */
@@ -1673,10 +1810,18 @@ namespace ssd
 
 static inline int chunks_for(int nPoints, int chunkPoints) { return (nPoints + chunkPoints - 1) / chunkPoints; }
 
+static inline bool aligned16(const float *xyz, size_t strideFloats, int nPoints)
+{
+  return (reinterpret_cast<uintptr_t>(xyz) & 15u) == 0 && (strideFloats & 3u) == 0 && (nPoints & 3) == 0;
+}
+
 void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, int nframes, int chunkPoints, hipStream_t s)
 {
   dim3 grid(chunks_for(P.nPoints, chunkPoints), nframes);
-  hipLaunchKernelGGL(k_hist, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, chunkPoints);
+  if(aligned16(xyz, strideFloats, P.nPoints))
+    hipLaunchKernelGGL(k_hist<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, chunkPoints);
+  else
+    hipLaunchKernelGGL(k_hist<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, chunkPoints);
 }
 void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s)
 {
@@ -1685,7 +1830,10 @@ void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg,
 void launch_raster(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned int *stepImg, int nframes, int chunkPoints, hipStream_t s)
 {
   dim3 grid(chunks_for(P.nPoints, chunkPoints), nframes);
-  hipLaunchKernelGGL(k_raster, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, stepImg, chunkPoints);
+  if(aligned16(xyz, strideFloats, P.nPoints))
+    hipLaunchKernelGGL(k_raster<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, stepImg, chunkPoints);
+  else
+    hipLaunchKernelGGL(k_raster<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, stepImg, chunkPoints);
 }
 void launch_outline(const Params &P, FrameState *st, unsigned long long *stepImg, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
 {
@@ -1699,7 +1847,10 @@ void launch_quads(const Params &P, FrameState *st, int nframes, DebugFrame *dbg,
 void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned int *groundImg, int nframes, int chunkPoints, hipStream_t s)
 {
   dim3 grid(chunks_for(P.nPoints, chunkPoints), nframes);
-  hipLaunchKernelGGL(k_inquad, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, groundImg, chunkPoints);
+  if(aligned16(xyz, strideFloats, P.nPoints))
+    hipLaunchKernelGGL(k_inquad<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, groundImg, chunkPoints);
+  else
+    hipLaunchKernelGGL(k_inquad<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, groundImg, chunkPoints);
 }
 void launch_final(const Params &P, FrameState *st, unsigned long long *groundImg, ssd_frame_result *results, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
 {

@@ -97,6 +97,27 @@ def test_device_resident_enqueue_fetch(ssd, oracle, gpu_device):
     buf.free()
 
 
+def test_unaligned_frames_take_the_12_byte_load_path(ssd, oracle, gpu_device):
+    """A frame stride that is not a multiple of 16 bytes makes the kernels fall back from 16-byte to
+    12-byte loads; results must not change."""
+    sc_list = scenes.batch_scenes(ssd, 640, 480, 3, base_seed=77)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    cfg = ssd.default_config(640, 480, max_frames_per_batch=4)
+    frame_bytes = 640 * 480 * 12
+    host = ssd.synth_host(sc_list)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    want = det.process_host(host)
+    stride = frame_bytes + 4
+    buf = ssd.DeviceBuffer(stride * 3 + 16, gpu_device)
+    for i in range(3):
+        buf.upload(host[i], offset=4 + i * stride)          # base pointer 4 (not 16) byte aligned as well
+    det.enqueue(buf.ptr + 4, 3, stride_bytes=stride)
+    got = det.fetch(3)
+    assert [bytes(x) for x in got] == [bytes(x) for x in want]
+    det.close()
+    buf.free()
+
+
 def test_device_hypot_matches_libm(ssd, oracle, gpu_device):
     rng = np.random.default_rng(3)
     a = np.concatenate([rng.integers(-2000, 2000, 4000).astype(np.float64), rng.standard_normal(4000), rng.standard_normal(2000) * 1e-3])
