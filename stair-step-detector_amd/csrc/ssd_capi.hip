@@ -188,28 +188,35 @@ static int make_params(const ssd_config &c, const ssd_calibration &k, Params &P)
   P.W = c.width; P.H = c.height;
   P.W64 = (c.width + 63) / 64;
   P.nPoints = c.width * c.height;
-  for(int i = 0; i < 9; i++) P.a[i] = k.a[i];
-  for(int i = 0; i < 3; i++) P.b[i] = k.b[i];
+  for(int i = 0; i < 9; i++) P.pt.a[i] = k.a[i];
+  for(int i = 0; i < 3; i++) P.pt.b[i] = k.b[i];
   for(int i = 0; i < 4; i++) P.r2[i] = k.r2[i];
   P.t2[0] = k.t2[0]; P.t2[1] = k.t2[1];
   P.worldZ = k.world_z;
   P.xMin = c.x_min; P.xMax = c.x_max; P.yMin = c.y_min; P.yMax = c.y_max; P.zMin = c.z_min; P.zMax = c.z_max;
   /* ProcessingConfiguration / Projection2D, pointcloud.cpp:60-106 */
-  P.recip = 1.0 / c.height_interval;
-  P.minHeight = static_cast<uint16_t>((c.min_height_above_ground - c.z_min) * P.recip);
+  P.pt.recip = 1.0 / c.height_interval;
+  P.minHeight = static_cast<uint16_t>((c.min_height_above_ground - c.z_min) * P.pt.recip);
   P.minImgYExtent = static_cast<int>(c.min_step_depth * c.height / (c.y_max - c.y_min));
   P.xToImage = c.width / (c.x_max - c.x_min);
   P.yToImage = c.height / (c.y_max - c.y_min);
   P.xToWorld = 1 / P.xToImage;
   P.yToWorld = 1 / P.yToImage;
   P.xyRatio = P.xToImage / P.yToImage;
-  const size_t nBins = static_cast<size_t>((c.z_max - c.z_min) * P.recip) + 1;   /* pointcloud.cpp:196 */
+  const size_t nBins = static_cast<size_t>((c.z_max - c.z_min) * P.pt.recip) + 1;   /* pointcloud.cpp:196 */
   if(nBins < 3 || nBins > SSD_MAX_BINS)
     return fail(SSD_E_ARG, "config: histogram needs 3.." + std::to_string(SSD_MAX_BINS) + " bins");
   P.nBins = static_cast<int>(nBins);
   if(c.max_step_plateaus < 1 || c.max_step_plateaus > SSD_MAX_STEP_IMAGES)
     return fail(SSD_E_ARG, "config: max_step_plateaus out of range");
   P.maxStepImages = c.max_step_plateaus;
+  P.pt.xMin = c.x_min; P.pt.xMax = c.x_max; P.pt.yMin = c.y_min; P.pt.yMax = c.y_max; P.pt.zMin = c.z_min; P.pt.zMax = c.z_max;
+  P.pt.nPoints = P.nPoints;
+  P.pt.nBins = P.nBins;
+  P.px.xToImage = P.xToImage; P.px.yToImage = P.yToImage;
+  P.px.W = P.W; P.px.H = P.H; P.px.W64 = P.W64;
+  P.px.maxStepImages = P.maxStepImages;
+  P.px.exp = env_int("SSD_EXP", 0);
   if((c.width - 1) / 25 + 2 > SSD_MAX_SCANS)
     return fail(SSD_E_ARG, "config: width needs more scan columns than SSD_MAX_SCANS");
   return SSD_OK;
@@ -381,7 +388,7 @@ int ssd_enqueue_stages(ssd_handle *h, const void *d_xyz, size_t frame_stride_byt
     launch_peaks(P, h->dState, nframes, dbg, s);
   mark();
   if(stages & SSD_STAGE_RASTER)
-    launch_raster(xyz, strideFloats, P, h->dState, reinterpret_cast<unsigned int *>(h->dStepImg), nframes, chunk, s);
+    launch_raster(xyz, strideFloats, P, h->dState, h->dStepImg, nframes, chunk, s);
   mark();
   if(stages & SSD_STAGE_OUTLINE)
     launch_outline(P, h->dState, h->dStepImg, nframes, dbg, dbgImg, s);
@@ -390,7 +397,7 @@ int ssd_enqueue_stages(ssd_handle *h, const void *d_xyz, size_t frame_stride_byt
     launch_quads(P, h->dState, nframes, dbg, s);
   mark();
   if(stages & SSD_STAGE_INQUAD)
-    launch_inquad(xyz, strideFloats, P, h->dState, reinterpret_cast<unsigned int *>(h->dGroundImg), nframes, chunk, s);
+    launch_inquad(xyz, strideFloats, P, h->dState, h->dGroundImg, nframes, chunk, s);
   mark();
   if(stages & SSD_STAGE_FINAL)
     launch_final(P, h->dState, h->dGroundImg, h->dResults, nframes, dbg, dbgImg, s);

@@ -27,15 +27,34 @@ constexpr int kZFixShift = 40;                    /* mean z accumulates round(z 
 /* the four horizontal edges of a plateau outline, in this order everywhere (segmentation.cpp:585-589) */
 enum { kFL = 0, kFR = 1, kBL = 2, kBR = 3 };
 
-/* constants of one handle, passed by value as kernel argument */
+/* Kernel arguments are passed by value and live in SGPRs; a 256-thread block is admitted 8x per CU only
+ * while the kernel needs <= 80 SGPRs (MI355X_MICROARCH.md, residency), so the streaming kernels get just
+ * the constants they use: PointParams (44 SGPRs) and PixelParams, not the whole Params. */
+struct PointParams
+{
+  double a[9], b[3];                          /* CameraToWorld: w = a * x + b (transformation.h:59-64) */
+  double xMin, xMax, yMin, yMax, zMin, zMax;  /* Configuration::MeasuringRange (configuration.h:40-46) */
+  double recip;                               /* 1 / heightInterval */
+  int nPoints, nBins;
+};
+
+struct PixelParams
+{
+  double xToImage, yToImage;                  /* Projection2D (pointcloud.cpp:73-74) */
+  int W, H, W64;                              /* W64 = 64-bit words per image row */
+  int maxStepImages;
+  int exp;                                    /* SSD_EXP timing experiments (results are wrong when non-zero) */
+};
+
+/* all constants of one handle */
 struct Params
 {
-  int W, H, W64;                 /* W64 = 64-bit words per image row */
+  PointParams pt;
+  PixelParams px;
+  int W, H, W64;
   int nPoints;
-  double a[9], b[3];
   double r2[4], t2[2], worldZ;
   double xMin, xMax, yMin, yMax, zMin, zMax;
-  double recip;                  /* 1 / heightInterval */
   double xToImage, yToImage, xToWorld, yToWorld, xyRatio;
   int nBins, minHeight, minImgYExtent;
   int maxStepImages;
@@ -74,7 +93,7 @@ struct FrameState
   int nPlateaus, firstStep, nStepImages, groundInd, firstValidInd;
   int groundFrontValid;
   unsigned char lut[kMaxBins];     /* bin -> plateau index, 0xff = none */
-  /* bounding box of the raw bits of each step image ([kMaxStepImages] = ground image): rows and 32-bit
+  /* bounding box of the raw bits of each step image ([kMaxStepImages] = ground image): rows and 64-bit
    * word columns, written by the rasterising kernels, read by the kernels that close and scan the image */
   int imgYMin[kMaxStepImages + 1], imgYMax[kMaxStepImages + 1];
   int imgXMin[kMaxStepImages + 1], imgXMax[kMaxStepImages + 1];

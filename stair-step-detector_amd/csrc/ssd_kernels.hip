@@ -29,7 +29,7 @@ struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
 /* CameraToWorld (transformation.h:59-64, 79-87): a*x + b, float promoted to double,
  * row sums left to right, then the translation; followed by the six strict range
  * compares of getPointsInRange (pointcloud.cpp:150-165). */
-__device__ __forceinline__ bool world_point(const Params &P, const F3 &v, double &wx, double &wy, double &wz)
+__device__ __forceinline__ bool world_point(const PointParams &P, const F3 &v, double &wx, double &wy, double &wz)
 {
   if(!(v.z > 0.0f))                                   /* pointcloud.cpp:143-146 */
     return false;
@@ -44,7 +44,7 @@ __device__ __forceinline__ bool world_point(const Params &P, const F3 &v, double
 }
 
 /* calcHeights (pointcloud.cpp:175): truncating conversion, value is in [0, nBins) */
-__device__ __forceinline__ int height_bin(const Params &P, double wz)
+__device__ __forceinline__ int height_bin(const PointParams &P, double wz)
 {
   return static_cast<int>((wz - P.zMin) * P.recip);
 }
@@ -84,8 +84,24 @@ __device__ __forceinline__ void load_points(const float *__restrict__ base, int 
   }
 }
 
+/* The streaming kernels (K1, K2, K4) share one loop shape: a block owns a contiguous chunk of a frame and
+ * walks it in tiles of 1024 points; the loads of the next tile are issued before the current tile is
+ * processed (register double buffer), so that HBM requests stay in flight while the SIMDs do the fp64 work. */
+#define SSD_STREAM_LOOP(...)                                                                        \
+  {                                                                                                 \
+    F3 v[kPts], vn[kPts];                                                                           \
+    load_points<ALIGNED>(base, begin + kPts * tid, end, v);                                         \
+    for(int i0 = begin; i0 < end; i0 += kTile)                                                      \
+    {                                                                                               \
+      if(i0 + kTile < end)                                                                          \
+        load_points<ALIGNED>(base, i0 + kTile + kPts * tid, end, vn);                               \
+      __VA_ARGS__                                                                                   \
+      _Pragma("unroll") for(int j = 0; j < kPts; j++) v[j] = vn[j];                                 \
+    }                                                                                               \
+  }
+
 template<bool ALIGNED>
-__global__ __launch_bounds__(kThreads) void k_hist(const float *__restrict__ xyz, size_t strideFloats, Params P,
+__global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                    FrameState *__restrict__ st, int chunkPoints)
 {
   /* [bin][copy]: a vote goes to copy = lane & 31, i.e. LDS bank = copy: the 32 lanes the LDS serves per
@@ -107,19 +123,15 @@ __global__ __launch_bounds__(kThreads) void k_hist(const float *__restrict__ xyz
 
   unsigned int *mine = lh + (lane & (kHistCopies - 1));
   unsigned int nz = 0;
-  for(int i0 = begin; i0 < end; i0 += kTile)
-  {
-    F3 v[kPts];
-    load_points<ALIGNED>(base, i0 + kPts * tid, end, v);
-#pragma unroll
-    for(int j = 0; j < kPts; j++)
+  SSD_STREAM_LOOP(
+    _Pragma("unroll") for(int j = 0; j < kPts; j++)
     {
       double wx, wy, wz;
       nz += v[j].z > 0.0f ? 1u : 0u;
       if(world_point(P, v[j], wx, wy, wz))
         atomicAdd(mine + height_bin(P, wz) * kHistCopies, 1u);          /* ++hist[bin], pointcloud.cpp:199-202 */
     }
-  }
+  )
 
   /* wave-reduce the non-zero count */
 #pragma unroll
@@ -293,41 +305,141 @@ __global__ void k_peaks(Params P, FrameState *__restrict__ st, int nframes, Debu
 
 constexpr unsigned int kNoKey = 0xffffffffu;
 
-/* ORs `mask` into word `key` of a bit-image array for every lane with key != kNoKey, after merging the
- * lanes of a wave that hit the same word: neighbouring camera pixels land on neighbouring image pixels, so
- * runs of equal keys are contiguous in the lane order.  Segmented inclusive OR-scan over the run (6 steps),
- * then the last lane of each run issues one global atomic.  Must be called by all 64 lanes. */
-__device__ __forceinline__ void wave_merged_or(unsigned int *__restrict__ words, unsigned int key, unsigned int mask, int lane)
+/* Write-combining LDS window for the rasterising kernels.
+ *
+ * Setting one bit per point with global atomics costs more than the whole fp64 path (memory-side atomics:
+ * ~1.9 ms of K2's 3.8 ms per 1024 XGA frames, profiles/r01).  A block walks consecutive camera rows, and
+ * those land on a narrow band of rows of ONE top-down image at a time; so the block keeps a window of
+ * `rows` image rows of one image (slot, row0) in LDS, ORs bits into it with LDS atomics (no global traffic,
+ * no vmcnt) and writes the non-zero words out with global atomics only when the window moves and at the
+ * end of the block.  Bits outside the window go straight to memory, so the result never depends on where
+ * the window is.  The bounding box of everything written (rows, 64-bit word columns, per image) is
+ * collected on the same two slow paths, not per point. */
+struct TileCounters { unsigned int hitLanes, missLanes, missMin; };
+
+struct ImageBox { int yMin, yMax, xMin, xMax; };
+
+template<int WORDS>
+struct TileWindow
 {
-#pragma unroll
-  for(int d = 1; d < 64; d <<= 1)
+  unsigned long long w[WORDS];
+  TileCounters cnt[3];
+};
+
+template<int WORDS>
+__device__ __forceinline__ void tile_init(TileWindow<WORDS> &T, int tid)
+{
+  for(int i = tid; i < WORDS; i += kThreads)
+    T.w[i] = 0ull;
+  if(tid < 3)
+    T.cnt[tid] = TileCounters{ 0u, 0u, 0xffffffffu };
+}
+
+__device__ __forceinline__ void box_note(ImageBox &b, int iy, int xw)
+{
+  atomicMin(&b.yMin, iy); atomicMax(&b.yMax, iy);
+  atomicMin(&b.xMin, xw); atomicMax(&b.xMax, xw);
+}
+
+/* writes the window out (non-zero words only) and clears it; all threads of the block */
+template<int WORDS>
+__device__ __forceinline__ void tile_flush(TileWindow<WORDS> &T, unsigned long long *__restrict__ images, unsigned int imgWords,
+                                           int W64, int H, int slot, int row0, int rows, ImageBox *boxes, int tid)
+{
+  if(slot < 0)
+    return;
+  unsigned long long *img = images + static_cast<size_t>(slot) * imgWords;
+  const int n = min(rows, H - row0) * W64;
+  int y0 = 0x7fffffff, y1 = -1, x0 = 0x7fffffff, x1 = -1;
+  for(int i = tid; i < n; i += kThreads)
   {
-    const unsigned int k2 = __shfl_up(key, d);
-    const unsigned int m2 = __shfl_up(mask, d);
-    if(lane >= d && k2 == key)
-      mask |= m2;
+    const unsigned long long v = T.w[i];
+    if(v)
+    {
+      atomicOr(img + static_cast<size_t>(row0) * W64 + i, v);
+      T.w[i] = 0ull;
+      const int r = i / W64, xw = i - r * W64;
+      y0 = min(y0, row0 + r); y1 = max(y1, row0 + r);
+      x0 = min(x0, xw); x1 = max(x1, xw);
+    }
   }
-  const unsigned int kn = __shfl_down(key, 1);
-  if(key != kNoKey && (lane == 63 || kn != key))
-    atomicOr(words + key, mask);
+  if(y1 >= 0)
+  {
+    atomicMin(&boxes[slot].yMin, y0); atomicMax(&boxes[slot].yMax, y1);
+    atomicMin(&boxes[slot].xMin, x0); atomicMax(&boxes[slot].xMax, x1);
+  }
+}
+
+/* one word's worth of bits of image `slot`: into the window when it is inside, straight to memory otherwise */
+template<int WORDS>
+__device__ __forceinline__ void tile_or(TileWindow<WORDS> &T, TileCounters &c, unsigned long long *__restrict__ images,
+                                        unsigned int imgWords, int W64, int rows, int winSlot, int winRow0, ImageBox *boxes,
+                                        int slot, int iy, int xw, unsigned long long mask, bool &hit, bool &miss)
+{
+  const unsigned int r = static_cast<unsigned int>(iy - winRow0);
+  if(slot == winSlot && r < static_cast<unsigned int>(rows))
+  {
+    atomicOr(&T.w[r * W64 + xw], mask);
+    hit = true;
+  }
+  else
+  {
+    atomicOr(images + static_cast<size_t>(slot) * imgWords + static_cast<size_t>(iy) * W64 + xw, mask);
+    atomicMin(&c.missMin, (static_cast<unsigned int>(slot) << 16) | static_cast<unsigned int>(iy));
+    box_note(boxes[slot], iy, xw);
+    miss = true;
+  }
+}
+
+/* End of one tile of 1024 points, called by every thread: when more lanes missed the window than hit it,
+ * the window is flushed and re-anchored at the lowest missing (image, row).  `it` counts tiles; the
+ * counters rotate over three slots so that one barrier per tile suffices. */
+template<int WORDS>
+__device__ __forceinline__ void tile_end_of_iteration(TileWindow<WORDS> &T, unsigned long long *__restrict__ images,
+                                                      unsigned int imgWords, int W64, int H, int rows, int it, ImageBox *boxes,
+                                                      bool hit, bool miss, int &winSlot, int &winRow0, int tid, int lane)
+{
+  TileCounters &c = T.cnt[it % 3];
+  const unsigned int nh = static_cast<unsigned int>(__popcll(__ballot(hit)));
+  const unsigned int nm = static_cast<unsigned int>(__popcll(__ballot(miss)));
+  if(lane == 0)
+  {
+    if(nh) atomicAdd(&c.hitLanes, nh);
+    if(nm) atomicAdd(&c.missLanes, nm);
+  }
+  __syncthreads();
+  const unsigned int hitLanes = c.hitLanes, missLanes = c.missLanes, missMin = c.missMin;
+  if(tid == 0)
+    T.cnt[(it + 2) % 3] = TileCounters{ 0u, 0u, 0xffffffffu };
+  if(missLanes > hitLanes)                                 /* block-uniform */
+  {
+    tile_flush(T, images, imgWords, W64, H, winSlot, winRow0, rows, boxes, tid);
+    winSlot = static_cast<int>(missMin >> 16);
+    winRow0 = static_cast<int>(missMin & 0xffffu);
+    __syncthreads();
+  }
 }
 
 /* Projection2D::worldToImage (pointcloud.cpp:79-83); false = outside the image (quirk Q5) */
-__device__ __forceinline__ bool image_pixel(const Params &P, double wx, double wy, int &ix, int &iy)
+__device__ __forceinline__ bool image_pixel(const PointParams &P, const PixelParams &X, double wx, double wy, int &ix, int &iy)
 {
-  ix = static_cast<int>((wx - P.xMin) * P.xToImage);
-  iy = static_cast<int>((P.yMax - wy) * P.yToImage);
-  return ix >= 0 && ix < P.W && iy >= 0 && iy < P.H;
+  ix = static_cast<int>((wx - P.xMin) * X.xToImage);
+  iy = static_cast<int>((P.yMax - wy) * X.yToImage);
+  return ix >= 0 && ix < X.W && iy >= 0 && iy < X.H;
 }
 
+constexpr int kTileWordsK2 = 2048;     /* 16 KiB window: 128 rows at XGA */
+constexpr int kTileWordsK4 = 1024;     /*  8 KiB window */
+
 template<bool ALIGNED>
-__global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ xyz, size_t strideFloats, Params P,
-                                                     FrameState *__restrict__ st, unsigned int *__restrict__ stepImg,
-                                                     int chunkPoints)
+__global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
+                                                        PixelParams X, FrameState *__restrict__ st,
+                                                        unsigned long long *__restrict__ stepImg, int chunkPoints)
 {
+  __shared__ TileWindow<kTileWordsK2> T;
+  __shared__ ImageBox boxes[kMaxStepImages];
   __shared__ unsigned char lut[kMaxBins];
   __shared__ unsigned int lOob;
-  __shared__ int lYMin[kMaxStepImages], lYMax[kMaxStepImages], lXMin[kMaxStepImages], lXMax[kMaxStepImages];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int frame = blockIdx.y;
@@ -339,55 +451,31 @@ __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ x
   if(tid < kMaxBins)
     lut[tid] = fs.lut[tid];
   if(tid < kMaxStepImages)
-  {
-    lYMin[tid] = 0x7fffffff; lYMax[tid] = -1;
-    lXMin[tid] = 0x7fffffff; lXMax[tid] = -1;
-  }
+    boxes[tid] = ImageBox{ 0x7fffffff, -1, 0x7fffffff, -1 };
   if(tid == 0)
     lOob = 0;
+  tile_init(T, tid);
   __syncthreads();
 
   const float *base = xyz + static_cast<size_t>(frame) * strideFloats;
   const int begin = blockIdx.x * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
-  const int W32 = P.W64 * 2;
-  const unsigned int imgWords = static_cast<unsigned int>(P.H) * W32;
-  unsigned int *frameImg = stepImg + static_cast<size_t>(frame) * P.maxStepImages * imgWords;
+  const unsigned int imgWords = static_cast<unsigned int>(X.H) * X.W64;
+  unsigned long long *frameImg = stepImg + static_cast<size_t>(frame) * X.maxStepImages * imgWords;
+  const int rows = min(X.H, kTileWordsK2 / X.W64);
+  int winSlot = -1, winRow0 = 0, it = 0;
   unsigned int oob = 0;
-  /* bounding box (rows, 32-bit word columns) of the bits this thread sets, kept in registers per image and
-   * flushed to LDS only when the thread moves on to another image (a thread walks down a camera column) */
-  int bSlot = -1, bY0 = 0, bY1 = 0, bX0 = 0, bX1 = 0;
-  auto flushBox = [&]()
-  {
-    if(bSlot >= 0)
-    {
-      atomicMin(&lYMin[bSlot], bY0); atomicMax(&lYMax[bSlot], bY1);
-      atomicMin(&lXMin[bSlot], bX0); atomicMax(&lXMax[bSlot], bX1);
-    }
-  };
-  auto noteBox = [&](int slot, int iy, int xw)
-  {
-    if(slot != bSlot)
-    {
-      flushBox();
-      bSlot = slot; bY0 = bY1 = iy; bX0 = bX1 = xw;
-    }
-    else
-    {
-      bY0 = min(bY0, iy); bY1 = max(bY1, iy);
-      bX0 = min(bX0, xw); bX1 = max(bX1, xw);
-    }
-  };
 
-  for(int i0 = begin; i0 < end; i0 += kTile)
-  {
-    F3 v[kPts];
-    load_points<ALIGNED>(base, i0 + kPts * tid, end, v);
-    /* the lane's four neighbouring pixels: merge those that share a word, keep one primary word for
-     * the cross-lane merge, send the (rare) others straight to memory */
-    unsigned int pKey = kNoKey, pMask = 0;
-#pragma unroll
-    for(int j = 0; j < kPts; j++)
+  SSD_STREAM_LOOP(
+    /* the lane's four neighbouring pixels usually share one 64-bit word: merge them before touching LDS */
+    TileCounters &cnt = T.cnt[it % 3];
+    bool hit = false;
+    bool miss = false;
+    int pSlot = -1;
+    int pY = 0;
+    int pXw = 0;
+    unsigned long long pMask = 0;
+    _Pragma("unroll") for(int j = 0; j < kPts; j++)
     {
       double wx, wy, wz;
       if(!world_point(P, v[j], wx, wy, wz))
@@ -396,33 +484,34 @@ __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ x
       if(slot < 0 || slot >= nImg)
         continue;
       int ix, iy;
-      if(!image_pixel(P, wx, wy, ix, iy))
+      if(!image_pixel(P, X, wx, wy, ix, iy))
       {
         oob++;                                              /* quirk Q5 */
         continue;
       }
-      const unsigned int key = static_cast<unsigned int>(slot) * imgWords + static_cast<unsigned int>(iy) * W32 + (ix >> 5);
-      const unsigned int bit = 1u << (ix & 31);
-      if(key != pKey)
-        noteBox(slot, iy, ix >> 5);
-      if(pKey == kNoKey || key == pKey)
+      const unsigned long long bit = 1ull << (ix & 63);
+      if(slot == pSlot && iy == pY && (ix >> 6) == pXw)
       {
-        pKey = key;
         pMask |= bit;
+        continue;
       }
-      else
-        atomicOr(frameImg + key, bit);
+      if(pSlot >= 0)
+        tile_or(T, cnt, frameImg, imgWords, X.W64, rows, winSlot, winRow0, boxes, pSlot, pY, pXw, pMask, hit, miss);
+      pSlot = slot; pY = iy; pXw = ix >> 6; pMask = bit;
     }
-    wave_merged_or(frameImg, pKey, pMask, lane);
-  }
-  flushBox();
+    if(pSlot >= 0)
+      tile_or(T, cnt, frameImg, imgWords, X.W64, rows, winSlot, winRow0, boxes, pSlot, pY, pXw, pMask, hit, miss);
+    tile_end_of_iteration(T, frameImg, imgWords, X.W64, X.H, rows, it, boxes, hit, miss, winSlot, winRow0, tid, lane);
+    it++;
+  )
+  tile_flush(T, frameImg, imgWords, X.W64, X.H, winSlot, winRow0, rows, boxes, tid);
   if(oob)
     atomicAdd(&lOob, oob);
   __syncthreads();
-  if(tid < nImg && lYMax[tid] >= 0)
+  if(tid < nImg && boxes[tid].yMax >= 0)
   {
-    atomicMin(&fs.imgYMin[tid], lYMin[tid]); atomicMax(&fs.imgYMax[tid], lYMax[tid]);
-    atomicMin(&fs.imgXMin[tid], lXMin[tid]); atomicMax(&fs.imgXMax[tid], lXMax[tid]);
+    atomicMin(&fs.imgYMin[tid], boxes[tid].yMin); atomicMax(&fs.imgYMax[tid], boxes[tid].yMax);
+    atomicMin(&fs.imgXMin[tid], boxes[tid].xMin); atomicMax(&fs.imgXMax[tid], boxes[tid].xMax);
   }
   if(tid == 0 && lOob)
   {
@@ -717,7 +806,7 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
   }
   /* the closing of a set never leaves the bounding box of the set: only that window is visited
    * (with debug capture on, the whole image, so that the captured images are complete) */
-  int by0 = fs.imgYMin[slot], by1 = fs.imgYMax[slot], bc0 = fs.imgXMin[slot] >> 1, bc1 = fs.imgXMax[slot] >> 1;
+  int by0 = fs.imgYMin[slot], by1 = fs.imgYMax[slot], bc0 = fs.imgXMin[slot], bc1 = fs.imgXMax[slot];
   const bool emptyImg = by1 < by0;
   if(dbgImg)
   {
@@ -1069,8 +1158,8 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
   /* leave the raw image zeroed for the next batch (all its bits lie inside the bounding box) */
   if(!emptyImg)
   {
-    const int cy0 = fs.imgYMin[slot], cc0 = fs.imgXMin[slot] >> 1;
-    const int cw = (fs.imgXMax[slot] >> 1) - cc0 + 1, ch = fs.imgYMax[slot] - cy0 + 1;
+    const int cy0 = fs.imgYMin[slot], cc0 = fs.imgXMin[slot];
+    const int cw = fs.imgXMax[slot] - cc0 + 1, ch = fs.imgYMax[slot] - cy0 + 1;
     for(int idx = tid; idx < cw * ch; idx += kThreads)
     {
       const int ry = idx / cw;
@@ -1274,17 +1363,19 @@ __device__ __forceinline__ bool quad_test(const QuadTest &t, double x, double y)
   int c = 0;
   if(nc > 1 && !(x < t.xTrans[r][0]))
     c = (nc == 2 || x < t.xTrans[r][1]) ? 1 : 2;
-  const unsigned int mask = t.cellMask[r][c];
+  unsigned int mask = t.cellMask[r][c];
   if(mask == 0)
-    return t.cellConst[r][c] != 0;
+    return t.cellConst[r][c] != 0;                     /* the large middle cell of a tread: no arithmetic */
+  const bool inside = t.insideIsLeft != 0;
   bool ok = true;
-#pragma unroll
-  for(int s = 0; s < 4; s++)
+  while(mask)                                          /* at most two segments per cell (:370-372) */
   {
-    const bool positive = t.segSteep[s] ? (x + y * t.segK[s] + t.segC[s] > 0) : (x * t.segK[s] + y + t.segC[s] > 0);
+    const int s = __ffs(static_cast<int>(mask)) - 1;
+    mask &= mask - 1;
+    const double k = t.segK[s], cc = t.segC[s];
+    const bool positive = t.segSteep[s] ? (x + y * k + cc > 0) : (x * k + y + cc > 0);
     const bool left = t.segLeftIfPositive[s] ? positive : !positive;
-    if((mask >> s) & 1u)
-      ok = ok && (left == (t.insideIsLeft != 0));
+    ok = ok && (left == inside);
   }
   return ok;
 }
@@ -1369,17 +1460,27 @@ __global__ void k_quads(Params P, FrameState *__restrict__ st, int nframes, Debu
 /* ========================================================================= */
 /* K4: in-quadrilateral filter, z sums, ground image                           */
 
-template<bool ALIGNED>
-__global__ __launch_bounds__(kThreads) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, Params P,
-                                                     FrameState *__restrict__ st, unsigned int *__restrict__ groundImg,
-                                                     int chunkPoints)
+/* round(z * 2^40) without a double->int64 conversion (a long software sequence on this ISA): adding
+ * 1.5 * 2^12 puts z (|z| < 2048) on the 2^-40 grid of [4096, 8192), rounded to nearest even by the add;
+ * the mantissa difference to the constant is the integer.  Same value as llrint(z * 2^40). */
+__device__ __forceinline__ long long z_to_fixed(double z)
 {
+  const double magic = 6144.0;
+  return __double_as_longlong(z + magic) - __double_as_longlong(magic);
+}
+
+template<bool ALIGNED>
+__global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
+                                                        PixelParams X, FrameState *__restrict__ st,
+                                                        unsigned long long *__restrict__ groundImg, int chunkPoints)
+{
+  __shared__ TileWindow<kTileWordsK4> T;
+  __shared__ ImageBox box[1];
   __shared__ QuadTest qts[kMaxPlateaus + 1];
   __shared__ unsigned char lut[kMaxBins];
   __shared__ unsigned char active[kMaxPlateaus + 1];
   __shared__ unsigned long long lsum[kMaxPlateaus + 1][8];
   __shared__ unsigned int lcnt[kMaxPlateaus + 1][8];
-  __shared__ int lBox[4];
   __shared__ unsigned int lOob;
   __shared__ int anyActive;
 
@@ -1392,7 +1493,7 @@ __global__ __launch_bounds__(kThreads) void k_inquad(const float *__restrict__ x
     for(int k = 0; k <= kMaxPlateaus; k++)
       a |= fs.accActive[k];
     anyActive = a;
-    lBox[0] = 0x7fffffff; lBox[1] = -1; lBox[2] = 0x7fffffff; lBox[3] = -1;
+    box[0] = ImageBox{ 0x7fffffff, -1, 0x7fffffff, -1 };
     lOob = 0;
   }
   __syncthreads();
@@ -1408,6 +1509,7 @@ __global__ __launch_bounds__(kThreads) void k_inquad(const float *__restrict__ x
     (&lsum[0][0])[i] = 0ull;
     (&lcnt[0][0])[i] = 0u;
   }
+  tile_init(T, tid);
   {
     /* copy the live quadrilateral tests as 32-bit words */
     const unsigned int *src = reinterpret_cast<const unsigned int *>(fs.qt);
@@ -1420,12 +1522,18 @@ __global__ __launch_bounds__(kThreads) void k_inquad(const float *__restrict__ x
   __syncthreads();
 
   const int groundInd = fs.groundInd;
+  const bool haveGround = active[kGroundAcc] != 0;
   const float *base = xyz + static_cast<size_t>(frame) * strideFloats;
   const int begin = blockIdx.x * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
-  const int W32 = P.W64 * 2;
-  unsigned int *gimg = groundImg + static_cast<size_t>(frame) * P.H * W32;
+  unsigned long long *gimg = groundImg + static_cast<size_t>(frame) * X.H * X.W64;
   const int copy = lane & 7;
+  const unsigned int imgWords = static_cast<unsigned int>(X.H) * X.W64;
+  const int rows = min(X.H, kTileWordsK4 / X.W64);
+  /* the ground window is anchored once, at the first tile that meets ground points (camera rows run
+   * towards the camera, image rows with them); until then one barrier per tile, none afterwards */
+  int winSlot = -1, winRow0 = 0;
+  bool anchored = !haveGround;
 
   /* calcAverageZ (pointcloud.cpp:574-581) as an order-independent fixed-point sum: a thread walks down a
    * camera column, so consecutive hits nearly always belong to the same quadrilateral — the running sum
@@ -1441,15 +1549,14 @@ __global__ __launch_bounds__(kThreads) void k_inquad(const float *__restrict__ x
       atomicAdd(&lcnt[curQ][copy], accN);
     }
   };
-  int bY0 = 0x7fffffff, bY1 = -1, bX0 = 0x7fffffff, bX1 = -1;     /* bounding box of this thread's ground bits */
 
-  for(int i0 = begin; i0 < end; i0 += kTile)
-  {
-    F3 v[kPts];
-    load_points<ALIGNED>(base, i0 + kPts * tid, end, v);
-    unsigned int pKey = kNoKey, pMask = 0;
-#pragma unroll
-    for(int j = 0; j < kPts; j++)
+  SSD_STREAM_LOOP(
+    bool hit = false;
+    bool miss = false;
+    int pY = -1;
+    int pXw = 0;
+    unsigned long long pMask = 0;
+    _Pragma("unroll") for(int j = 0; j < kPts; j++)
     {
       double wx, wy, wz;
       if(!world_point(P, v[j], wx, wy, wz))
@@ -1467,38 +1574,48 @@ __global__ __launch_bounds__(kThreads) void k_inquad(const float *__restrict__ x
         flushAcc();
         curQ = q; accZ = 0; accN = 0;
       }
-      accZ += __double2ll_rn(wz * static_cast<double>(1ll << kZFixShift));
+      accZ += z_to_fixed(wz);
       accN++;
       if(q == kGroundAcc)
       {
         /* projectToBinaryImage(pointsInQuadri) (pointcloud.cpp:531) */
         int ix, iy;
-        if(!image_pixel(P, wx, wy, ix, iy))
+        if(!image_pixel(P, X, wx, wy, ix, iy))
         {
           oob++;
           continue;
         }
-        const unsigned int key = static_cast<unsigned int>(iy) * W32 + (ix >> 5);
-        const unsigned int bit = 1u << (ix & 31);
-        bY0 = min(bY0, iy); bY1 = max(bY1, iy);
-        bX0 = min(bX0, ix >> 5); bX1 = max(bX1, ix >> 5);
-        if(pKey == kNoKey || key == pKey)
+        const unsigned long long bit = 1ull << (ix & 63);
+        if(iy == pY && (ix >> 6) == pXw)
         {
-          pKey = key;
           pMask |= bit;
+          continue;
         }
-        else
-          atomicOr(gimg + key, bit);
+        if(pY >= 0)
+          tile_or(T, T.cnt[0], gimg, imgWords, X.W64, rows, winSlot, winRow0, box, 0, pY, pXw, pMask, hit, miss);
+        pY = iy; pXw = ix >> 6; pMask = bit;
       }
     }
-    wave_merged_or(gimg, pKey, pMask, lane);
-  }
+    if(pY >= 0)
+      tile_or(T, T.cnt[0], gimg, imgWords, X.W64, rows, winSlot, winRow0, box, 0, pY, pXw, pMask, hit, miss);
+    if(!anchored)                                          /* block-uniform */
+    {
+      __syncthreads();
+      if(tid == 0)
+        T.cnt[1].missMin = T.cnt[0].missMin;               /* one snapshot for the whole block */
+      __syncthreads();
+      const unsigned int missMin = T.cnt[1].missMin;
+      if(missMin != 0xffffffffu)
+      {
+        winSlot = 0;
+        winRow0 = max(0, static_cast<int>(missMin & 0xffffu) - 2);
+        anchored = true;
+      }
+    }
+  )
+  __syncthreads();
+  tile_flush(T, gimg, imgWords, X.W64, X.H, winSlot, winRow0, rows, box, tid);
   flushAcc();
-  if(bY1 >= 0)
-  {
-    atomicMin(&lBox[0], bY0); atomicMax(&lBox[1], bY1);
-    atomicMin(&lBox[2], bX0); atomicMax(&lBox[3], bX1);
-  }
   if(oob)
     atomicAdd(&lOob, oob);
   __syncthreads();
@@ -1519,10 +1636,10 @@ __global__ __launch_bounds__(kThreads) void k_inquad(const float *__restrict__ x
   }
   if(tid == 0)
   {
-    if(lBox[1] >= 0)
+    if(box[0].yMax >= 0)
     {
-      atomicMin(&fs.imgYMin[kMaxStepImages], lBox[0]); atomicMax(&fs.imgYMax[kMaxStepImages], lBox[1]);
-      atomicMin(&fs.imgXMin[kMaxStepImages], lBox[2]); atomicMax(&fs.imgXMax[kMaxStepImages], lBox[3]);
+      atomicMin(&fs.imgYMin[kMaxStepImages], box[0].yMin); atomicMax(&fs.imgYMax[kMaxStepImages], box[0].yMax);
+      atomicMin(&fs.imgXMin[kMaxStepImages], box[0].xMin); atomicMax(&fs.imgXMax[kMaxStepImages], box[0].xMax);
     }
     if(lOob)
     {
@@ -1585,7 +1702,7 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
       dbgClosed = dbgRaw + imgWords;
     }
     int by0 = fs.imgYMin[kMaxStepImages], by1 = fs.imgYMax[kMaxStepImages];
-    int bc0 = fs.imgXMin[kMaxStepImages] >> 1, bc1 = fs.imgXMax[kMaxStepImages] >> 1;
+    int bc0 = fs.imgXMin[kMaxStepImages], bc1 = fs.imgXMax[kMaxStepImages];
     const bool emptyImg = by1 < by0;
     if(dbgImg)
     {
@@ -1757,8 +1874,8 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
   /* leave the ground image zeroed for the next batch (all its bits lie inside the bounding box) */
   if(fs.imgYMax[kMaxStepImages] >= fs.imgYMin[kMaxStepImages])
   {
-    const int cy0 = fs.imgYMin[kMaxStepImages], cc0 = fs.imgXMin[kMaxStepImages] >> 1;
-    const int cw = (fs.imgXMax[kMaxStepImages] >> 1) - cc0 + 1, ch = fs.imgYMax[kMaxStepImages] - cy0 + 1;
+    const int cy0 = fs.imgYMin[kMaxStepImages], cc0 = fs.imgXMin[kMaxStepImages];
+    const int cw = fs.imgXMax[kMaxStepImages] - cc0 + 1, ch = fs.imgYMax[kMaxStepImages] - cy0 + 1;
     for(int idx = tid; idx < cw * ch; idx += kThreads)
     {
       const int ry = idx / cw;
@@ -1819,21 +1936,21 @@ void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameSt
 {
   dim3 grid(chunks_for(P.nPoints, chunkPoints), nframes);
   if(aligned16(xyz, strideFloats, P.nPoints))
-    hipLaunchKernelGGL(k_hist<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, chunkPoints);
+    hipLaunchKernelGGL(k_hist<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, chunkPoints);
   else
-    hipLaunchKernelGGL(k_hist<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, chunkPoints);
+    hipLaunchKernelGGL(k_hist<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, chunkPoints);
 }
 void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s)
 {
   hipLaunchKernelGGL(k_peaks, dim3((nframes + 63) / 64), dim3(64), 0, s, P, st, nframes, dbg);
 }
-void launch_raster(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned int *stepImg, int nframes, int chunkPoints, hipStream_t s)
+void launch_raster(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *stepImg, int nframes, int chunkPoints, hipStream_t s)
 {
   dim3 grid(chunks_for(P.nPoints, chunkPoints), nframes);
   if(aligned16(xyz, strideFloats, P.nPoints))
-    hipLaunchKernelGGL(k_raster<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, stepImg, chunkPoints);
+    hipLaunchKernelGGL(k_raster<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, chunkPoints);
   else
-    hipLaunchKernelGGL(k_raster<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, stepImg, chunkPoints);
+    hipLaunchKernelGGL(k_raster<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, chunkPoints);
 }
 void launch_outline(const Params &P, FrameState *st, unsigned long long *stepImg, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
 {
@@ -1844,13 +1961,13 @@ void launch_quads(const Params &P, FrameState *st, int nframes, DebugFrame *dbg,
 {
   hipLaunchKernelGGL(k_quads, dim3((nframes + 63) / 64), dim3(64), 0, s, P, st, nframes, dbg);
 }
-void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned int *groundImg, int nframes, int chunkPoints, hipStream_t s)
+void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *groundImg, int nframes, int chunkPoints, hipStream_t s)
 {
   dim3 grid(chunks_for(P.nPoints, chunkPoints), nframes);
   if(aligned16(xyz, strideFloats, P.nPoints))
-    hipLaunchKernelGGL(k_inquad<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, groundImg, chunkPoints);
+    hipLaunchKernelGGL(k_inquad<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, groundImg, chunkPoints);
   else
-    hipLaunchKernelGGL(k_inquad<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P, st, groundImg, chunkPoints);
+    hipLaunchKernelGGL(k_inquad<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, groundImg, chunkPoints);
 }
 void launch_final(const Params &P, FrameState *st, unsigned long long *groundImg, ssd_frame_result *results, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
 {

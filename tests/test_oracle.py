@@ -72,6 +72,41 @@ def test_quadtest_live_against_reference(oracle, ref):
     assert 0 in codes and -1 in codes
 
 
+def test_reference_cell_map_is_not_the_geometric_test(oracle, ref):
+    """Quirk Q9 (found while building the GPU path): for some convex quadrilaterals the reference accepts
+    (even at 5-15 degrees of yaw) QuadrilateralTest::isPointWithin (quadrilateralTest.cpp:275-451) returns
+    true for points far outside the quadrilateral: a cell of its 3x3 map tests only the segments whose
+    bounding boxes overlap the cell.  The build therefore reproduces the cell map (oracle and HIP kernels
+    alike) instead of a half-plane test; this test pins that against the real reference code."""
+    rng = np.random.default_rng(5)
+    n_quads = n_disagree = 0
+    for i in range(1500):
+        a = rng.uniform(0.05, 0.5)
+        w, d = rng.uniform(0.05, 0.6), rng.uniform(0.03, 0.4)
+        base = np.array([[-w, -d], [w, -d], [-w, d], [w, d]]) * (1 + rng.normal(0, 0.1, (4, 2)))
+        q = base @ np.array([[np.cos(a), np.sin(a)], [-np.sin(a), np.cos(a)]])
+        lo, hi = q.min(0), q.max(0)
+        pts = rng.uniform(lo - 0.02, hi + 0.02, (600, 2))
+        rc, inside = oracle.quad_test(q, pts)
+        rc_r, inside_r = ref.quad_test(q, pts)
+        assert rc == rc_r
+        if rc != 0:
+            continue
+        assert np.array_equal(inside, inside_r)
+        n_quads += 1
+        c = q.mean(0)
+        dmin = np.full(len(pts), np.inf)
+        for s, e in ((0, 1), (1, 3), (3, 2), (2, 0)):
+            ax, ay = q[e][1] - q[s][1], q[s][0] - q[e][0]
+            cc = q[e][0] * q[s][1] - q[s][0] * q[e][1]
+            sg = 1.0 if ax * c[0] + ay * c[1] + cc >= 0 else -1.0
+            dmin = np.minimum(dmin, sg * (ax * pts[:, 0] + ay * pts[:, 1] + cc) / np.hypot(ax, ay))
+        clear = np.abs(dmin) > 1e-6
+        if np.any((inside.astype(bool) != (dmin > 0)) & clear):
+            n_disagree += 1
+    assert n_quads > 1000 and n_disagree > 10
+
+
 # ------------------------------------------------------------------ morphology (OpenCV absent: documented semantics)
 def test_close3x3_against_scipy(oracle):
     ndi = pytest.importorskip("scipy.ndimage")
