@@ -216,7 +216,6 @@ static int make_params(const ssd_config &c, const ssd_calibration &k, Params &P)
   P.px.xToImage = P.xToImage; P.px.yToImage = P.yToImage;
   P.px.W = P.W; P.px.H = P.H; P.px.W64 = P.W64;
   P.px.maxStepImages = P.maxStepImages;
-  P.px.exp = env_int("SSD_EXP", 0);
   if((c.width - 1) / 25 + 2 > SSD_MAX_SCANS)
     return fail(SSD_E_ARG, "config: width needs more scan columns than SSD_MAX_SCANS");
   return SSD_OK;

@@ -43,7 +43,6 @@ struct PixelParams
   double xToImage, yToImage;                  /* Projection2D (pointcloud.cpp:73-74) */
   int W, H, W64;                              /* W64 = 64-bit words per image row */
   int maxStepImages;
-  int exp;                                    /* SSD_EXP timing experiments (results are wrong when non-zero) */
 };
 
 /* all constants of one handle */
@@ -64,6 +63,9 @@ struct Params
  * (reference quadrilateralTest.cpp:275-451: 3x3 cell map, <= 2 segments tested per cell) */
 struct QuadTest
 {
+  /* the largest cell of the map that holds no segment and counts as inside (the middle of a tread):
+   * fx0 <= x < fx1 && fy0 <= y < fy1 decides most points with four compares; empty when fx0 > fx1 */
+  double fx0, fx1, fy0, fy1;
   double bxLo, bxUp, byLo, byUp;
   double segK[4], segC[4];
   double yTrans[2];

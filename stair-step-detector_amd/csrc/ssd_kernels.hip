@@ -303,121 +303,151 @@ __global__ void k_peaks(Params P, FrameState *__restrict__ st, int nframes, Debu
 /* ========================================================================= */
 /* K2: raster the step plateaus into bit images                               */
 
-constexpr unsigned int kNoKey = 0xffffffffu;
-
-/* Write-combining LDS window for the rasterising kernels.
+/* Write-combining LDS windows for the rasterising kernels — one per WAVE, no barriers.
  *
  * Setting one bit per point with global atomics costs more than the whole fp64 path (memory-side atomics:
- * ~1.9 ms of K2's 3.8 ms per 1024 XGA frames, profiles/r01).  A block walks consecutive camera rows, and
- * those land on a narrow band of rows of ONE top-down image at a time; so the block keeps a window of
- * `rows` image rows of one image (slot, row0) in LDS, ORs bits into it with LDS atomics (no global traffic,
- * no vmcnt) and writes the non-zero words out with global atomics only when the window moves and at the
- * end of the block.  Bits outside the window go straight to memory, so the result never depends on where
- * the window is.  The bounding box of everything written (rows, 64-bit word columns, per image) is
- * collected on the same two slow paths, not per point. */
-struct TileCounters { unsigned int hitLanes, missLanes, missMin; };
+ * ~1.9 ms of K2's 3.8 ms per 1024 XGA frames, profiles/r01).  A wave owns 256 consecutive camera pixels of
+ * every camera row of its block's chunk; on one plateau those land on a patch of a few 64-bit word columns
+ * that creeps down the top-down image by one or two rows per camera row.  So each wave keeps a window of
+ * kWinRows x kWinCols words of ONE image (slot, row0, col0 — wave-uniform) in LDS, ORs bits into it with LDS
+ * atomics (no global traffic, no vmcnt) and writes the non-zero words out with global atomics only when the
+ * window moves and at the end.  Bits outside the window go straight to memory, so the result never depends
+ * on where the window is; when more lanes missed than hit during a tile the wave flushes and re-anchors at
+ * the lowest missing (image, row).  Everything is decided with ballots and shuffles inside the wave. */
+constexpr int kWinRows = 32, kWinCols = 8, kWinWords = kWinRows * kWinCols;      /* 2 KiB per wave */
 
 struct ImageBox { int yMin, yMax, xMin, xMax; };
 
-template<int WORDS>
-struct TileWindow
+struct WaveWindow
 {
-  unsigned long long w[WORDS];
-  TileCounters cnt[3];
+  int slot = -1, row0 = 0, col0 = 0;     /* wave-uniform */
 };
 
-template<int WORDS>
-__device__ __forceinline__ void tile_init(TileWindow<WORDS> &T, int tid)
+/* bounding box of the bits a lane sent straight to memory (window misses), kept in registers */
+struct MissBox
 {
-  for(int i = tid; i < WORDS; i += kThreads)
-    T.w[i] = 0ull;
-  if(tid < 3)
-    T.cnt[tid] = TileCounters{ 0u, 0u, 0xffffffffu };
-}
-
-__device__ __forceinline__ void box_note(ImageBox &b, int iy, int xw)
+  int slot = -1, y0 = 0, y1 = 0, x0 = 0, x1 = 0;
+};
+__device__ __forceinline__ void missbox_flush(const MissBox &m, ImageBox *boxes)
 {
-  atomicMin(&b.yMin, iy); atomicMax(&b.yMax, iy);
-  atomicMin(&b.xMin, xw); atomicMax(&b.xMax, xw);
-}
-
-/* writes the window out (non-zero words only) and clears it; all threads of the block */
-template<int WORDS>
-__device__ __forceinline__ void tile_flush(TileWindow<WORDS> &T, unsigned long long *__restrict__ images, unsigned int imgWords,
-                                           int W64, int H, int slot, int row0, int rows, ImageBox *boxes, int tid)
-{
-  if(slot < 0)
-    return;
-  unsigned long long *img = images + static_cast<size_t>(slot) * imgWords;
-  const int n = min(rows, H - row0) * W64;
-  int y0 = 0x7fffffff, y1 = -1, x0 = 0x7fffffff, x1 = -1;
-  for(int i = tid; i < n; i += kThreads)
+  if(m.slot >= 0)
   {
-    const unsigned long long v = T.w[i];
+    atomicMin(&boxes[m.slot].yMin, m.y0); atomicMax(&boxes[m.slot].yMax, m.y1);
+    atomicMin(&boxes[m.slot].xMin, m.x0); atomicMax(&boxes[m.slot].xMax, m.x1);
+  }
+}
+__device__ __forceinline__ void missbox_note(MissBox &m, ImageBox *boxes, int slot, int iy, int xw)
+{
+  if(slot != m.slot)
+  {
+    missbox_flush(m, boxes);
+    m.slot = slot; m.y0 = m.y1 = iy; m.x0 = m.x1 = xw;
+  }
+  else
+  {
+    m.y0 = min(m.y0, iy); m.y1 = max(m.y1, iy);
+    m.x0 = min(m.x0, xw); m.x1 = max(m.x1, xw);
+  }
+}
+
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1)
+    v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1)
+    v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+/* writes the wave's window out (non-zero words only), clears it, extends the image's bounding box; all 64 lanes */
+__device__ __forceinline__ void wavewin_flush(unsigned long long *ww, const WaveWindow &w, unsigned long long *__restrict__ images,
+                                              unsigned int imgWords, int W64, ImageBox *boxes, int lane)
+{
+  if(w.slot < 0)
+    return;
+  unsigned long long *img = images + static_cast<size_t>(w.slot) * imgWords;
+  int y0 = 0x7fffffff, y1 = -1, x0 = 0x7fffffff, x1 = -1;
+#pragma unroll
+  for(int k = 0; k < kWinWords / 64; k++)
+  {
+    const int i = k * 64 + lane;
+    const unsigned long long v = ww[i];
     if(v)
     {
-      atomicOr(img + static_cast<size_t>(row0) * W64 + i, v);
-      T.w[i] = 0ull;
-      const int r = i / W64, xw = i - r * W64;
-      y0 = min(y0, row0 + r); y1 = max(y1, row0 + r);
-      x0 = min(x0, xw); x1 = max(x1, xw);
+      const int y = w.row0 + i / kWinCols, x = w.col0 + i % kWinCols;
+      atomicOr(img + static_cast<size_t>(y) * W64 + x, v);
+      ww[i] = 0ull;
+      y0 = min(y0, y); y1 = max(y1, y);
+      x0 = min(x0, x); x1 = max(x1, x);
     }
   }
+  y1 = wave_max_i(y1);
   if(y1 >= 0)
   {
-    atomicMin(&boxes[slot].yMin, y0); atomicMax(&boxes[slot].yMax, y1);
-    atomicMin(&boxes[slot].xMin, x0); atomicMax(&boxes[slot].xMax, x1);
+    y0 = wave_min_i(y0); x0 = wave_min_i(x0); x1 = wave_max_i(x1);
+    if(lane == 0)
+    {
+      atomicMin(&boxes[w.slot].yMin, y0); atomicMax(&boxes[w.slot].yMax, y1);
+      atomicMin(&boxes[w.slot].xMin, x0); atomicMax(&boxes[w.slot].xMax, x1);
+    }
   }
 }
 
-/* one word's worth of bits of image `slot`: into the window when it is inside, straight to memory otherwise */
-template<int WORDS>
-__device__ __forceinline__ void tile_or(TileWindow<WORDS> &T, TileCounters &c, unsigned long long *__restrict__ images,
-                                        unsigned int imgWords, int W64, int rows, int winSlot, int winRow0, ImageBox *boxes,
-                                        int slot, int iy, int xw, unsigned long long mask, bool &hit, bool &miss)
+/* per-lane record of what missed the window during one tile */
+struct MissInfo
 {
-  const unsigned int r = static_cast<unsigned int>(iy - winRow0);
-  if(slot == winSlot && r < static_cast<unsigned int>(rows))
+  bool hit = false, miss = false;
+  unsigned int key = 0xffffffffu;          /* lowest (slot << 16 | row) that missed */
+  int col = 0x7fffffff;                    /* lowest word column that missed */
+};
+
+/* one word's worth of bits of image `slot`: into the window when it is inside, straight to memory otherwise */
+__device__ __forceinline__ void wavewin_or(unsigned long long *ww, const WaveWindow &w, unsigned long long *__restrict__ images,
+                                           unsigned int imgWords, int W64, ImageBox *boxes, MissBox &mb, MissInfo &mi,
+                                           int slot, int iy, int xw, unsigned long long mask)
+{
+  const unsigned int r = static_cast<unsigned int>(iy - w.row0), c = static_cast<unsigned int>(xw - w.col0);
+  if(slot == w.slot && r < static_cast<unsigned int>(kWinRows) && c < static_cast<unsigned int>(kWinCols))
   {
-    atomicOr(&T.w[r * W64 + xw], mask);
-    hit = true;
+    atomicOr(&ww[r * kWinCols + c], mask);
+    mi.hit = true;
   }
   else
   {
     atomicOr(images + static_cast<size_t>(slot) * imgWords + static_cast<size_t>(iy) * W64 + xw, mask);
-    atomicMin(&c.missMin, (static_cast<unsigned int>(slot) << 16) | static_cast<unsigned int>(iy));
-    box_note(boxes[slot], iy, xw);
-    miss = true;
+    missbox_note(mb, boxes, slot, iy, xw);
+    mi.miss = true;
+    mi.key = min(mi.key, (static_cast<unsigned int>(slot) << 16) | static_cast<unsigned int>(iy));
+    mi.col = min(mi.col, xw);
   }
 }
 
-/* End of one tile of 1024 points, called by every thread: when more lanes missed the window than hit it,
- * the window is flushed and re-anchored at the lowest missing (image, row).  `it` counts tiles; the
- * counters rotate over three slots so that one barrier per tile suffices. */
-template<int WORDS>
-__device__ __forceinline__ void tile_end_of_iteration(TileWindow<WORDS> &T, unsigned long long *__restrict__ images,
-                                                      unsigned int imgWords, int W64, int H, int rows, int it, ImageBox *boxes,
-                                                      bool hit, bool miss, int &winSlot, int &winRow0, int tid, int lane)
+/* end of a tile, all 64 lanes: nothing to do unless some lane missed; re-anchor when misses outnumber hits */
+__device__ __forceinline__ void wavewin_end_of_tile(unsigned long long *ww, WaveWindow &w, unsigned long long *__restrict__ images,
+                                                    unsigned int imgWords, int W64, ImageBox *boxes, const MissInfo &mi, int lane)
 {
-  TileCounters &c = T.cnt[it % 3];
-  const unsigned int nh = static_cast<unsigned int>(__popcll(__ballot(hit)));
-  const unsigned int nm = static_cast<unsigned int>(__popcll(__ballot(miss)));
-  if(lane == 0)
-  {
-    if(nh) atomicAdd(&c.hitLanes, nh);
-    if(nm) atomicAdd(&c.missLanes, nm);
-  }
-  __syncthreads();
-  const unsigned int hitLanes = c.hitLanes, missLanes = c.missLanes, missMin = c.missMin;
-  if(tid == 0)
-    T.cnt[(it + 2) % 3] = TileCounters{ 0u, 0u, 0xffffffffu };
-  if(missLanes > hitLanes)                                 /* block-uniform */
-  {
-    tile_flush(T, images, imgWords, W64, H, winSlot, winRow0, rows, boxes, tid);
-    winSlot = static_cast<int>(missMin >> 16);
-    winRow0 = static_cast<int>(missMin & 0xffffu);
-    __syncthreads();
-  }
+  const unsigned long long missing = __ballot(mi.miss);
+  if(missing == 0ull)
+    return;
+  if(__popcll(missing) <= __popcll(__ballot(mi.hit)))
+    return;
+  wavewin_flush(ww, w, images, imgWords, W64, boxes, lane);
+  const unsigned int key = static_cast<unsigned int>(wave_min_i(static_cast<int>(mi.key >> 1))) ;   /* keys are < 2^31 after >> 1 */
+  /* recover the exact minimum: the lanes whose key >> 1 equals the minimum vote with their low bit */
+  const unsigned int lowBit = (__ballot((mi.key >> 1) == key && !(mi.key & 1u)) != 0ull) ? 0u : 1u;
+  const unsigned int full = (key << 1) | lowBit;
+  const int slot = static_cast<int>(full >> 16);
+  /* leftmost missing column of that image */
+  const int col = wave_min_i((mi.miss && static_cast<int>(mi.key >> 16) == slot) ? mi.col : 0x7fffffff);
+  w.slot = slot;
+  w.row0 = static_cast<int>(full & 0xffffu);
+  w.col0 = max(0, min(col - 1, W64 - kWinCols));
 }
 
 /* Projection2D::worldToImage (pointcloud.cpp:79-83); false = outside the image (quirk Q5) */
@@ -428,15 +458,12 @@ __device__ __forceinline__ bool image_pixel(const PointParams &P, const PixelPar
   return ix >= 0 && ix < X.W && iy >= 0 && iy < X.H;
 }
 
-constexpr int kTileWordsK2 = 2048;     /* 16 KiB window: 128 rows at XGA */
-constexpr int kTileWordsK4 = 1024;     /*  8 KiB window */
-
 template<bool ALIGNED>
 __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                         PixelParams X, FrameState *__restrict__ st,
                                                         unsigned long long *__restrict__ stepImg, int chunkPoints)
 {
-  __shared__ TileWindow<kTileWordsK2> T;
+  __shared__ unsigned long long wins[kThreads / 64][kWinWords];
   __shared__ ImageBox boxes[kMaxStepImages];
   __shared__ unsigned char lut[kMaxBins];
   __shared__ unsigned int lOob;
@@ -454,7 +481,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
     boxes[tid] = ImageBox{ 0x7fffffff, -1, 0x7fffffff, -1 };
   if(tid == 0)
     lOob = 0;
-  tile_init(T, tid);
+  for(int i = tid; i < (kThreads / 64) * kWinWords; i += kThreads)
+    (&wins[0][0])[i] = 0ull;
   __syncthreads();
 
   const float *base = xyz + static_cast<size_t>(frame) * strideFloats;
@@ -462,15 +490,14 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
   const int end = min(begin + chunkPoints, P.nPoints);
   const unsigned int imgWords = static_cast<unsigned int>(X.H) * X.W64;
   unsigned long long *frameImg = stepImg + static_cast<size_t>(frame) * X.maxStepImages * imgWords;
-  const int rows = min(X.H, kTileWordsK2 / X.W64);
-  int winSlot = -1, winRow0 = 0, it = 0;
+  unsigned long long *ww = wins[tid >> 6];
+  WaveWindow win;
+  MissBox mb;
   unsigned int oob = 0;
 
   SSD_STREAM_LOOP(
     /* the lane's four neighbouring pixels usually share one 64-bit word: merge them before touching LDS */
-    TileCounters &cnt = T.cnt[it % 3];
-    bool hit = false;
-    bool miss = false;
+    MissInfo mi;
     int pSlot = -1;
     int pY = 0;
     int pXw = 0;
@@ -496,15 +523,15 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
         continue;
       }
       if(pSlot >= 0)
-        tile_or(T, cnt, frameImg, imgWords, X.W64, rows, winSlot, winRow0, boxes, pSlot, pY, pXw, pMask, hit, miss);
+        wavewin_or(ww, win, frameImg, imgWords, X.W64, boxes, mb, mi, pSlot, pY, pXw, pMask);
       pSlot = slot; pY = iy; pXw = ix >> 6; pMask = bit;
     }
     if(pSlot >= 0)
-      tile_or(T, cnt, frameImg, imgWords, X.W64, rows, winSlot, winRow0, boxes, pSlot, pY, pXw, pMask, hit, miss);
-    tile_end_of_iteration(T, frameImg, imgWords, X.W64, X.H, rows, it, boxes, hit, miss, winSlot, winRow0, tid, lane);
-    it++;
+      wavewin_or(ww, win, frameImg, imgWords, X.W64, boxes, mb, mi, pSlot, pY, pXw, pMask);
+    wavewin_end_of_tile(ww, win, frameImg, imgWords, X.W64, boxes, mi, lane);
   )
-  tile_flush(T, frameImg, imgWords, X.W64, X.H, winSlot, winRow0, rows, boxes, tid);
+  wavewin_flush(ww, win, frameImg, imgWords, X.W64, boxes, lane);
+  missbox_flush(mb, boxes);
   if(oob)
     atomicAdd(&lOob, oob);
   __syncthreads();
@@ -1195,6 +1222,7 @@ __device__ __forceinline__ bool sector_overlaps(double lo, double up, double olo
 __device__ void build_quad_test(const double *q /* 4 x (x,y) */, QuadTest &t)
 {
   t.err = 0;
+  t.fx0 = 1.0; t.fx1 = 0.0; t.fy0 = 1.0; t.fy1 = 0.0;
   sector_init(q[0], q[2], t.bxLo, t.bxUp);
   sector_init(q[1], q[3], t.byLo, t.byUp);
   sector_expand(q[4], t.bxLo, t.bxUp); sector_expand(q[5], t.byLo, t.byUp);
@@ -1349,6 +1377,28 @@ __device__ void build_quad_test(const double *q /* 4 x (x,y) */, QuadTest &t)
   }
   t.yTrans[0] = nRows > 1 ? rowUpper[0] : 0.0;
   t.yTrans[1] = nRows > 2 ? rowUpper[1] : 0.0;
+
+  /* fast cell: the selectors put (x, y) into row r / cell c exactly when lower <= coordinate < upper
+   * (quadrilateralTest.cpp:487-571), first and last cells being bounded by the strict bounding box */
+  double bestArea = -1.0;
+  for(int r = 0; r < nRows; r++)
+  {
+    const double y0 = r == 0 ? nextafter(t.byLo, 1e300) : rowUpper[r - 1];
+    const double y1 = r == nRows - 1 ? t.byUp : rowUpper[r];
+    for(int c = 0; c < nCells[r]; c++)
+    {
+      if(cellMask[r][c] != 0 || cellConst[r][c] == 0)
+        continue;
+      const double x0 = c == 0 ? nextafter(t.bxLo, 1e300) : cellUpper[r][c - 1];
+      const double x1 = c == nCells[r] - 1 ? t.bxUp : cellUpper[r][c];
+      const double area = (x1 - x0) * (y1 - y0);
+      if(area > bestArea)
+      {
+        bestArea = area;
+        t.fx0 = x0; t.fx1 = x1; t.fy0 = y0; t.fy1 = y1;
+      }
+    }
+  }
 }
 
 /* QuadrilateralTest::isPointWithin (quadrilateralTest.cpp:445-451 and the selector lambdas :487-571) */
@@ -1470,11 +1520,11 @@ __device__ __forceinline__ long long z_to_fixed(double z)
 }
 
 template<bool ALIGNED>
-__global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
+__global__ __launch_bounds__(kThreads, 7) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                         PixelParams X, FrameState *__restrict__ st,
                                                         unsigned long long *__restrict__ groundImg, int chunkPoints)
 {
-  __shared__ TileWindow<kTileWordsK4> T;
+  __shared__ unsigned long long wins[kThreads / 64][kWinWords];
   __shared__ ImageBox box[1];
   __shared__ QuadTest qts[kMaxPlateaus + 1];
   __shared__ unsigned char lut[kMaxBins];
@@ -1509,7 +1559,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
     (&lsum[0][0])[i] = 0ull;
     (&lcnt[0][0])[i] = 0u;
   }
-  tile_init(T, tid);
+  for(int i = tid; i < (kThreads / 64) * kWinWords; i += kThreads)
+    (&wins[0][0])[i] = 0ull;
   {
     /* copy the live quadrilateral tests as 32-bit words */
     const unsigned int *src = reinterpret_cast<const unsigned int *>(fs.qt);
@@ -1522,18 +1573,15 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
   __syncthreads();
 
   const int groundInd = fs.groundInd;
-  const bool haveGround = active[kGroundAcc] != 0;
   const float *base = xyz + static_cast<size_t>(frame) * strideFloats;
   const int begin = blockIdx.x * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
   unsigned long long *gimg = groundImg + static_cast<size_t>(frame) * X.H * X.W64;
   const int copy = lane & 7;
   const unsigned int imgWords = static_cast<unsigned int>(X.H) * X.W64;
-  const int rows = min(X.H, kTileWordsK4 / X.W64);
-  /* the ground window is anchored once, at the first tile that meets ground points (camera rows run
-   * towards the camera, image rows with them); until then one barrier per tile, none afterwards */
-  int winSlot = -1, winRow0 = 0;
-  bool anchored = !haveGround;
+  unsigned long long *ww = wins[tid >> 6];
+  WaveWindow win;
+  MissBox mb;
 
   /* calcAverageZ (pointcloud.cpp:574-581) as an order-independent fixed-point sum: a thread walks down a
    * camera column, so consecutive hits nearly always belong to the same quadrilateral — the running sum
@@ -1551,8 +1599,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
   };
 
   SSD_STREAM_LOOP(
-    bool hit = false;
-    bool miss = false;
+    MissInfo mi;
     int pY = -1;
     int pXw = 0;
     unsigned long long pMask = 0;
@@ -1567,8 +1614,12 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
       const int q = p == groundInd ? kGroundAcc : p;
       if(!active[q])
         continue;
-      if(!quad_test(qts[q], wx, wy))
-        continue;
+      {
+        const QuadTest &t = qts[q];
+        const bool fast = wx >= t.fx0 && wx < t.fx1 && wy >= t.fy0 && wy < t.fy1;
+        if(!fast && !quad_test(t, wx, wy))
+          continue;
+      }
       if(q != curQ)
       {
         flushAcc();
@@ -1592,29 +1643,16 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
           continue;
         }
         if(pY >= 0)
-          tile_or(T, T.cnt[0], gimg, imgWords, X.W64, rows, winSlot, winRow0, box, 0, pY, pXw, pMask, hit, miss);
+          wavewin_or(ww, win, gimg, imgWords, X.W64, box, mb, mi, 0, pY, pXw, pMask);
         pY = iy; pXw = ix >> 6; pMask = bit;
       }
     }
     if(pY >= 0)
-      tile_or(T, T.cnt[0], gimg, imgWords, X.W64, rows, winSlot, winRow0, box, 0, pY, pXw, pMask, hit, miss);
-    if(!anchored)                                          /* block-uniform */
-    {
-      __syncthreads();
-      if(tid == 0)
-        T.cnt[1].missMin = T.cnt[0].missMin;               /* one snapshot for the whole block */
-      __syncthreads();
-      const unsigned int missMin = T.cnt[1].missMin;
-      if(missMin != 0xffffffffu)
-      {
-        winSlot = 0;
-        winRow0 = max(0, static_cast<int>(missMin & 0xffffu) - 2);
-        anchored = true;
-      }
-    }
+      wavewin_or(ww, win, gimg, imgWords, X.W64, box, mb, mi, 0, pY, pXw, pMask);
+    wavewin_end_of_tile(ww, win, gimg, imgWords, X.W64, box, mi, lane);
   )
-  __syncthreads();
-  tile_flush(T, gimg, imgWords, X.W64, X.H, winSlot, winRow0, rows, box, tid);
+  wavewin_flush(ww, win, gimg, imgWords, X.W64, box, lane);
+  missbox_flush(mb, box);
   flushAcc();
   if(oob)
     atomicAdd(&lOob, oob);
