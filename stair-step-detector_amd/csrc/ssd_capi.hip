@@ -54,6 +54,8 @@ struct ssd_handle
   FrameState *dState = nullptr;
   unsigned long long *dStepImg = nullptr;
   unsigned long long *dGroundImg = nullptr;
+  unsigned short *dTileMasks = nullptr;     /* per wave tile (256 points): which groups of 8 height bins occur; K1 -> K2, K4 */
+  size_t tileMaskStride = 0;
   ssd_frame_result *dResults = nullptr;
   ssd_frame_result *hResults = nullptr;     /* pinned */
   float *dFrames = nullptr;                 /* staging for ssd_process_host */
@@ -261,6 +263,8 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   HIP_TRY_H(hipMalloc(&h->dState, sizeof(FrameState) * h->F));
   HIP_TRY_H(hipMalloc(&h->dStepImg, stepBytes));
   HIP_TRY_H(hipMalloc(&h->dGroundImg, groundBytes));
+  h->tileMaskStride = (static_cast<size_t>(P.nPoints) + kTileHost - 1) / kTileHost * 4;
+  HIP_TRY_H(hipMalloc(&h->dTileMasks, h->tileMaskStride * 2 * h->F));
   HIP_TRY_H(hipMalloc(&h->dResults, sizeof(ssd_frame_result) * h->F));
   HIP_TRY_H(hipHostMalloc(&h->hResults, sizeof(ssd_frame_result) * h->F, hipHostMallocDefault));
   HIP_TRY_H(hipMemset(h->dState, 0, sizeof(FrameState) * h->F));
@@ -282,6 +286,7 @@ int ssd_destroy(ssd_handle *h)
   if(h->dState) (void)hipFree(h->dState);
   if(h->dStepImg) (void)hipFree(h->dStepImg);
   if(h->dGroundImg) (void)hipFree(h->dGroundImg);
+  if(h->dTileMasks) (void)hipFree(h->dTileMasks);
   if(h->dResults) (void)hipFree(h->dResults);
   if(h->hResults) (void)hipHostFree(h->hResults);
   if(h->dFrames) (void)hipFree(h->dFrames);
@@ -334,14 +339,20 @@ static int choose_chunk(int nPoints, int nframes)
 {
   const int forced = env_int("SSD_CHUNK_POINTS", 0);
   if(forced > 0)
-    return ((forced + kTileHost - 1) / kTileHost) * kTileHost;
+  {
+    const int c = ((forced + kTileHost - 1) / kTileHost) * kTileHost;
+    return c > kMaxTilesPerBlockHost * kTileHost ? kMaxTilesPerBlockHost * kTileHost : c;
+  }
   const int target = env_int("SSD_TARGET_BLOCKS", 16384);
   int cpf = (target + nframes - 1) / nframes;
   const int maxCpf = (nPoints + kTileHost - 1) / kTileHost;
   if(cpf > maxCpf) cpf = maxCpf;
   if(cpf < 1) cpf = 1;
   const int per = (nPoints + cpf - 1) / cpf;
-  return ((per + kTileHost - 1) / kTileHost) * kTileHost;
+  int chunk = ((per + kTileHost - 1) / kTileHost) * kTileHost;
+  if(chunk > kMaxTilesPerBlockHost * kTileHost)
+    chunk = kMaxTilesPerBlockHost * kTileHost;
+  return chunk;
 }
 
 int ssd_enqueue_stages(ssd_handle *h, const void *d_xyz, size_t frame_stride_bytes, int nframes, void *stream, int stages)
@@ -381,13 +392,13 @@ int ssd_enqueue_stages(ssd_handle *h, const void *d_xyz, size_t frame_stride_byt
   }
   mark();
   if(stages & SSD_STAGE_HIST)
-    launch_hist(xyz, strideFloats, P, h->dState, nframes, chunk, s);
+    launch_hist(xyz, strideFloats, P, h->dState, h->dTileMasks, h->tileMaskStride, nframes, chunk, s);
   mark();
   if(stages & SSD_STAGE_PEAKS)
     launch_peaks(P, h->dState, nframes, dbg, s);
   mark();
   if(stages & SSD_STAGE_RASTER)
-    launch_raster(xyz, strideFloats, P, h->dState, h->dStepImg, nframes, chunk, s);
+    launch_raster(xyz, strideFloats, P, h->dState, h->dStepImg, h->dTileMasks, h->tileMaskStride, nframes, chunk, s);
   mark();
   if(stages & SSD_STAGE_OUTLINE)
     launch_outline(P, h->dState, h->dStepImg, nframes, dbg, dbgImg, s);
@@ -396,7 +407,7 @@ int ssd_enqueue_stages(ssd_handle *h, const void *d_xyz, size_t frame_stride_byt
     launch_quads(P, h->dState, nframes, dbg, s);
   mark();
   if(stages & SSD_STAGE_INQUAD)
-    launch_inquad(xyz, strideFloats, P, h->dState, h->dGroundImg, nframes, chunk, s);
+    launch_inquad(xyz, strideFloats, P, h->dState, h->dGroundImg, h->dTileMasks, h->tileMaskStride, nframes, chunk, s);
   mark();
   if(stages & SSD_STAGE_FINAL)
     launch_final(P, h->dState, h->dGroundImg, h->dResults, nframes, dbg, dbgImg, s);

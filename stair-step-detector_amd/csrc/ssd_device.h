@@ -103,6 +103,9 @@ struct FrameState
   double groundQuadWorld[8];
   QuadTest qt[kMaxPlateaus + 1];   /* [kGroundAcc] = ground */
   unsigned char accActive[kMaxPlateaus + 1];
+  /* gates of K2 / K4 against K1's tile masks: groups of 8 height bins that hold a bin of a step plateau /
+   * of a live quadrilateral; anyActive = some accumulator is live */
+  unsigned int wantedSteps, wantedQuads, anyActive;
   long long sumZ[kMaxPlateaus + 1];
   unsigned int cnt[kMaxPlateaus + 1];
 };

@@ -100,19 +100,39 @@ __device__ __forceinline__ void load_points(const float *__restrict__ base, int 
     }                                                                                               \
   }
 
+/* K2 and K4 run after frame-wide decisions (plateau table, outlines) and need only the points of a few
+ * height bins.  Camera rows sweep one plateau at a time, so whole wave tiles (256 consecutive points) are
+ * irrelevant to them.  K1 therefore leaves one 16-bit mask per wave tile — which groups of 8 height bins
+ * occur in it (2 B per 256 points: no measurable traffic, unlike a byte per point which costs K1 a third of
+ * its bandwidth, tools/storebench.hip) — and the later passes skip, without loading anything, every tile
+ * whose mask has no group in common with the bins they care about. */
+constexpr int kBinsPerGroup = 8;
+constexpr int kWavesPerBlock = kThreads / 64;
+
+__device__ __forceinline__ unsigned int wave_or_u32(unsigned int v)
+{
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1)
+    v |= static_cast<unsigned int>(__shfl_xor(static_cast<int>(v), o));
+  return v;
+}
+
 template<bool ALIGNED>
 __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
-                                                   FrameState *__restrict__ st, int chunkPoints)
+                                                   FrameState *__restrict__ st, unsigned short *__restrict__ tileMasks,
+                                                   size_t tileMaskStride, int chunkPoints)
 {
+  constexpr int kMaxTilesPerBlock = 256;            /* chunkPoints <= 256 * 1024 (choose_chunk) */
+  __shared__ unsigned short lMasks[kMaxTilesPerBlock * kWavesPerBlock];
   /* [bin][copy]: a vote goes to copy = lane & 31, i.e. LDS bank = copy: the 32 lanes the LDS serves per
    * cycle never collide, whatever their bins (a camera row sweeping one plateau puts all 64 lanes in one bin) */
   __shared__ unsigned int lh[kMaxBins * kHistCopies];
   __shared__ unsigned int lNonZero;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int frame = blockIdx.y;
+  const int frame = blockIdx.x;                /* frame on the fast grid axis: see launch note on XCD balance */
   const float *base = xyz + static_cast<size_t>(frame) * strideFloats;
-  const int begin = blockIdx.x * chunkPoints;
+  const int begin = blockIdx.y * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
 
   for(int i = tid; i < kMaxBins * kHistCopies; i += kThreads)
@@ -123,14 +143,24 @@ __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ 
 
   unsigned int *mine = lh + (lane & (kHistCopies - 1));
   unsigned int nz = 0;
+  int it = 0;
   SSD_STREAM_LOOP(
+    unsigned int groups = 0u;
     _Pragma("unroll") for(int j = 0; j < kPts; j++)
     {
       double wx, wy, wz;
       nz += v[j].z > 0.0f ? 1u : 0u;
       if(world_point(P, v[j], wx, wy, wz))
-        atomicAdd(mine + height_bin(P, wz) * kHistCopies, 1u);          /* ++hist[bin], pointcloud.cpp:199-202 */
+      {
+        const int b = height_bin(P, wz);
+        atomicAdd(mine + b * kHistCopies, 1u);                          /* ++hist[bin], pointcloud.cpp:199-202 */
+        groups |= 1u << (b / kBinsPerGroup);
+      }
     }
+    groups = wave_or_u32(groups);
+    if(lane == 0)
+      lMasks[it * kWavesPerBlock + (tid >> 6)] = static_cast<unsigned short>(groups);
+    it++;
   )
 
   /* wave-reduce the non-zero count */
@@ -153,6 +183,12 @@ __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ 
   }
   if(tid == 0 && lNonZero)
     atomicAdd(&fs.nNonZero, lNonZero);
+  /* the block's tile masks, in one burst */
+  {
+    unsigned short *dst = tileMasks + static_cast<size_t>(frame) * tileMaskStride + static_cast<size_t>(begin / kTile) * kWavesPerBlock;
+    for(int i = tid; i < it * kWavesPerBlock; i += kThreads)
+      dst[i] = lMasks[i];
+  }
 }
 
 /* ========================================================================= */
@@ -267,6 +303,18 @@ __global__ void k_peaks(Params P, FrameState *__restrict__ st, int nframes, Debu
   }
   fs.nStepImages = nImg;
   fs.firstValidInd = -1;
+  {
+    unsigned int wanted = 0u;
+    for(int b = 0; b < nb; b++)
+    {
+      const int slot = static_cast<int>(fs.lut[b]) - i;
+      if(fs.lut[b] != 0xff && slot >= 0 && slot < nImg)
+        wanted |= 1u << (b / kBinsPerGroup);
+    }
+    fs.wantedSteps = wanted;
+    fs.wantedQuads = 0u;
+    fs.anyActive = 0u;
+  }
   for(int k = 0; k <= kMaxStepImages; k++)          /* [kMaxStepImages] = the ground image */
   {
     fs.imgYMin[k] = 0x7fffffff; fs.imgYMax[k] = -1;
@@ -461,7 +509,8 @@ __device__ __forceinline__ bool image_pixel(const PointParams &P, const PixelPar
 template<bool ALIGNED>
 __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                         PixelParams X, FrameState *__restrict__ st,
-                                                        unsigned long long *__restrict__ stepImg, int chunkPoints)
+                                                        unsigned long long *__restrict__ stepImg,
+                                                        const unsigned short *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints)
 {
   __shared__ unsigned long long wins[kThreads / 64][kWinWords];
   __shared__ ImageBox boxes[kMaxStepImages];
@@ -469,7 +518,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
   __shared__ unsigned int lOob;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int frame = blockIdx.y;
+  const int frame = blockIdx.x;                /* frame on the fast grid axis: see launch note on XCD balance */
   FrameState &fs = st[frame];
   const int nImg = fs.nStepImages;
   if(nImg == 0)
@@ -486,8 +535,10 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
   __syncthreads();
 
   const float *base = xyz + static_cast<size_t>(frame) * strideFloats;
-  const int begin = blockIdx.x * chunkPoints;
+  const int begin = blockIdx.y * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
+  const unsigned short *masks = tileMasks + static_cast<size_t>(frame) * tileMaskStride + (tid >> 6);
+  const unsigned int wanted = fs.wantedSteps;
   const unsigned int imgWords = static_cast<unsigned int>(X.H) * X.W64;
   unsigned long long *frameImg = stepImg + static_cast<size_t>(frame) * X.maxStepImages * imgWords;
   unsigned long long *ww = wins[tid >> 6];
@@ -495,14 +546,21 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
   MissBox mb;
   unsigned int oob = 0;
 
-  SSD_STREAM_LOOP(
+  for(int i0 = begin; i0 < end; i0 += kTile)
+  {
+    /* wave-uniform gate: nothing of this wave's 256 points can belong to a step plateau */
+    if(!(masks[static_cast<size_t>(i0 / kTile) * kWavesPerBlock] & wanted))
+      continue;
+    F3 v[kPts];
+    load_points<ALIGNED>(base, i0 + kPts * tid, end, v);
     /* the lane's four neighbouring pixels usually share one 64-bit word: merge them before touching LDS */
     MissInfo mi;
     int pSlot = -1;
     int pY = 0;
     int pXw = 0;
     unsigned long long pMask = 0;
-    _Pragma("unroll") for(int j = 0; j < kPts; j++)
+    #pragma unroll
+    for(int j = 0; j < kPts; j++)
     {
       double wx, wy, wz;
       if(!world_point(P, v[j], wx, wy, wz))
@@ -529,7 +587,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
     if(pSlot >= 0)
       wavewin_or(ww, win, frameImg, imgWords, X.W64, boxes, mb, mi, pSlot, pY, pXw, pMask);
     wavewin_end_of_tile(ww, win, frameImg, imgWords, X.W64, boxes, mi, lane);
-  )
+  }
   wavewin_flush(ww, win, frameImg, imgWords, X.W64, boxes, lane);
   missbox_flush(mb, boxes);
   if(oob)
@@ -789,7 +847,7 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
 {
   __shared__ OutlineShared S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int slot = blockIdx.x, frame = blockIdx.y;
+  const int slot = blockIdx.y, frame = blockIdx.x;
   FrameState &fs = st[frame];
   if(slot >= fs.nStepImages)
     return;
@@ -1495,6 +1553,19 @@ __global__ void k_quads(Params P, FrameState *__restrict__ st, int nframes, Debu
     for(int k = 0; k <= kMaxPlateaus; k++)
       fs.accActive[k] = 0;
   }
+  {
+    unsigned int wanted = 0u, any = 0u;
+    for(int k = 0; k <= kMaxPlateaus; k++)
+      any |= fs.accActive[k];
+    for(int b = 0; b < P.nBins; b++)
+    {
+      const int p = fs.lut[b];
+      if(p != 0xff && fs.accActive[p == fs.groundInd ? kGroundAcc : p])
+        wanted |= 1u << (b / kBinsPerGroup);
+    }
+    fs.wantedQuads = wanted;
+    fs.anyActive = any;
+  }
   if(dbg)
   {
     ssd_debug_frame &d = dbg[frame].d;
@@ -1522,7 +1593,8 @@ __device__ __forceinline__ long long z_to_fixed(double z)
 template<bool ALIGNED>
 __global__ __launch_bounds__(kThreads, 7) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                         PixelParams X, FrameState *__restrict__ st,
-                                                        unsigned long long *__restrict__ groundImg, int chunkPoints)
+                                                        unsigned long long *__restrict__ groundImg,
+                                                        const unsigned short *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints)
 {
   __shared__ unsigned long long wins[kThreads / 64][kWinWords];
   __shared__ ImageBox box[1];
@@ -1532,23 +1604,17 @@ __global__ __launch_bounds__(kThreads, 7) void k_inquad(const float *__restrict_
   __shared__ unsigned long long lsum[kMaxPlateaus + 1][8];
   __shared__ unsigned int lcnt[kMaxPlateaus + 1][8];
   __shared__ unsigned int lOob;
-  __shared__ int anyActive;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int frame = blockIdx.y;
+  const int frame = blockIdx.x;                /* frame on the fast grid axis: see launch note on XCD balance */
   FrameState &fs = st[frame];
+  if(!fs.anyActive)                                         /* block-uniform: set by k_quads */
+    return;
   if(tid == 0)
   {
-    int a = 0;
-    for(int k = 0; k <= kMaxPlateaus; k++)
-      a |= fs.accActive[k];
-    anyActive = a;
     box[0] = ImageBox{ 0x7fffffff, -1, 0x7fffffff, -1 };
     lOob = 0;
   }
-  __syncthreads();
-  if(!anyActive)
-    return;
 
   if(tid < kMaxBins)
     lut[tid] = fs.lut[tid];
@@ -1574,9 +1640,11 @@ __global__ __launch_bounds__(kThreads, 7) void k_inquad(const float *__restrict_
 
   const int groundInd = fs.groundInd;
   const float *base = xyz + static_cast<size_t>(frame) * strideFloats;
-  const int begin = blockIdx.x * chunkPoints;
+  const int begin = blockIdx.y * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
   unsigned long long *gimg = groundImg + static_cast<size_t>(frame) * X.H * X.W64;
+  const unsigned short *masks = tileMasks + static_cast<size_t>(frame) * tileMaskStride + (tid >> 6);
+  const unsigned int wanted = fs.wantedQuads;
   const int copy = lane & 7;
   const unsigned int imgWords = static_cast<unsigned int>(X.H) * X.W64;
   unsigned long long *ww = wins[tid >> 6];
@@ -1598,12 +1666,19 @@ __global__ __launch_bounds__(kThreads, 7) void k_inquad(const float *__restrict_
     }
   };
 
-  SSD_STREAM_LOOP(
+  for(int i0 = begin; i0 < end; i0 += kTile)
+  {
+    /* wave-uniform gate: nothing of this wave's 256 points can belong to a live quadrilateral */
+    if(!(masks[static_cast<size_t>(i0 / kTile) * kWavesPerBlock] & wanted))
+      continue;
+    F3 v[kPts];
+    load_points<ALIGNED>(base, i0 + kPts * tid, end, v);
     MissInfo mi;
     int pY = -1;
     int pXw = 0;
     unsigned long long pMask = 0;
-    _Pragma("unroll") for(int j = 0; j < kPts; j++)
+    #pragma unroll
+    for(int j = 0; j < kPts; j++)
     {
       double wx, wy, wz;
       if(!world_point(P, v[j], wx, wy, wz))
@@ -1650,7 +1725,7 @@ __global__ __launch_bounds__(kThreads, 7) void k_inquad(const float *__restrict_
     if(pY >= 0)
       wavewin_or(ww, win, gimg, imgWords, X.W64, box, mb, mi, 0, pY, pXw, pMask);
     wavewin_end_of_tile(ww, win, gimg, imgWords, X.W64, box, mi, lane);
-  )
+  }
   wavewin_flush(ww, win, gimg, imgWords, X.W64, box, lane);
   missbox_flush(mb, box);
   flushAcc();
@@ -1963,6 +2038,12 @@ __global__ void k_hypot(const double *a, const double *b, double *out, int n)
 namespace ssd
 {
 
+/* Grid layout of every per-frame kernel: FRAME on the fast axis (blockIdx.x), chunk / image slot on the slow
+ * one.  Workgroups are dealt round-robin over the 8 XCDs in linear-id order; with the chunk (or the image
+ * slot) on the fast axis every XCD would always get the same chunk positions of every frame — the stairs
+ * for some XCDs, the skipped ground for others (measured: +30 % on K2, and K3 running on half of the XCDs
+ * because only slots 0..3 hold images).  Frame-fastest gives each XCD whole frames: balanced, and a frame's
+ * state and images stay in one XCD's L2. */
 static inline int chunks_for(int nPoints, int chunkPoints) { return (nPoints + chunkPoints - 1) / chunkPoints; }
 
 static inline bool aligned16(const float *xyz, size_t strideFloats, int nPoints)
@@ -1970,42 +2051,45 @@ static inline bool aligned16(const float *xyz, size_t strideFloats, int nPoints)
   return (reinterpret_cast<uintptr_t>(xyz) & 15u) == 0 && (strideFloats & 3u) == 0 && (nPoints & 3) == 0;
 }
 
-void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, int nframes, int chunkPoints, hipStream_t s)
+void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned short *tileMasks, size_t tileMaskStride,
+                 int nframes, int chunkPoints, hipStream_t s)
 {
-  dim3 grid(chunks_for(P.nPoints, chunkPoints), nframes);
+  dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
   if(aligned16(xyz, strideFloats, P.nPoints))
-    hipLaunchKernelGGL(k_hist<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, chunkPoints);
+    hipLaunchKernelGGL(k_hist<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, tileMasks, tileMaskStride, chunkPoints);
   else
-    hipLaunchKernelGGL(k_hist<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, chunkPoints);
+    hipLaunchKernelGGL(k_hist<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, tileMasks, tileMaskStride, chunkPoints);
 }
 void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s)
 {
   hipLaunchKernelGGL(k_peaks, dim3((nframes + 63) / 64), dim3(64), 0, s, P, st, nframes, dbg);
 }
-void launch_raster(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *stepImg, int nframes, int chunkPoints, hipStream_t s)
+void launch_raster(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *stepImg,
+                   const unsigned short *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, hipStream_t s)
 {
-  dim3 grid(chunks_for(P.nPoints, chunkPoints), nframes);
+  dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
   if(aligned16(xyz, strideFloats, P.nPoints))
-    hipLaunchKernelGGL(k_raster<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, chunkPoints);
+    hipLaunchKernelGGL(k_raster<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints);
   else
-    hipLaunchKernelGGL(k_raster<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, chunkPoints);
+    hipLaunchKernelGGL(k_raster<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints);
 }
 void launch_outline(const Params &P, FrameState *st, unsigned long long *stepImg, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
 {
-  dim3 grid(P.maxStepImages, nframes);
+  dim3 grid(nframes, P.maxStepImages);
   hipLaunchKernelGGL(k_outline, grid, dim3(kThreads), 0, s, P, st, stepImg, dbg, dbgImg);
 }
 void launch_quads(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s)
 {
   hipLaunchKernelGGL(k_quads, dim3((nframes + 63) / 64), dim3(64), 0, s, P, st, nframes, dbg);
 }
-void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *groundImg, int nframes, int chunkPoints, hipStream_t s)
+void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *groundImg,
+                   const unsigned short *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, hipStream_t s)
 {
-  dim3 grid(chunks_for(P.nPoints, chunkPoints), nframes);
+  dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
   if(aligned16(xyz, strideFloats, P.nPoints))
-    hipLaunchKernelGGL(k_inquad<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, groundImg, chunkPoints);
+    hipLaunchKernelGGL(k_inquad<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, groundImg, tileMasks, tileMaskStride, chunkPoints);
   else
-    hipLaunchKernelGGL(k_inquad<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, groundImg, chunkPoints);
+    hipLaunchKernelGGL(k_inquad<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, groundImg, tileMasks, tileMaskStride, chunkPoints);
 }
 void launch_final(const Params &P, FrameState *st, unsigned long long *groundImg, ssd_frame_result *results, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
 {
