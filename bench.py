@@ -28,6 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec; ~6.3 TB/s achievable by a float4 copy)
 METRIC = "point-cloud frames/sec (1024×768 pts) at 1/2/4/8 GPUs; step height/corner max-abs err"
+METRIC_FHD = "point-cloud frames/sec (1920×1080 pts, stress); step height/corner max-abs err"
 
 
 def shard(total, world, rank):
@@ -42,10 +43,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=1024, help="frames per GPU per step")
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--height", type=int, default=768)
-    ap.add_argument("--cpu-frames", type=int, default=192, help="bounded CPU-baseline sample (frames)")
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (default: 1024 XGA / 256 FHD)")
+    ap.add_argument("--workload", choices=["xga_batch", "fhd_stress"], default="xga_batch",
+                    help="xga_batch = BASELINE configs[2] (the metric's configuration); fhd_stress = configs[4]")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="bounded CPU-baseline sample in frames (default: ~15 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -68,12 +69,17 @@ def main():
     ssd = importlib.import_module("stair-step-detector_amd")
     import scenes
 
-    W, H, F = args.width, args.height, args.frames
+    fhd = args.workload == "fhd_stress"
+    W, H = (1920, 1080) if fhd else (1024, 768)
+    F = args.frames or (256 if fhd else 1024)
     frame_bytes = W * H * 12
     # frames of this rank: a contiguous range of the global frame index space (no overlap between ranks)
     lo, hi = shard(F * world, world, rank)
     assert hi - lo == F
-    sc_list = scenes.batch_scenes(ssd, W, H, F, base_seed=100000 + lo, rng_seed=1000 + rank)
+    if fhd:
+        sc_list = scenes.fhd_stress_scenes(ssd, F, base_seed=9000 + lo)
+    else:
+        sc_list = scenes.batch_scenes(ssd, W, H, F, base_seed=100000 + lo, rng_seed=1000 + rank)
     trans = ssd.transformation_for_scene(sc_list[0])
     cfg = ssd.default_config(W, H, max_frames_per_batch=F)
     frames = torch.empty(F * frame_bytes, dtype=torch.uint8, device="cuda")
@@ -124,14 +130,19 @@ def main():
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch_at_%dx%dx%d" % (W, H, F))
+                if traffic is None and not fhd:     # measured at 1024 frames: scale per frame
+                    ref = json.load(open(pmc)).get("hbm_bytes_per_launch_at_1024x768x1024")
+                    traffic = None if ref is None else ref * F / 1024.0
             except Exception:
                 traffic = None
         out = {
-            "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "metric": METRIC_FHD if fhd else METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: batch of %d synthetic %dx%d frames (3-step staircases, randomised rise/"
-                                   "tread/yaw/noise) resident in HBM, streamed through the whole per-frame path; per GPU" % (F, W, H),
+            "config": {"workload": ("BASELINE configs[4]: %d synthetic %dx%d frames (8 noisy steps, 5 %% outliers) resident in HBM; per GPU"
+                                    if fhd else
+                                    "BASELINE configs[2]: batch of %d synthetic %dx%d frames (3-step staircases, randomised rise/"
+                                    "tread/yaw/noise) resident in HBM, streamed through the whole per-frame path; per GPU") % (F, W, H),
                        "frames_per_gpu_per_step": F, "width": W, "height": H, "parallelism": "frame-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "kernel": "k_hist (K1: transform+crop+bin+histogram)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -140,28 +151,30 @@ def main():
             "pipeline_bytes_algorithmic_frac_of_peak": (alg_bytes * args.steps / dt_max / 1e9) / HBM_PEAK_GBS,
         }
         steps_hist = [r.n_steps for r in res]
-        out["frames_with_ground_and_3_steps"] = int(sum(1 for n in steps_hist if n == 4))
+        out["steps_histogram"] = {str(k): int(sum(1 for n in steps_hist if n == k)) for k in sorted(set(steps_hist))}
 
         if not args.no_cpu:
             import oracle_binding as ob
             import parity
             oracle = ob.load_oracle()
             ocfg, ocal = ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants)
-            n_cpu = max(1, min(args.cpu_frames, F))
+            n_cpu = max(1, min(args.cpu_frames or (256 if fhd else 1280), F))
             idx = [int(i) for i in np.linspace(0, F - 1, n_cpu)]
-            host = [frames[i * frame_bytes:(i + 1) * frame_bytes].cpu().numpy().view(np.float32) for i in idx]
             rep = {}
-            c0 = time.perf_counter()
-            cpu_out = [oracle.process_lean(ocfg, ocal, x) for x in host]
-            cdt = time.perf_counter() - c0
+            cdt = 0.0
             checked = 0
-            for i, x in zip(idx, host):
+            for i in idx:                                   # one frame at a time: download (untimed), oracle (timed)
+                x = frames[i * frame_bytes:(i + 1) * frame_bytes].cpu().numpy().view(np.float32)
+                c0 = time.perf_counter()
+                oracle.process_lean(ocfg, ocal, x)
+                cdt += time.perf_counter() - c0
                 if i % 64 == 0 or i == idx[-1]:
                     parity.check_results_only(ssd, oracle, cfg, trans.constants, x, res[i], rep)
                     checked += 1
             out["cpu_baseline"] = {"value": n_cpu / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
-                                   "sample": "%d of the %d frames of rank 0's batch (evenly spaced), whole path incl. naive-free "
-                                             "separable 3x3 close, oracle/ssd_oracle.cpp single thread, %.1f s" % (n_cpu, F, cdt)}
+                                   "sample": "%d of the %d frames of rank 0's batch (evenly spaced), the whole per-frame path in "
+                                             "oracle/ssd_oracle.cpp (CPU restatement of the reference, one thread as the reference runs), "
+                                             "%.1f s of CPU time" % (n_cpu, F, cdt)}
             out["parity"] = {"frames_checked_against_oracle": checked, "max_abs_height_err_m": rep.get("max_height_err", 0.0),
                              "max_abs_corner_err_m": rep.get("max_corner_err", 0.0), "bar_m": 1e-4}
         print(json.dumps(out), flush=True)

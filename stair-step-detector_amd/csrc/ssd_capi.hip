@@ -343,7 +343,7 @@ static int choose_chunk(int nPoints, int nframes)
     const int c = ((forced + kTileHost - 1) / kTileHost) * kTileHost;
     return c > kMaxTilesPerBlockHost * kTileHost ? kMaxTilesPerBlockHost * kTileHost : c;
   }
-  const int target = env_int("SSD_TARGET_BLOCKS", 16384);
+  const int target = env_int("SSD_TARGET_BLOCKS", 32768);
   int cpf = (target + nframes - 1) / nframes;
   const int maxCpf = (nPoints + kTileHost - 1) / kTileHost;
   if(cpf > maxCpf) cpf = maxCpf;

@@ -1591,7 +1591,7 @@ __device__ __forceinline__ long long z_to_fixed(double z)
 }
 
 template<bool ALIGNED>
-__global__ __launch_bounds__(kThreads, 7) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
+__global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                         PixelParams X, FrameState *__restrict__ st,
                                                         unsigned long long *__restrict__ groundImg,
                                                         const unsigned short *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints)

@@ -49,3 +49,9 @@ def batch_scenes(ssd, width, height, n, base_seed=1000, rng_seed=7):
                                   rise=float(rng.uniform(0.14, 0.20)), tread=float(rng.uniform(0.25, 0.32)),
                                   yaw_deg=float(rng.uniform(-10.0, 10.0)), sigma=float(rng.uniform(0.0005, 0.003))))
     return out
+
+
+def fhd_stress_scenes(ssd, n, base_seed=9000):
+    """BASELINE.json config 5: 1920x1080, 8 noisy steps + 5 % outliers."""
+    return [ssd.make_scene(1920, 1080, n_steps=8, sigma=0.002, seed=base_seed + i, outlier_frac=0.05, tread=0.14, rise=0.12,
+                           first_riser_y=0.15, cam_height=1.4, pitch_deg=55.0) for i in range(n)]

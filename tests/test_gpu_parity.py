@@ -158,3 +158,22 @@ def test_full_size_properties_xga_batch(ssd, oracle, gpu_device):
         parity.check_results_only(ssd, oracle, cfg, trans.constants, host[k], r1[i])
     det.close()
     buf.free()
+
+
+def test_detect_stairs_driver_prints_the_reference_line(ssd, oracle, gpu_device):
+    """The C++ surface (stairs::Pointcloud::process via lib/detect-stairs-amd, the detect-stairs.cpp loop) prints
+    exactly the line the oracle derives for the same synthetic frame."""
+    import math
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(ssd.LIB_PATH), "detect-stairs-amd")
+    assert os.path.exists(exe), "driver not built"
+    out = subprocess.run([exe, "--width", "640", "--height", "480", "--frames", "2", "--steps", "3", "--seed", "77"],
+                         check=True, capture_output=True, text=True, timeout=300).stdout.strip().splitlines()
+    assert len(out) == 2
+    for f in range(2):
+        sc = ssd.make_scene(640, 480, n_steps=3, seed=77 + f)      # the driver's makeScene() defaults
+        trans = ssd.GeometricTransformation(*ssd.calibration_points(sc, world_offset=(0.0, 0.0, 0.0)))
+        cfg = ssd.default_config(640, 480)
+        res, *_ = oracle.process(ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants), ssd.synth_host([sc])[0])
+        assert out[f] == res.line.decode()

@@ -10,5 +10,9 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace_fhd --output-format csv -- python3 $R/bench.py --workload fhd_stress --steps 5 --warmup 2 --no-cpu > $OUT/trace_fhd.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch_fhd --output-format csv -- python3 $R/bench.py --workload fhd_stress --steps 3 --warmup 1 --no-cpu > $OUT/fetch_fhd.log 2>&1
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
-ls -R $OUT | head -40
+python3 $R/bench.py --workload fhd_stress --cpu-frames 48 > $OUT/bench_fhd.json 2> $OUT/bench_fhd.err
+python3 $R/tools/hostfed.py 64 > $OUT/hostfed.json 2>&1
+ls -R $OUT | head -50
