@@ -54,7 +54,7 @@ struct ssd_handle
   FrameState *dState = nullptr;
   unsigned long long *dStepImg = nullptr;
   unsigned long long *dGroundImg = nullptr;
-  unsigned short *dTileMasks = nullptr;     /* per wave tile (256 points): which groups of 8 height bins occur; K1 -> K2, K4 */
+  unsigned int *dTileMasks = nullptr;       /* per wave tile (256 points): which groups of 4 height bins occur; K1 -> K2, K4 */
   size_t tileMaskStride = 0;
   ssd_frame_result *dResults = nullptr;
   ssd_frame_result *hResults = nullptr;     /* pinned */
@@ -264,7 +264,7 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   HIP_TRY_H(hipMalloc(&h->dStepImg, stepBytes));
   HIP_TRY_H(hipMalloc(&h->dGroundImg, groundBytes));
   h->tileMaskStride = (static_cast<size_t>(P.nPoints) + kTileHost - 1) / kTileHost * 4;
-  HIP_TRY_H(hipMalloc(&h->dTileMasks, h->tileMaskStride * 2 * h->F));
+  HIP_TRY_H(hipMalloc(&h->dTileMasks, h->tileMaskStride * 4 * h->F));
   HIP_TRY_H(hipMalloc(&h->dResults, sizeof(ssd_frame_result) * h->F));
   HIP_TRY_H(hipHostMalloc(&h->hResults, sizeof(ssd_frame_result) * h->F, hipHostMallocDefault));
   HIP_TRY_H(hipMemset(h->dState, 0, sizeof(FrameState) * h->F));

@@ -43,6 +43,27 @@ __device__ __forceinline__ bool world_point(const PointParams &P, const F3 &v, d
   return wx > P.xMin && wx < P.xMax && wy > P.yMin && wy < P.yMax && wz > P.zMin && wz < P.zMax;
 }
 
+/* The same decisions taken height first, for the passes that drop most points on their height bin: the z row
+ * and the z tests, then (only for points whose bin matters) the x and y rows and their tests.  The
+ * conjunction of tests and every operation are those of world_point. */
+__device__ __forceinline__ bool world_z(const PointParams &P, const F3 &v, double &wz)
+{
+  if(!(v.z > 0.0f))
+    return false;
+  wz = (P.a[6] * static_cast<double>(v.x) + P.a[7] * static_cast<double>(v.y)) + P.a[8] * static_cast<double>(v.z);
+  wz = wz + P.b[2];
+  return wz > P.zMin && wz < P.zMax;
+}
+__device__ __forceinline__ bool world_xy(const PointParams &P, const F3 &v, double &wx, double &wy)
+{
+  const double x = v.x, y = v.y, z = v.z;
+  wx = (P.a[0] * x + P.a[1] * y) + P.a[2] * z;
+  wy = (P.a[3] * x + P.a[4] * y) + P.a[5] * z;
+  wx = wx + P.b[0];
+  wy = wy + P.b[1];
+  return wx > P.xMin && wx < P.xMax && wy > P.yMin && wy < P.yMax;
+}
+
 /* calcHeights (pointcloud.cpp:175): truncating conversion, value is in [0, nBins) */
 __device__ __forceinline__ int height_bin(const PointParams &P, double wz)
 {
@@ -102,11 +123,11 @@ __device__ __forceinline__ void load_points(const float *__restrict__ base, int 
 
 /* K2 and K4 run after frame-wide decisions (plateau table, outlines) and need only the points of a few
  * height bins.  Camera rows sweep one plateau at a time, so whole wave tiles (256 consecutive points) are
- * irrelevant to them.  K1 therefore leaves one 16-bit mask per wave tile — which groups of 8 height bins
- * occur in it (2 B per 256 points: no measurable traffic, unlike a byte per point which costs K1 a third of
+ * irrelevant to them.  K1 therefore leaves one 32-bit mask per wave tile — which groups of 4 height bins
+ * occur in it (4 B per 256 points: no measurable traffic, unlike a byte per point which costs K1 a third of
  * its bandwidth, tools/storebench.hip) — and the later passes skip, without loading anything, every tile
  * whose mask has no group in common with the bins they care about. */
-constexpr int kBinsPerGroup = 8;
+constexpr int kBinsPerGroup = 4;      /* 128 bins -> 32 groups: one 32-bit mask per wave tile */
 constexpr int kWavesPerBlock = kThreads / 64;
 
 __device__ __forceinline__ unsigned int wave_or_u32(unsigned int v)
@@ -119,11 +140,11 @@ __device__ __forceinline__ unsigned int wave_or_u32(unsigned int v)
 
 template<bool ALIGNED>
 __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
-                                                   FrameState *__restrict__ st, unsigned short *__restrict__ tileMasks,
+                                                   FrameState *__restrict__ st, unsigned int *__restrict__ tileMasks,
                                                    size_t tileMaskStride, int chunkPoints)
 {
   constexpr int kMaxTilesPerBlock = 256;            /* chunkPoints <= 256 * 1024 (choose_chunk) */
-  __shared__ unsigned short lMasks[kMaxTilesPerBlock * kWavesPerBlock];
+  __shared__ unsigned int lMasks[kMaxTilesPerBlock * kWavesPerBlock];
   /* [bin][copy]: a vote goes to copy = lane & 31, i.e. LDS bank = copy: the 32 lanes the LDS serves per
    * cycle never collide, whatever their bins (a camera row sweeping one plateau puts all 64 lanes in one bin) */
   __shared__ unsigned int lh[kMaxBins * kHistCopies];
@@ -159,7 +180,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ 
     }
     groups = wave_or_u32(groups);
     if(lane == 0)
-      lMasks[it * kWavesPerBlock + (tid >> 6)] = static_cast<unsigned short>(groups);
+      lMasks[it * kWavesPerBlock + (tid >> 6)] = groups;
     it++;
   )
 
@@ -185,7 +206,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ 
     atomicAdd(&fs.nNonZero, lNonZero);
   /* the block's tile masks, in one burst */
   {
-    unsigned short *dst = tileMasks + static_cast<size_t>(frame) * tileMaskStride + static_cast<size_t>(begin / kTile) * kWavesPerBlock;
+    unsigned int *dst = tileMasks + static_cast<size_t>(frame) * tileMaskStride + static_cast<size_t>(begin / kTile) * kWavesPerBlock;
     for(int i = tid; i < it * kWavesPerBlock; i += kThreads)
       dst[i] = lMasks[i];
   }
@@ -510,7 +531,7 @@ template<bool ALIGNED>
 __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                         PixelParams X, FrameState *__restrict__ st,
                                                         unsigned long long *__restrict__ stepImg,
-                                                        const unsigned short *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints)
+                                                        const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints)
 {
   __shared__ unsigned long long wins[kThreads / 64][kWinWords];
   __shared__ ImageBox boxes[kMaxStepImages];
@@ -537,7 +558,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
   const float *base = xyz + static_cast<size_t>(frame) * strideFloats;
   const int begin = blockIdx.y * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
-  const unsigned short *masks = tileMasks + static_cast<size_t>(frame) * tileMaskStride + (tid >> 6);
+  const unsigned int *masks = tileMasks + static_cast<size_t>(frame) * tileMaskStride + (tid >> 6);
   const unsigned int wanted = fs.wantedSteps;
   const unsigned int imgWords = static_cast<unsigned int>(X.H) * X.W64;
   unsigned long long *frameImg = stepImg + static_cast<size_t>(frame) * X.maxStepImages * imgWords;
@@ -563,10 +584,12 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
     for(int j = 0; j < kPts; j++)
     {
       double wx, wy, wz;
-      if(!world_point(P, v[j], wx, wy, wz))
+      if(!world_z(P, v[j], wz))
         continue;
       const int slot = static_cast<int>(lut[height_bin(P, wz)]) - firstStep;   /* 0xff - firstStep >= nImg */
       if(slot < 0 || slot >= nImg)
+        continue;
+      if(!world_xy(P, v[j], wx, wy))
         continue;
       int ix, iy;
       if(!image_pixel(P, X, wx, wy, ix, iy))
@@ -1594,7 +1617,7 @@ template<bool ALIGNED>
 __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                         PixelParams X, FrameState *__restrict__ st,
                                                         unsigned long long *__restrict__ groundImg,
-                                                        const unsigned short *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints)
+                                                        const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints)
 {
   __shared__ unsigned long long wins[kThreads / 64][kWinWords];
   __shared__ ImageBox box[1];
@@ -1643,7 +1666,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
   const int begin = blockIdx.y * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
   unsigned long long *gimg = groundImg + static_cast<size_t>(frame) * X.H * X.W64;
-  const unsigned short *masks = tileMasks + static_cast<size_t>(frame) * tileMaskStride + (tid >> 6);
+  const unsigned int *masks = tileMasks + static_cast<size_t>(frame) * tileMaskStride + (tid >> 6);
   const unsigned int wanted = fs.wantedQuads;
   const int copy = lane & 7;
   const unsigned int imgWords = static_cast<unsigned int>(X.H) * X.W64;
@@ -1681,13 +1704,15 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
     for(int j = 0; j < kPts; j++)
     {
       double wx, wy, wz;
-      if(!world_point(P, v[j], wx, wy, wz))
+      if(!world_z(P, v[j], wz))
         continue;
       const int p = lut[height_bin(P, wz)];
       if(p == 0xff)
         continue;
       const int q = p == groundInd ? kGroundAcc : p;
       if(!active[q])
+        continue;
+      if(!world_xy(P, v[j], wx, wy))
         continue;
       {
         const QuadTest &t = qts[q];
@@ -2051,7 +2076,7 @@ static inline bool aligned16(const float *xyz, size_t strideFloats, int nPoints)
   return (reinterpret_cast<uintptr_t>(xyz) & 15u) == 0 && (strideFloats & 3u) == 0 && (nPoints & 3) == 0;
 }
 
-void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned short *tileMasks, size_t tileMaskStride,
+void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned int *tileMasks, size_t tileMaskStride,
                  int nframes, int chunkPoints, hipStream_t s)
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
@@ -2065,7 +2090,7 @@ void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg,
   hipLaunchKernelGGL(k_peaks, dim3((nframes + 63) / 64), dim3(64), 0, s, P, st, nframes, dbg);
 }
 void launch_raster(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *stepImg,
-                   const unsigned short *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, hipStream_t s)
+                   const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, hipStream_t s)
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
   if(aligned16(xyz, strideFloats, P.nPoints))
@@ -2083,7 +2108,7 @@ void launch_quads(const Params &P, FrameState *st, int nframes, DebugFrame *dbg,
   hipLaunchKernelGGL(k_quads, dim3((nframes + 63) / 64), dim3(64), 0, s, P, st, nframes, dbg);
 }
 void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *groundImg,
-                   const unsigned short *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, hipStream_t s)
+                   const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, hipStream_t s)
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
   if(aligned16(xyz, strideFloats, P.nPoints))
