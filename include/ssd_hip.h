@@ -95,6 +95,16 @@ typedef struct ssd_handle ssd_handle;
 int ssd_default_config(ssd_config *cfg, int width, int height);
 int ssd_calibration_from_points(const double world_points[9], const double camera_points[9], ssd_calibration *out);
 int ssd_calibration_identity(ssd_calibration *out);   /* GeometricTransformation() default, transformation.h:51-55 */
+/* GeometricCalibration::load() (geometricCalibration.cpp:185-203): reads the two text files the calibration
+ * step leaves in the working directory — "calibration-triangle" (calibrationTriangle.cpp:97-125: header line
+ * `calibration triangle`, `xN = v, yN = v, zN = v` for N = 1..3, `lowerQuadrant = left|right`) and
+ * "calibration-points" (geometricCalibration.cpp:73-98: header line `calibration points`, 10 rows of
+ * `x, y, z; x, y, z; x, y, z`) — averages the 10 point sets and builds the transformation.
+ * Returns SSD_OK and *loaded = 1; if a file is missing or invalid the reference logs an error and carries on
+ * with the identity transformation (:199-202): *loaded = 0, identity in *out, still SSD_OK.
+ * world_points / camera_points (9 doubles each, may be NULL) receive what was read. */
+int ssd_calibration_load(const char *triangle_path, const char *points_path, ssd_calibration *out, int *loaded,
+                         double *world_points, double *camera_points);
 
 /* ---- lifetime ------------------------------------------------------------ */
 int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ssd_handle **out);

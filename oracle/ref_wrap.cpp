@@ -3,6 +3,7 @@
  * compile from their own sources with no third-party dependency:
  *   /root/reference/stairs.cpp            (Stairs::serialize, stairs.cpp:55-70)
  *   /root/reference/quadrilateralTest.cpp (QuadrilateralTest, quadrilateralTest.cpp:275-451)
+ *   /root/reference/calibrationTriangle.cpp (CalibrationTriangle::load / isValid, calibrationTriangle.cpp:97-172)
  * The reference sources are compiled where they lie (see Makefile target `ref`);
  * nothing of them is copied into this repository.  Output: oracle/_ref/libssd_ref.so.
  * TEST INFRASTRUCTURE ONLY: used to pin oracle/ssd_oracle.cpp's restatement of
@@ -10,6 +11,7 @@
  */
 #include "stairs.h"
 #include "quadrilateralTest.h"
+#include "calibrationTriangle.h"
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -56,4 +58,29 @@ extern "C" int ssdref_quad_test(const double quad[8], const double *pts_xy, int 
     return -99;
   }
   return 0;
+}
+
+#include <unistd.h>
+
+/* CalibrationTriangle::load() reads "calibration-triangle" from the working directory: run it inside `dir`.
+ * returns 0 = loaded and valid (world[9], *side: 1 left, 2 right), 1 = load failed, 2 = not valid */
+extern "C" int ssdref_load_triangle(const char *dir, double world[9], int *side)
+{
+  char cwd[4096];
+  if(!getcwd(cwd, sizeof cwd) || chdir(dir) != 0)
+    return -1;
+  stairs::CalibrationTriangle t;
+  const int rc = t.load();
+  const bool valid = rc == 0 && t.isValid();
+  if(chdir(cwd) != 0)
+    return -1;
+  if(rc != 0)
+    return 1;
+  const auto &c = t.getTriangleCorners();
+  for(int i = 0; i < 3; i++)
+  {
+    world[3 * i] = c[i].x; world[3 * i + 1] = c[i].y; world[3 * i + 2] = c[i].z;
+  }
+  *side = t.getLowerQuadrant() == stairs::CalibrationTriangle::Side::left ? 1 : (t.getLowerQuadrant() == stairs::CalibrationTriangle::Side::right ? 2 : 0);
+  return valid ? 0 : 2;
 }

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <iomanip>
 #include <optional>
 #include <sstream>
@@ -1336,6 +1337,91 @@ int ssdo_calibration_from_points(const double world[9], const double cam[9], ssd
   out->t2[1] = rp0.y - (out->r2[2] * m0.x + out->r2[3] * m0.y);
   out->world_z = world[2];
   return rc;
+}
+
+/* calibrationTriangle.cpp:48-68,97-125,148-172 and geometricCalibration.cpp:73-98,127-141,185-203 */
+int ssdo_calibration_load(const char *triangle_path, const char *points_path, double world[9], double cam[9])
+{
+  auto readValue = [](std::ifstream &file, const std::string &name, auto &value)
+  {
+    while(file)
+    {
+      std::string chars;
+      file >> chars;
+      if(chars == name)
+      {
+        std::string sign;
+        file >> sign;
+        if(sign == "=")
+        {
+          file >> value;
+          return static_cast<bool>(file);
+        }
+      }
+    }
+    return false;
+  };
+  {
+    std::ifstream file(triangle_path);
+    std::string id;
+    std::getline(file, id);
+    if(id != "calibration triangle")
+      return -1;
+    bool r = true;
+    for(int n = 1; n <= 3; n++)
+    {
+      const std::string ns = std::to_string(n);
+      r = r && readValue(file, "x" + ns, world[3 * (n - 1)]);
+      r = r && readValue(file, "y" + ns, world[3 * (n - 1) + 1]);
+      r = r && readValue(file, "z" + ns, world[3 * (n - 1) + 2]);
+    }
+    std::string side;
+    r = r && readValue(file, std::string("lowerQuadrant"), side);
+    if(!r)
+      return -1;
+    auto distQu = [&](int a, int b)
+    {
+      const double dx = world[3 * b] - world[3 * a], dy = world[3 * b + 1] - world[3 * a + 1], dz = world[3 * b + 2] - world[3 * a + 2];
+      return dx * dx + dy * dy + dz * dz;
+    };
+    const double minDistQu = 0.01 * 0.01;
+    if(distQu(0, 1) < minDistQu || distQu(1, 2) < minDistQu || distQu(2, 0) < minDistQu)
+      return -1;
+    if(side != "left" && side != "right")
+      return -1;
+  }
+  {
+    std::ifstream file(points_path);
+    std::string id;
+    std::getline(file, id);
+    if(id != "calibration points")
+      return -2;
+    std::vector<std::array<float, 9>> sets;
+    while(true)
+    {
+      std::array<float, 9> p;
+      char ch;
+      file >> p[0] >> ch >> p[1] >> ch >> p[2] >> ch >> p[3] >> ch >> p[4] >> ch >> p[5] >> ch >> p[6] >> ch >> p[7] >> ch >> p[8];
+      if(!file)
+        break;
+      sets.push_back(p);
+      if(sets.size() == 10)
+        break;
+    }
+    if(sets.size() != 10)
+      return -2;
+    P3 avg[3];
+    for(const auto &p : sets)
+      for(int k = 0; k < 3; k++)
+      {
+        avg[k].x += double(p[3 * k]); avg[k].y += double(p[3 * k + 1]); avg[k].z += double(p[3 * k + 2]);
+      }
+    for(int k = 0; k < 3; k++)
+    {
+      cam[3 * k] = avg[k].x / sets.size(); cam[3 * k + 1] = avg[k].y / sets.size(); cam[3 * k + 2] = avg[k].z / sets.size();
+    }
+  }
+  return 0;
 }
 
 int ssdo_process(const ssdo_config *cfg, const ssdo_calibration *cal, const float *xyz, ssdo_result *out,

@@ -119,6 +119,10 @@ void ssdo_default_config(ssdo_config *cfg, int width, int height);
 /* GeometricTransformation(worldPoints, cameraPoints); 0 = ok, <0 = a reference assert would fire */
 int ssdo_calibration_from_points(const double world[9], const double cam[9], ssdo_calibration *out);
 
+/* GeometricCalibration::load(): the two calibration text files -> world / camera points (9 doubles each).
+ * 0 = both loaded, -1 = triangle missing/invalid, -2 = points missing/invalid (the reference then uses identity) */
+int ssdo_calibration_load(const char *triangle_path, const char *points_path, double world[9], double cam[9]);
+
 /*
  * Pointcloud::process on one frame of width*height float xyz (AoS).
  * raw_images / closed_images: optional, n_step_plateaus x H x W bytes each (step

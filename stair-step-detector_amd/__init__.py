@@ -107,7 +107,7 @@ class Scene(C.Structure):
 
 
 EXPORTS = [
-    "ssd_default_config", "ssd_calibration_from_points", "ssd_calibration_identity",
+    "ssd_default_config", "ssd_calibration_from_points", "ssd_calibration_identity", "ssd_calibration_load",
     "ssd_create", "ssd_destroy", "ssd_last_error", "ssd_workspace_bytes",
     "ssd_process_host", "ssd_enqueue", "ssd_fetch", "ssd_enqueue_stages",
     "ssd_set_timing", "ssd_get_stage_times", "ssd_get_stage_times_back", "ssd_serialize",
@@ -136,6 +136,8 @@ def lib():
     L.ssd_default_config.argtypes = [C.POINTER(Config), i32, i32]
     L.ssd_calibration_from_points.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(Calibration)]
     L.ssd_calibration_identity.argtypes = [C.POINTER(Calibration)]
+    L.ssd_calibration_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Calibration), C.POINTER(C.c_int),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ssd_create.argtypes = [C.POINTER(Config), C.POINTER(Calibration), i32, C.POINTER(vp)]
     L.ssd_destroy.argtypes = [vp]
     L.ssd_process_host.argtypes = [vp, vp, i32, C.POINTER(FrameResult)]
@@ -194,6 +196,23 @@ class GeometricTransformation:
             w = (C.c_double * 9)(*np.asarray(world_points, dtype=np.float64).reshape(9))
             c = (C.c_double * 9)(*np.asarray(camera_points, dtype=np.float64).reshape(9))
             _check(lib().ssd_calibration_from_points(w, c, C.byref(self.constants)))
+
+
+class GeometricCalibration:
+    """reference geometricCalibration.h:32-37: the offline half."""
+
+    @staticmethod
+    def load(directory="."):
+        """GeometricCalibration::load() (geometricCalibration.cpp:185-203) -> (GeometricTransformation, loaded)."""
+        t = GeometricTransformation()
+        loaded = C.c_int(0)
+        w, c = (C.c_double * 9)(), (C.c_double * 9)()
+        _check(lib().ssd_calibration_load(os.path.join(directory, "calibration-triangle").encode(),
+                                          os.path.join(directory, "calibration-points").encode(),
+                                          C.byref(t.constants), C.byref(loaded), w, c))
+        t.world_points = np.array(w).reshape(3, 3) if loaded.value else None
+        t.camera_points = np.array(c).reshape(3, 3) if loaded.value else None
+        return t, bool(loaded.value)
 
 
 class Stairs:

@@ -5,6 +5,7 @@
  * (ros/stair_step_detector_pkg/.../stair_step_detector.py:32-44).
  *
  *   detect-stairs-amd [--width W] [--height H] [--frames N] [--steps K] [--seed S] [--file frames.f32]
+ *                     [--calibration files]   (GeometricCalibration::load() from the working directory, as detect-stairs.cpp:30)
  */
 #include "stairs_api.h"
 #include <cmath>
@@ -43,6 +44,7 @@ int main(int argc, char **argv)
   int W = 1024, H = 768, frames = 1, K = 3;
   uint64_t seed = 12345;
   const char *file = nullptr;
+  bool calibrationFromFiles = false;
   for(int i = 1; i + 1 < argc; i += 2)
   {
     if(!std::strcmp(argv[i], "--width")) W = std::atoi(argv[i + 1]);
@@ -51,6 +53,7 @@ int main(int argc, char **argv)
     else if(!std::strcmp(argv[i], "--steps")) K = std::atoi(argv[i + 1]);
     else if(!std::strcmp(argv[i], "--seed")) seed = std::strtoull(argv[i + 1], nullptr, 10);
     else if(!std::strcmp(argv[i], "--file")) file = argv[i + 1];
+    else if(!std::strcmp(argv[i], "--calibration")) calibrationFromFiles = !std::strcmp(argv[i + 1], "files");
   }
 
   Window app("stair-step-detector");
@@ -66,8 +69,9 @@ int main(int argc, char **argv)
     wor[i] = Point3{ marks[i][0], marks[i][1], marks[i][2] };
     cam[i] = Point3{ c[0], c[1], c[2] };
   }
-  const GeometricTransformation trans(wor, cam);
-  const Pointcloud pointcloud(app, trans);
+  const GeometricTransformation transSynthetic(wor, cam);
+  const GeometricTransformation transFiles = GeometricCalibration::load();     /* identity when the files are missing */
+  const Pointcloud pointcloud(app, calibrationFromFiles ? transFiles : transSynthetic);
 
   std::vector<float> xyz(static_cast<size_t>(W) * H * 3);
   FILE *fp = file ? std::fopen(file, "rb") : nullptr;

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <string>
 #include <vector>
 
@@ -171,6 +172,124 @@ int ssd_calibration_from_points(const double w[9], const double c[9], ssd_calibr
   if(!std::isfinite(xBaseX) || !std::isfinite(xBaseY))
     return fail(SSD_E_ARG, "ssd_calibration_from_points: coincident reference points");
   return SSD_OK;
+}
+
+/* ---- calibration files -------------------------------------------- */
+extern "C++"
+{
+namespace
+{
+
+/* readValue, calibrationTriangle.cpp:48-68: skip tokens until `name`, expect "=", read the value */
+template<typename T>
+bool read_named_value(std::ifstream &file, const std::string &name, T &value)
+{
+  while(file)
+  {
+    std::string chars;
+    file >> chars;
+    if(chars == name)
+    {
+      std::string sign;
+      file >> sign;
+      if(sign == "=")
+      {
+        file >> value;
+        return static_cast<bool>(file);
+      }
+    }
+  }
+  return false;
+}
+
+/* CalibrationTriangle::load + isValid, calibrationTriangle.cpp:97-125, 148-172 */
+bool load_triangle(const char *path, double w[9])
+{
+  std::ifstream file(path);
+  std::string id;
+  std::getline(file, id);
+  if(id != "calibration triangle")
+    return false;
+  bool r = true;
+  for(int n = 1; n <= 3; n++)
+  {
+    const std::string ns = std::to_string(n);
+    r = r && read_named_value(file, "x" + ns, w[3 * (n - 1)]);
+    r = r && read_named_value(file, "y" + ns, w[3 * (n - 1) + 1]);
+    r = r && read_named_value(file, "z" + ns, w[3 * (n - 1) + 2]);
+  }
+  std::string side;
+  r = r && read_named_value(file, "lowerQuadrant", side);
+  if(!r)
+    return false;
+  const double minDistQu = 0.01 * 0.01;
+  auto distQu = [&](int a, int b)
+  {
+    const double dx = w[3 * b] - w[3 * a], dy = w[3 * b + 1] - w[3 * a + 1], dz = w[3 * b + 2] - w[3 * a + 2];
+    return dx * dx + dy * dy + dz * dz;
+  };
+  if(distQu(0, 1) < minDistQu || distQu(1, 2) < minDistQu || distQu(2, 0) < minDistQu)
+    return false;
+  return side == "left" || side == "right";
+}
+
+/* loadPoints + calcAverageRefPointSet, geometricCalibration.cpp:73-98, 127-141: ten rows of three float
+ * points, summed in double in file order, divided by the count */
+bool load_points(const char *path, double c[9])
+{
+  std::ifstream file(path);
+  std::string id;
+  std::getline(file, id);
+  if(id != "calibration points")
+    return false;
+  const int numIterations = 10;
+  double sum[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+  int n = 0;
+  while(true)
+  {
+    float p[9];
+    char ch;
+    for(int k = 0; k < 3; k++)
+    {
+      file >> p[3 * k] >> ch >> p[3 * k + 1] >> ch >> p[3 * k + 2];
+      if(k < 2)
+        file >> ch;
+    }
+    if(!file)
+      break;
+    for(int k = 0; k < 9; k++)
+      sum[k] += static_cast<double>(p[k]);
+    if(++n == numIterations)
+    {
+      for(int k = 0; k < 9; k++)
+        c[k] = sum[k] / static_cast<double>(static_cast<size_t>(n));
+      return true;
+    }
+  }
+  return false;
+}
+
+} // namespace
+} // extern "C++"
+
+int ssd_calibration_load(const char *triangle_path, const char *points_path, ssd_calibration *out, int *loaded,
+                         double *world_points, double *camera_points)
+{
+  if(!triangle_path || !points_path || !out)
+    return fail(SSD_E_ARG, "ssd_calibration_load: null argument");
+  double w[9], c[9];
+  if(loaded)
+    *loaded = 0;
+  if(load_triangle(triangle_path, w) && load_points(points_path, c))
+  {
+    if(world_points) std::memcpy(world_points, w, sizeof(w));
+    if(camera_points) std::memcpy(camera_points, c, sizeof(c));
+    const int rc = ssd_calibration_from_points(w, c, out);
+    if(rc == SSD_OK && loaded)
+      *loaded = 1;
+    return rc;
+  }
+  return ssd_calibration_identity(out);      /* geometricCalibration.cpp:199-202: log an error, return {} */
 }
 
 int ssd_device_count(void)

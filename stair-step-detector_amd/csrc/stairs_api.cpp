@@ -38,6 +38,15 @@ GeometricTransformation::GeometricTransformation(const RefPoints &w, const RefPo
     throw std::invalid_argument(ssd_last_error());
 }
 
+GeometricTransformation GeometricCalibration::load()
+{
+  ssd_calibration cal;
+  int loaded = 0;
+  ssd_calibration_load("calibration-triangle", "calibration-points", &cal, &loaded, nullptr, nullptr);
+  (void)loaded;      /* the reference logs "calibration points could not be loaded" and carries on with identity (:199-202) */
+  return GeometricTransformation(cal);
+}
+
 Pointcloud::Pointcloud(const Window &window, const GeometricTransformation &trans)
 : _window(window),
   _transformation(trans)

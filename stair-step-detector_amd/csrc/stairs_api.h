@@ -59,11 +59,19 @@ public:
   using RefPoints = std::array<Point3, 3>;
   GeometricTransformation();                                                        /* identity, transformation.h:51-55 */
   GeometricTransformation(const RefPoints &worldPoints, const RefPoints &cameraPoints);
+  explicit GeometricTransformation(const ssd_calibration &constants) : _cal(constants) {}
   const ssd_calibration &constants() const { return _cal; }
 
 private:
   GeometricTransformation(const GeometricTransformation &) = delete;
   ssd_calibration _cal;
+};
+
+/* geometricCalibration.h:32-37: only the offline half (load) is on the path's boundary */
+class GeometricCalibration
+{
+public:
+  static GeometricTransformation load();      /* reads "calibration-triangle" and "calibration-points" from the working directory */
 };
 
 class Pointcloud

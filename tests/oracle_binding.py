@@ -80,6 +80,7 @@ class Oracle:
         lib.ssdo_hypot.restype = C.c_double
         lib.ssdo_hypot.argtypes = [C.c_double, C.c_double]
         lib.ssdo_best_line.argtypes = [vp, i32, vp]
+        lib.ssdo_calibration_load.argtypes = [C.c_char_p, C.c_char_p, vp, vp]
 
     def config(self, width, height):
         cfg = Config()
@@ -92,6 +93,13 @@ class Oracle:
         c = (C.c_double * 9)(*np.asarray(cam, dtype=np.float64).reshape(9))
         rc = self.lib.ssdo_calibration_from_points(w, c, C.byref(cal))
         return rc, cal
+
+    def calibration_load(self, directory):
+        w, c = np.zeros(9), np.zeros(9)
+        rc = self.lib.ssdo_calibration_load(os.path.join(directory, "calibration-triangle").encode(),
+                                            os.path.join(directory, "calibration-points").encode(),
+                                            w.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p))
+        return rc, w.reshape(3, 3), c.reshape(3, 3)
 
     def process(self, cfg, cal, xyz, images=0, ground_images=False):
         """-> (Result, raw_images, closed_images, ground_raw, ground_closed)"""
@@ -152,12 +160,19 @@ class Ref:
         self.lib = lib
         lib.ssdref_serialize.argtypes = [C.c_int, C.c_void_p, C.c_char_p, C.c_int]
         lib.ssdref_quad_test.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        lib.ssdref_load_triangle.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(C.c_int)]
 
     def serialize(self, steps_ext):
         s = np.ascontiguousarray(steps_ext, dtype=np.float64).reshape(-1, 9)
         buf = C.create_string_buffer(LINE_CAP)
         self.lib.ssdref_serialize(len(s), s.ctypes.data_as(C.c_void_p), buf, LINE_CAP)
         return buf.value.decode()
+
+    def load_triangle(self, directory):
+        w = np.zeros(9)
+        side = C.c_int(0)
+        rc = self.lib.ssdref_load_triangle(directory.encode(), w.ctypes.data_as(C.c_void_p), C.byref(side))
+        return rc, w.reshape(3, 3), side.value
 
     def quad_test(self, quad, pts):
         q = np.ascontiguousarray(quad, dtype=np.float64).reshape(8)

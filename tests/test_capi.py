@@ -163,3 +163,72 @@ def test_oracle_runs_the_config1_frame(ssd, oracle):
     assert line.startswith('["stairs",["stairSteps",4],[[["height",0.004],')
     n, steps, status = oracle.process_lean(ob.to_oracle_config(cfg), ob.to_oracle_calibration(t.constants), xyz)
     assert n == 4 and np.array_equal(steps, np.array([list(res.steps_ext[i]) for i in range(4)]))
+
+
+# ------------------------------------------------------------------ calibration files
+REFERENCE_TRIANGLE = """calibration triangle
+x1 = -1.121, y1 = 1.79826, z1 = 0.004
+x2 = 1.121, y2 = 1.79826, z2 = 0.004
+x3 = 0.769229, y3 = 0.3, z3 = 0.004
+lowerQuadrant = right
+"""          # the data file the reference ships (calibration-triangle:1-5)
+
+
+def _write_calibration(tmp_path, ssd, triangle=REFERENCE_TRIANGLE, rows=10, header="calibration points", jitter=1e-3, seed=3):
+    """Writes the two files as the reference's calibrate tool does (geometricCalibration.cpp:43-71:
+    `fixed << setprecision(6) << setw(9) x << ", " << setw(9) y << ", " << setw(8) z`, sets joined by "; ")."""
+    rng = np.random.default_rng(seed)
+    world = np.array([[-1.121, 1.79826, 0.004], [1.121, 1.79826, 0.004], [0.769229, 0.3, 0.004]])
+    sc = ssd.make_scene(640, 480, cam_height=1.3, pitch_deg=42.0)
+    _, cam = ssd.calibration_points(sc, [tuple(w[:2]) + (0.0,) for w in world])
+    (tmp_path / "calibration-triangle").write_text(triangle)
+    lines = [header]
+    sets = []
+    for _ in range(rows):
+        s = cam + rng.normal(0, jitter, cam.shape)
+        sets.append(s)
+        lines.append("; ".join("%9.6f, %9.6f, %8.6f" % tuple(p) for p in s))
+    (tmp_path / "calibration-points").write_text("\n".join(lines) + "\n")
+    return world, np.array(sets)
+
+
+def test_calibration_loader_matches_oracle_and_reference_triangle(ssd, oracle, tmp_path):
+    world, sets = _write_calibration(tmp_path, ssd)
+    t, loaded = ssd.GeometricCalibration.load(str(tmp_path))
+    assert loaded
+    rc, w_o, c_o = oracle.calibration_load(str(tmp_path))
+    assert rc == 0
+    assert np.array_equal(t.world_points, w_o) and np.array_equal(t.camera_points, c_o)
+    assert np.array_equal(t.world_points, world)
+    # mean of the ten point sets as float32 values summed in double (geometricCalibration.cpp:127-141)
+    want = np.float32(np.round(sets, 6)).astype(np.float64).sum(0) / 10.0
+    assert np.allclose(t.camera_points, want, atol=1e-12)
+    rc2, cal = oracle.calibration(w_o, c_o)
+    assert rc2 == 0 and bytes(cal) == bytes(t.constants)
+    import oracle_binding
+    ref = oracle_binding.load_ref()
+    if ref is not None:                       # the real CalibrationTriangle::load / isValid
+        rc3, w_r, side = ref.load_triangle(str(tmp_path))
+        assert rc3 == 0 and side == 2 and np.array_equal(w_r, t.world_points)
+
+
+def test_calibration_loader_falls_back_to_identity_like_the_reference(ssd, oracle, tmp_path):
+    """geometricCalibration.cpp:199-202: missing / short / invalid files -> error message, identity transformation."""
+    ident = bytes(ssd.GeometricTransformation().constants)
+    t, loaded = ssd.GeometricCalibration.load(str(tmp_path))                 # no files at all
+    assert not loaded and bytes(t.constants) == ident
+    _write_calibration(tmp_path, ssd, rows=9)                                # fewer than 10 rows
+    t, loaded = ssd.GeometricCalibration.load(str(tmp_path))
+    assert not loaded and bytes(t.constants) == ident and oracle.calibration_load(str(tmp_path))[0] == -2
+    _write_calibration(tmp_path, ssd, header="calibration pts")              # wrong header
+    assert not ssd.GeometricCalibration.load(str(tmp_path))[1]
+    _write_calibration(tmp_path, ssd, triangle=REFERENCE_TRIANGLE.replace("lowerQuadrant = right", "lowerQuadrant = up"))
+    assert not ssd.GeometricCalibration.load(str(tmp_path))[1] and oracle.calibration_load(str(tmp_path))[0] == -1
+    _write_calibration(tmp_path, ssd, triangle=REFERENCE_TRIANGLE.replace("x2 = 1.121", "x2 = -1.121"))   # coincident corners
+    assert not ssd.GeometricCalibration.load(str(tmp_path))[1]
+    import oracle_binding
+    ref = oracle_binding.load_ref()
+    if ref is not None:
+        assert ref.load_triangle(str(tmp_path))[0] == 2                      # loaded but not valid
+    _write_calibration(tmp_path, ssd)                                        # and a good pair loads again
+    assert ssd.GeometricCalibration.load(str(tmp_path))[1]
