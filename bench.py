@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--workload", choices=["xga_batch", "fhd_stress"], default="xga_batch",
                     help="xga_batch = BASELINE configs[2] (the metric's configuration); fhd_stress = configs[4]")
     ap.add_argument("--cpu-frames", type=int, default=0, help="bounded CPU-baseline sample in frames (default: ~15 s of CPU work)")
+    ap.add_argument("--input", choices=["float3", "depth16"], default="float3",
+                    help="float3 = xyz vertices (the metric's input); depth16 = 16-bit depth frames deprojected on the fly (SURVEY 8f rank 1)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -82,14 +84,25 @@ def main():
         sc_list = scenes.batch_scenes(ssd, W, H, F, base_seed=100000 + lo, rng_seed=1000 + rank)
     trans = ssd.transformation_for_scene(sc_list[0])
     cfg = ssd.default_config(W, H, max_frames_per_batch=F)
+    depth_in = args.input == "depth16"
+    if depth_in:
+        frame_bytes = W * H * 2
     frames = torch.empty(F * frame_bytes, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    ssd.synth_device(sc_list, frames.data_ptr(), device=local_rank, stream=stream)
     det = ssd.Detector(cfg, trans, local_rank)
     det.set_timing(True)
+    intr = ssd.intrinsics_for_scene(sc_list[0])
+    if depth_in:
+        ssd.synth_depth_device(sc_list, frames.data_ptr(), device=local_rank, stream=stream)
+        det.set_intrinsics(intr)
+    else:
+        ssd.synth_device(sc_list, frames.data_ptr(), device=local_rank, stream=stream)
 
     def step():
-        det.enqueue(frames.data_ptr(), F, stream=stream)
+        if depth_in:
+            det.enqueue_depth(frames.data_ptr(), F, stream=stream)
+        else:
+            det.enqueue(frames.data_ptr(), F, stream=stream)
         return det.fetch(F, stream=stream)
 
     for _ in range(args.warmup):
@@ -123,14 +136,16 @@ def main():
     if rank == 0:
         value = world * F * args.steps / dt_max
         k1_ms = stage["hist"]
-        alg_bytes = 12.0 * W * H * F                       # 12 B per raw point, read once
+        alg_bytes = (2.0 if depth_in else 12.0) * W * H * F    # 12 B per raw point (2 B per depth pixel), read once
         achieved = alg_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_k_hist.json")
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch_at_%dx%dx%d" % (W, H, F))
-                if traffic is None and not fhd:     # measured at 1024 frames: scale per frame
+                if depth_in:
+                    traffic = None
+                elif traffic is None and not fhd:     # measured at 1024 frames: scale per frame
                     ref = json.load(open(pmc)).get("hbm_bytes_per_launch_at_1024x768x1024")
                     traffic = None if ref is None else ref * F / 1024.0
             except Exception:
@@ -143,7 +158,7 @@ def main():
                                     if fhd else
                                     "BASELINE configs[2]: batch of %d synthetic %dx%d frames (3-step staircases, randomised rise/"
                                     "tread/yaw/noise) resident in HBM, streamed through the whole per-frame path; per GPU") % (F, W, H),
-                       "frames_per_gpu_per_step": F, "width": W, "height": H, "parallelism": "frame-sharded x%d, no collective" % world},
+                       "frames_per_gpu_per_step": F, "width": W, "height": H, "input": args.input, "parallelism": "frame-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "kernel": "k_hist (K1: transform+crop+bin+histogram)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms},
@@ -164,7 +179,8 @@ def main():
             cdt = 0.0
             checked = 0
             for i in idx:                                   # one frame at a time: download (untimed), oracle (timed)
-                x = frames[i * frame_bytes:(i + 1) * frame_bytes].cpu().numpy().view(np.float32)
+                x = frames[i * frame_bytes:(i + 1) * frame_bytes].cpu().numpy()
+                x = oracle.deproject(intr, x.view(np.uint16).reshape(H, W)) if depth_in else x.view(np.float32)
                 c0 = time.perf_counter()
                 oracle.process_lean(ocfg, ocal, x)
                 cdt += time.perf_counter() - c0

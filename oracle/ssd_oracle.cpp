@@ -1437,6 +1437,23 @@ int ssdo_process_lean(const ssdo_config *cfg, const ssdo_calibration *cal, const
   return processFrame(*cfg, *cal, xyz, true, nullptr, steps_ext, status, nullptr, nullptr, 0, nullptr, nullptr);
 }
 
+void ssdo_deproject(float fx, float fy, float ppx, float ppy, float depth_units, int width, int height,
+                    const uint16_t *depth, float *xyz)
+{
+  for(int v = 0; v < height; v++)
+    for(int u = 0; u < width; u++)
+    {
+      const size_t i = size_t(v) * width + u;
+      const float px = float(u), py = float(v);
+      const float x = (px - ppx) / fx;            /* rs2_deproject_pixel_to_point / pre_compute_x_y_map */
+      const float y = (py - ppy) / fy;
+      const float d = depth_units * float(depth[i]);
+      xyz[3 * i] = d * x;
+      xyz[3 * i + 1] = d * y;
+      xyz[3 * i + 2] = d;
+    }
+}
+
 void ssdo_close3x3(uint8_t *img, int width, int height)
 {
   close3x3(img, width, height);

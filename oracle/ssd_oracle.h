@@ -138,6 +138,12 @@ int ssdo_process(const ssdo_config *cfg, const ssdo_calibration *cal, const floa
 int ssdo_process_lean(const ssdo_config *cfg, const ssdo_calibration *cal, const float *xyz,
                       double *steps_ext /* [SSDO_MAX_STEPS][9] */, int *status);
 
+/* rs2::pointcloud::calculate (pointcloud.cpp:138) for an undistorted depth stream, as librealsense2 2.42.0 computes it
+ * in float (third party, absent from the reference tree: restated from src/proc/pointcloud.cpp + rsutil.h; parity unpinned):
+ * d = raw * depth_units; x = d * ((u - ppx) / fx); y = d * ((v - ppy) / fy); z = d; raw 0 -> (0,0,0) */
+void ssdo_deproject(float fx, float fy, float ppx, float ppy, float depth_units, int width, int height,
+                    const uint16_t *depth, float *xyz);
+
 /* pieces exposed for unit tests */
 void ssdo_close3x3(uint8_t *img, int width, int height);
 int ssdo_serialize(int n_steps, const double *steps_ext /* n x 9 */, char *buf, int cap);

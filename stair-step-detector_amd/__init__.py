@@ -91,6 +91,10 @@ class DebugFrame(C.Structure):
                 ("plateaus", DebugPlateau * MAX_PLATEAUS)]
 
 
+class Intrinsics(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("ppx", C.c_float), ("ppy", C.c_float), ("depth_units", C.c_float)]
+
+
 class Scene(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
@@ -110,6 +114,8 @@ EXPORTS = [
     "ssd_default_config", "ssd_calibration_from_points", "ssd_calibration_identity", "ssd_calibration_load",
     "ssd_create", "ssd_destroy", "ssd_last_error", "ssd_workspace_bytes",
     "ssd_process_host", "ssd_enqueue", "ssd_fetch", "ssd_enqueue_stages",
+    "ssd_set_intrinsics", "ssd_process_depth_host", "ssd_enqueue_depth", "ssd_deproject_host",
+    "ssd_synth_depth_host", "ssd_synth_depth_device",
     "ssd_set_timing", "ssd_get_stage_times", "ssd_get_stage_times_back", "ssd_serialize",
     "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
     "ssd_synth_generate_host", "ssd_synth_generate_device", "ssd_synth_scene_to_camera",
@@ -144,6 +150,12 @@ def lib():
     L.ssd_enqueue.argtypes = [vp, vp, sz, i32, vp]
     L.ssd_enqueue_stages.argtypes = [vp, vp, sz, i32, vp, i32]
     L.ssd_fetch.argtypes = [vp, C.POINTER(FrameResult), i32, vp]
+    L.ssd_set_intrinsics.argtypes = [vp, C.POINTER(Intrinsics)]
+    L.ssd_process_depth_host.argtypes = [vp, vp, i32, C.POINTER(FrameResult)]
+    L.ssd_enqueue_depth.argtypes = [vp, vp, sz, i32, vp]
+    L.ssd_deproject_host.argtypes = [C.POINTER(Intrinsics), i32, i32, vp, vp]
+    L.ssd_synth_depth_host.argtypes = [C.POINTER(Scene), i32, C.c_float, vp]
+    L.ssd_synth_depth_device.argtypes = [C.POINTER(Scene), i32, C.c_float, vp, sz, i32, vp]
     L.ssd_set_timing.argtypes = [vp, i32]
     L.ssd_get_stage_times.argtypes = [vp, C.POINTER(C.c_float)]
     L.ssd_get_stage_times_back.argtypes = [vp, i32, C.POINTER(C.c_float)]
@@ -273,6 +285,21 @@ class Detector:
         _check(lib().ssd_process_host(self._h, a.ctypes.data_as(C.c_void_p), n, res))
         return list(res)
 
+    def set_intrinsics(self, intr):
+        _check(lib().ssd_set_intrinsics(self._h, C.byref(intr)))
+
+    def process_depth_host(self, depth):
+        """depth: uint16 array [n, H, W] (or [H, W]) on the host -> list of FrameResult."""
+        a = np.ascontiguousarray(depth, dtype=np.uint16)
+        n = a.size // (self.cfg.width * self.cfg.height)
+        res = (FrameResult * n)()
+        _check(lib().ssd_process_depth_host(self._h, a.ctypes.data_as(C.c_void_p), n, res))
+        return list(res)
+
+    def enqueue_depth(self, d_ptr, nframes, stride_bytes=None, stream=None):
+        _check(lib().ssd_enqueue_depth(self._h, C.c_void_p(d_ptr), stride_bytes or self.cfg.width * self.cfg.height * 2, nframes,
+                                       C.c_void_p(stream or 0)))
+
     def enqueue(self, d_ptr, nframes, stride_bytes=None, stream=None, stages=STAGE_ALL):
         _check(lib().ssd_enqueue_stages(self._h, C.c_void_p(d_ptr), stride_bytes or self.frame_bytes, nframes,
                                         C.c_void_p(stream or 0), stages))
@@ -370,6 +397,35 @@ def synth_host(scenes):
     h, w = scenes[0].height, scenes[0].width
     out = np.empty((len(scenes), h, w, 3), dtype=np.float32)
     _check(lib().ssd_synth_generate_host(arr, len(scenes), out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def intrinsics_for_scene(scene, depth_units=0.00025):
+    """rs2_intrinsics of the synthetic camera (L515 depth unit: 0.25 mm)."""
+    i = Intrinsics()
+    i.fx, i.fy, i.ppx, i.ppy, i.depth_units = scene.fx, scene.fy, scene.cx, scene.cy, depth_units
+    return i
+
+
+def synth_depth_host(scenes, depth_units=0.00025):
+    """-> uint16 [n, H, W]: the scenes as 16-bit depth frames; host, bit-identical to the device generator."""
+    arr = scene_array(scenes)
+    out = np.empty((len(scenes), scenes[0].height, scenes[0].width), dtype=np.uint16)
+    _check(lib().ssd_synth_depth_host(arr, len(scenes), depth_units, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def synth_depth_device(scenes, d_ptr, depth_units=0.00025, stride_bytes=None, device=0, stream=None):
+    arr = scene_array(scenes)
+    stride = stride_bytes or scenes[0].width * scenes[0].height * 2
+    _check(lib().ssd_synth_depth_device(arr, len(scenes), depth_units, C.c_void_p(d_ptr), stride, device, C.c_void_p(stream or 0)))
+
+
+def deproject_host(intr, depth):
+    """rs2::pointcloud::calculate restated (host): uint16 [H, W] -> float32 [H, W, 3]."""
+    a = np.ascontiguousarray(depth, dtype=np.uint16)
+    out = np.empty(a.shape + (3,), dtype=np.float32)
+    _check(lib().ssd_deproject_host(C.byref(intr), a.shape[1], a.shape[0], a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
     return out
 
 

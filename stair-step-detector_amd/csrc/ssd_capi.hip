@@ -57,6 +57,9 @@ struct ssd_handle
   unsigned long long *dGroundImg = nullptr;
   unsigned int *dTileMasks = nullptr;       /* per wave tile (256 points): which groups of 4 height bins occur; K1 -> K2, K4 */
   size_t tileMaskStride = 0;
+  float *dDepthMaps = nullptr;              /* xmap[W] then ymap[H] (ssd_set_intrinsics) */
+  ssd_intrinsics intr{};
+  bool haveIntr = false;
   ssd_frame_result *dResults = nullptr;
   ssd_frame_result *hResults = nullptr;     /* pinned */
   float *dFrames = nullptr;                 /* staging for ssd_process_host */
@@ -406,6 +409,7 @@ int ssd_destroy(ssd_handle *h)
   if(h->dStepImg) (void)hipFree(h->dStepImg);
   if(h->dGroundImg) (void)hipFree(h->dGroundImg);
   if(h->dTileMasks) (void)hipFree(h->dTileMasks);
+  if(h->dDepthMaps) (void)hipFree(h->dDepthMaps);
   if(h->dResults) (void)hipFree(h->dResults);
   if(h->hResults) (void)hipHostFree(h->hResults);
   if(h->dFrames) (void)hipFree(h->dFrames);
@@ -474,22 +478,34 @@ static int choose_chunk(int nPoints, int nframes)
   return chunk;
 }
 
-int ssd_enqueue_stages(ssd_handle *h, const void *d_xyz, size_t frame_stride_bytes, int nframes, void *stream, int stages)
+static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_bytes, int nframes, void *stream, int stages, bool depthInput)
 {
   if(!h || !d_xyz)
     return fail(SSD_E_ARG, "ssd_enqueue: null argument");
   if(nframes < 1 || nframes > h->F)
     return fail(SSD_E_ARG, "ssd_enqueue: nframes must be 1..max_frames_per_batch");
-  const size_t frameBytes = static_cast<size_t>(h->P.nPoints) * 12;
-  if(frame_stride_bytes < frameBytes || frame_stride_bytes % 4 != 0)
-    return fail(SSD_E_ARG, "ssd_enqueue: frame stride smaller than a frame or not a multiple of 4");
-  if((reinterpret_cast<uintptr_t>(d_xyz) & 3u) != 0)
-    return fail(SSD_E_ARG, "ssd_enqueue: frame pointer must be 4-byte aligned");
+  const size_t frameBytes = static_cast<size_t>(h->P.nPoints) * (depthInput ? 2 : 12);
+  if(depthInput)
+  {
+    if(!h->haveIntr)
+      return fail(SSD_E_ARG, "ssd_enqueue_depth: call ssd_set_intrinsics first");
+    if(frame_stride_bytes < frameBytes || frame_stride_bytes % 8 != 0 || (reinterpret_cast<uintptr_t>(d_xyz) & 7u) != 0 || h->P.W % 4 != 0)
+      return fail(SSD_E_ARG, "ssd_enqueue_depth: frames must be 8-byte aligned, stride a multiple of 8, width a multiple of 4");
+  }
+  else
+  {
+    if(frame_stride_bytes < frameBytes || frame_stride_bytes % 4 != 0)
+      return fail(SSD_E_ARG, "ssd_enqueue: frame stride smaller than a frame or not a multiple of 4");
+    if((reinterpret_cast<uintptr_t>(d_xyz) & 3u) != 0)
+      return fail(SSD_E_ARG, "ssd_enqueue: frame pointer must be 4-byte aligned");
+  }
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const Params &P = h->P;
   const float *xyz = static_cast<const float *>(d_xyz);
-  const size_t strideFloats = frame_stride_bytes / 4;
+  const size_t strideFloats = depthInput ? frame_stride_bytes / 2 : frame_stride_bytes / 4;    /* elements of the source type */
+  const DepthSrc depthSrc{ h->dDepthMaps, h->dDepthMaps ? h->dDepthMaps + P.W : nullptr, h->intr.depth_units, P.W };
+  const DepthSrc *depth = depthInput ? &depthSrc : nullptr;
   const int chunk = choose_chunk(P.nPoints, nframes);
   DebugFrame *dbg = h->debug ? h->dDebug : nullptr;
   unsigned long long *dbgImg = h->debug ? h->dDebugImg : nullptr;
@@ -511,13 +527,13 @@ int ssd_enqueue_stages(ssd_handle *h, const void *d_xyz, size_t frame_stride_byt
   }
   mark();
   if(stages & SSD_STAGE_HIST)
-    launch_hist(xyz, strideFloats, P, h->dState, h->dTileMasks, h->tileMaskStride, nframes, chunk, s);
+    launch_hist(xyz, strideFloats, P, h->dState, h->dTileMasks, h->tileMaskStride, nframes, chunk, depth, s);
   mark();
   if(stages & SSD_STAGE_PEAKS)
     launch_peaks(P, h->dState, nframes, dbg, s);
   mark();
   if(stages & SSD_STAGE_RASTER)
-    launch_raster(xyz, strideFloats, P, h->dState, h->dStepImg, h->dTileMasks, h->tileMaskStride, nframes, chunk, s);
+    launch_raster(xyz, strideFloats, P, h->dState, h->dStepImg, h->dTileMasks, h->tileMaskStride, nframes, chunk, depth, s);
   mark();
   if(stages & SSD_STAGE_OUTLINE)
     launch_outline(P, h->dState, h->dStepImg, nframes, dbg, dbgImg, s);
@@ -526,7 +542,7 @@ int ssd_enqueue_stages(ssd_handle *h, const void *d_xyz, size_t frame_stride_byt
     launch_quads(P, h->dState, nframes, dbg, s);
   mark();
   if(stages & SSD_STAGE_INQUAD)
-    launch_inquad(xyz, strideFloats, P, h->dState, h->dGroundImg, h->dTileMasks, h->tileMaskStride, nframes, chunk, s);
+    launch_inquad(xyz, strideFloats, P, h->dState, h->dGroundImg, h->dTileMasks, h->tileMaskStride, nframes, chunk, depth, s);
   mark();
   if(stages & SSD_STAGE_FINAL)
     launch_final(P, h->dState, h->dGroundImg, h->dResults, nframes, dbg, dbgImg, s);
@@ -540,9 +556,93 @@ int ssd_enqueue_stages(ssd_handle *h, const void *d_xyz, size_t frame_stride_byt
   return SSD_OK;
 }
 
+int ssd_enqueue_stages(ssd_handle *h, const void *d_xyz, size_t frame_stride_bytes, int nframes, void *stream, int stages)
+{
+  return enqueue_impl(h, d_xyz, frame_stride_bytes, nframes, stream, stages, false);
+}
+
 int ssd_enqueue(ssd_handle *h, const void *d_xyz, size_t frame_stride_bytes, int nframes, void *stream)
 {
-  return ssd_enqueue_stages(h, d_xyz, frame_stride_bytes, nframes, stream, SSD_STAGE_ALL);
+  return enqueue_impl(h, d_xyz, frame_stride_bytes, nframes, stream, SSD_STAGE_ALL, false);
+}
+
+int ssd_enqueue_depth(ssd_handle *h, const void *d_depth, size_t frame_stride_bytes, int nframes, void *stream)
+{
+  return enqueue_impl(h, d_depth, frame_stride_bytes, nframes, stream, SSD_STAGE_ALL, true);
+}
+
+/* rs2::pointcloud's maps (librealsense2 src/proc/pointcloud.cpp, pre_compute_x_y_map), float arithmetic */
+static void depth_maps(const ssd_intrinsics &in, int W, int H, std::vector<float> &maps)
+{
+  maps.resize(static_cast<size_t>(W) + H);
+  for(int u = 0; u < W; u++)
+    maps[u] = (static_cast<float>(u) - in.ppx) / in.fx;
+  for(int v = 0; v < H; v++)
+    maps[W + v] = (static_cast<float>(v) - in.ppy) / in.fy;
+}
+
+int ssd_set_intrinsics(ssd_handle *h, const ssd_intrinsics *intr)
+{
+  if(!h || !intr || !(intr->fx != 0.0f) || !(intr->fy != 0.0f) || !(intr->depth_units > 0.0f))
+    return fail(SSD_E_ARG, "ssd_set_intrinsics: bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  std::vector<float> maps;
+  depth_maps(*intr, h->P.W, h->P.H, maps);
+  if(!h->dDepthMaps)
+    HIP_TRY(hipMalloc(&h->dDepthMaps, maps.size() * 4));
+  HIP_TRY(hipMemcpy(h->dDepthMaps, maps.data(), maps.size() * 4, hipMemcpyHostToDevice));
+  h->intr = *intr;
+  h->haveIntr = true;
+  return SSD_OK;
+}
+
+int ssd_deproject_host(const ssd_intrinsics *intr, int width, int height, const uint16_t *depth, float *xyz)
+{
+  if(!intr || !depth || !xyz || width <= 0 || height <= 0)
+    return fail(SSD_E_ARG, "ssd_deproject_host: bad argument");
+  std::vector<float> maps;
+  depth_maps(*intr, width, height, maps);
+  for(int v = 0; v < height; v++)
+    for(int u = 0; u < width; u++)
+    {
+      const size_t i = static_cast<size_t>(v) * width + u;
+      const float d = static_cast<float>(depth[i]) * intr->depth_units;
+      xyz[3 * i] = d * maps[u];
+      xyz[3 * i + 1] = d * maps[width + v];
+      xyz[3 * i + 2] = d;
+    }
+  return SSD_OK;
+}
+
+int ssd_process_depth_host(ssd_handle *h, const uint16_t *depth, int nframes, ssd_frame_result *results)
+{
+  if(!h || !depth || !results || nframes < 1)
+    return fail(SSD_E_ARG, "ssd_process_depth_host: bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t frameElems = (static_cast<size_t>(h->P.nPoints) + 3) / 4 * 4;       /* stride kept a multiple of 8 bytes */
+  const size_t needFloats = (static_cast<size_t>(nframes < h->F ? nframes : h->F) * frameElems * 2 + 3) / 4;
+  const size_t frameFloats = static_cast<size_t>(h->P.nPoints) * 3;
+  if(h->dFramesCap * frameFloats < needFloats)
+  {
+    if(h->dFrames) (void)hipFree(h->dFrames);
+    h->dFrames = nullptr;
+    h->dFramesCap = 0;
+    const size_t frames = (needFloats + frameFloats - 1) / frameFloats;
+    HIP_TRY(hipMalloc(&h->dFrames, frames * frameFloats * 4));
+    h->dFramesCap = frames;
+  }
+  for(int done = 0; done < nframes; )
+  {
+    const int n = nframes - done < h->F ? nframes - done : h->F;
+    HIP_TRY(hipMemcpy2DAsync(h->dFrames, frameElems * 2, depth + static_cast<size_t>(done) * h->P.nPoints, static_cast<size_t>(h->P.nPoints) * 2,
+                             static_cast<size_t>(h->P.nPoints) * 2, n, hipMemcpyHostToDevice, nullptr));
+    int rc = ssd_enqueue_depth(h, h->dFrames, frameElems * 2, n, nullptr);
+    if(rc) return rc;
+    rc = ssd_fetch(h, results + done, n, nullptr);
+    if(rc) return rc;
+    done += n;
+  }
+  return SSD_OK;
 }
 
 /* milliseconds of the 7 stages of a timed enqueue; `back` = 0 is the last one, 1 the one before, ...
@@ -744,6 +844,53 @@ int ssd_synth_generate_device(const ssd_scene *scenes, int nframes, void *d_xyz,
   (void)hipFree(dScenes);
   if(e != hipSuccess)
     return fail(SSD_E_HIP, std::string("ssd_synth_generate_device: ") + hipGetErrorString(e));
+  return SSD_OK;
+}
+
+int ssd_synth_depth_host(const ssd_scene *scenes, int nframes, float depth_units, uint16_t *depth)
+{
+  if(!scenes || !depth || nframes < 1 || !(depth_units > 0.0f))
+    return fail(SSD_E_ARG, "ssd_synth_depth_host: bad argument");
+  size_t off = 0;
+  for(int f = 0; f < nframes; f++)
+  {
+    const ssd_scene &s = scenes[f];
+    const uint64_t key = synth_frame_key(s);
+    for(int v = 0; v < s.height; v++)
+      for(int u = 0; u < s.width; u++)
+        depth[off++] = synth_depth_raw(s, key, u, v, depth_units);
+  }
+  return SSD_OK;
+}
+
+int ssd_synth_depth_device(const ssd_scene *scenes, int nframes, float depth_units, void *d_depth, size_t frame_stride_bytes,
+                           int device, void *stream)
+{
+  if(!scenes || !d_depth || nframes < 1 || nframes > 65535 || !(depth_units > 0.0f))
+    return fail(SSD_E_ARG, "ssd_synth_depth_device: bad argument");
+  const int nPoints = scenes[0].width * scenes[0].height;
+  for(int f = 0; f < nframes; f++)
+    if(scenes[f].width != scenes[0].width || scenes[f].height != scenes[0].height)
+      return fail(SSD_E_ARG, "ssd_synth_depth_device: all scenes of a batch must share one resolution");
+  if(frame_stride_bytes < static_cast<size_t>(nPoints) * 2 || frame_stride_bytes % 2)
+    return fail(SSD_E_ARG, "ssd_synth_depth_device: bad stride");
+  if(ssd_device_count() <= 0)
+    return fail(SSD_E_NODEVICE, "ssd_synth_depth_device: no HIP device");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ssd_scene *dScenes = nullptr;
+  HIP_TRY(hipMalloc(&dScenes, sizeof(ssd_scene) * nframes));
+  hipError_t e = hipMemcpyAsync(dScenes, scenes, sizeof(ssd_scene) * nframes, hipMemcpyHostToDevice, s);
+  if(e == hipSuccess)
+  {
+    launch_synth_depth(dScenes, static_cast<unsigned short *>(d_depth), frame_stride_bytes / 2, depth_units, nframes, nPoints, s);
+    e = hipGetLastError();
+  }
+  if(e == hipSuccess)
+    e = hipStreamSynchronize(s);
+  (void)hipFree(dScenes);
+  if(e != hipSuccess)
+    return fail(SSD_E_HIP, std::string("ssd_synth_depth_device: ") + hipGetErrorString(e));
   return SSD_OK;
 }
 

@@ -45,6 +45,15 @@ struct PixelParams
   int maxStepImages;
 };
 
+/* what the 16-bit depth source needs beside the depth image: rs2::pointcloud's pre-computed maps
+ * x = (u - ppx) / fx, y = (v - ppy) / fy (L515: no distortion, so they depend on one coordinate each) */
+struct DepthSrc
+{
+  const float *xmap, *ymap;
+  float depthUnits;
+  int W;
+};
+
 /* all constants of one handle */
 struct Params
 {

@@ -78,14 +78,48 @@ constexpr int kPts = 4;                 /* points per thread per iteration: four
 constexpr int kTile = kThreads * kPts;  /* 1024 points per block iteration */
 constexpr int kHistCopies = 32;         /* LDS histogram privatised by lane & 31: bank = copy, no conflicts */
 
-/* Four consecutive points of one lane.  ALIGNED: three 16-byte loads (lanes 48 B apart; the three
+/* Point sources of the streaming kernels */
+constexpr int kSrcF3 = 0;          /* float xyz, 12-byte loads (unaligned frames, or a point count not divisible by 4) */
+constexpr int kSrcF3Aligned = 1;   /* float xyz, 16-byte loads */
+constexpr int kSrcDepth16 = 2;     /* 16-bit depth image + intrinsics: deprojected on the fly */
+
+/* Four consecutive points of one lane.  kSrcF3Aligned: three 16-byte loads (lanes 48 B apart; the three
  * instructions of a wave together cover 3 KiB contiguously — measured 6.2-6.3 TB/s on MI355X, the same as
- * a plain float4 stream, tools/loadbench.hip).  Otherwise (frame base/stride not 16-byte aligned, or the
- * tail of a frame whose point count is not a multiple of 4): 12-byte loads. */
-template<bool ALIGNED>
-__device__ __forceinline__ void load_points(const float *__restrict__ base, int idx0, int end, F3 (&v)[kPts])
+ * a plain float4 stream, tools/loadbench.hip).  kSrcF3 (frame base/stride not 16-byte aligned, or the
+ * tail of a frame whose point count is not a multiple of 4): 12-byte loads.  kSrcDepth16: four 16-bit depth
+ * values (one 8-byte load) turned into points exactly as librealsense's pointcloud block does in float:
+ * d = raw * depth_units; point = (d * xmap[u], d * ymap[v], d); raw = 0 gives the invalid point (0,0,0). */
+template<int SRC>
+__device__ __forceinline__ void load_points(const float *__restrict__ base, int idx0, int end, F3 (&v)[kPts], const DepthSrc &D)
 {
-  if(ALIGNED && idx0 + kPts <= end)
+  if(SRC == kSrcDepth16)
+  {
+    const unsigned short *depth = reinterpret_cast<const unsigned short *>(base);
+    unsigned short raw[kPts] = { 0, 0, 0, 0 };
+    if(idx0 + kPts <= end)
+    {
+      const ushort4 q = *reinterpret_cast<const ushort4 *>(depth + idx0);
+      raw[0] = q.x; raw[1] = q.y; raw[2] = q.z; raw[3] = q.w;
+    }
+    else
+    {
+#pragma unroll
+      for(int j = 0; j < kPts; j++)
+        if(idx0 + j < end)
+          raw[j] = depth[idx0 + j];
+    }
+    const int row = idx0 / D.W, col = idx0 - row * D.W;      /* W % 4 == 0: the four points share the row */
+    const float ym = D.ymap[min(row, 0x7fffffff)];
+#pragma unroll
+    for(int j = 0; j < kPts; j++)
+    {
+      const float d = static_cast<float>(raw[j]) * D.depthUnits;
+      const float xm = D.xmap[col + j < D.W ? col + j : 0];
+      v[j] = F3{ d * xm, d * ym, d };
+    }
+    return;
+  }
+  if(SRC == kSrcF3Aligned && idx0 + kPts <= end)
   {
     const float4 *q = reinterpret_cast<const float4 *>(base + 3 * static_cast<size_t>(idx0));
     const float4 a = q[0], b = q[1], c = q[2];
@@ -111,11 +145,11 @@ __device__ __forceinline__ void load_points(const float *__restrict__ base, int 
 #define SSD_STREAM_LOOP(...)                                                                        \
   {                                                                                                 \
     F3 v[kPts], vn[kPts];                                                                           \
-    load_points<ALIGNED>(base, begin + kPts * tid, end, v);                                         \
+    load_points<SRC>(base, begin + kPts * tid, end, v, D);                                         \
     for(int i0 = begin; i0 < end; i0 += kTile)                                                      \
     {                                                                                               \
       if(i0 + kTile < end)                                                                          \
-        load_points<ALIGNED>(base, i0 + kTile + kPts * tid, end, vn);                               \
+        load_points<SRC>(base, i0 + kTile + kPts * tid, end, vn, D);                               \
       __VA_ARGS__                                                                                   \
       _Pragma("unroll") for(int j = 0; j < kPts; j++) v[j] = vn[j];                                 \
     }                                                                                               \
@@ -138,10 +172,10 @@ __device__ __forceinline__ unsigned int wave_or_u32(unsigned int v)
   return v;
 }
 
-template<bool ALIGNED>
+template<int SRC>
 __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                    FrameState *__restrict__ st, unsigned int *__restrict__ tileMasks,
-                                                   size_t tileMaskStride, int chunkPoints)
+                                                   size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
   constexpr int kMaxTilesPerBlock = 256;            /* chunkPoints <= 256 * 1024 (choose_chunk) */
   __shared__ unsigned int lMasks[kMaxTilesPerBlock * kWavesPerBlock];
@@ -152,7 +186,10 @@ __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int frame = blockIdx.x;                /* frame on the fast grid axis: see launch note on XCD balance */
-  const float *base = xyz + static_cast<size_t>(frame) * strideFloats;
+  /* strideFloats counts floats, or 16-bit depth values for kSrcDepth16 */
+  const float *base = SRC == kSrcDepth16
+    ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(xyz) + static_cast<size_t>(frame) * strideFloats)
+    : xyz + static_cast<size_t>(frame) * strideFloats;
   const int begin = blockIdx.y * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
 
@@ -527,11 +564,11 @@ __device__ __forceinline__ bool image_pixel(const PointParams &P, const PixelPar
   return ix >= 0 && ix < X.W && iy >= 0 && iy < X.H;
 }
 
-template<bool ALIGNED>
+template<int SRC>
 __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                         PixelParams X, FrameState *__restrict__ st,
                                                         unsigned long long *__restrict__ stepImg,
-                                                        const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints)
+                                                        const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
   __shared__ unsigned long long wins[kThreads / 64][kWinWords];
   __shared__ ImageBox boxes[kMaxStepImages];
@@ -555,7 +592,10 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
     (&wins[0][0])[i] = 0ull;
   __syncthreads();
 
-  const float *base = xyz + static_cast<size_t>(frame) * strideFloats;
+  /* strideFloats counts floats, or 16-bit depth values for kSrcDepth16 */
+  const float *base = SRC == kSrcDepth16
+    ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(xyz) + static_cast<size_t>(frame) * strideFloats)
+    : xyz + static_cast<size_t>(frame) * strideFloats;
   const int begin = blockIdx.y * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
   const unsigned int *masks = tileMasks + static_cast<size_t>(frame) * tileMaskStride + (tid >> 6);
@@ -573,7 +613,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
     if(!(masks[static_cast<size_t>(i0 / kTile) * kWavesPerBlock] & wanted))
       continue;
     F3 v[kPts];
-    load_points<ALIGNED>(base, i0 + kPts * tid, end, v);
+    load_points<SRC>(base, i0 + kPts * tid, end, v, D);
     /* the lane's four neighbouring pixels usually share one 64-bit word: merge them before touching LDS */
     MissInfo mi;
     int pSlot = -1;
@@ -1613,11 +1653,11 @@ __device__ __forceinline__ long long z_to_fixed(double z)
   return __double_as_longlong(z + magic) - __double_as_longlong(magic);
 }
 
-template<bool ALIGNED>
+template<int SRC>
 __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                         PixelParams X, FrameState *__restrict__ st,
                                                         unsigned long long *__restrict__ groundImg,
-                                                        const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints)
+                                                        const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
   __shared__ unsigned long long wins[kThreads / 64][kWinWords];
   __shared__ ImageBox box[1];
@@ -1662,7 +1702,10 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
   __syncthreads();
 
   const int groundInd = fs.groundInd;
-  const float *base = xyz + static_cast<size_t>(frame) * strideFloats;
+  /* strideFloats counts floats, or 16-bit depth values for kSrcDepth16 */
+  const float *base = SRC == kSrcDepth16
+    ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(xyz) + static_cast<size_t>(frame) * strideFloats)
+    : xyz + static_cast<size_t>(frame) * strideFloats;
   const int begin = blockIdx.y * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
   unsigned long long *gimg = groundImg + static_cast<size_t>(frame) * X.H * X.W64;
@@ -1695,7 +1738,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
     if(!(masks[static_cast<size_t>(i0 / kTile) * kWavesPerBlock] & wanted))
       continue;
     F3 v[kPts];
-    load_points<ALIGNED>(base, i0 + kPts * tid, end, v);
+    load_points<SRC>(base, i0 + kPts * tid, end, v, D);
     MissInfo mi;
     int pY = -1;
     int pXw = 0;
@@ -2046,6 +2089,22 @@ __global__ __launch_bounds__(kThreads) void k_synth(const ssd_scene *__restrict_
   }
 }
 
+/* synthetic 16-bit depth frames: the same scenes, depth quantised to depth_units as the sensor reports it */
+__global__ __launch_bounds__(kThreads) void k_synth_depth(const ssd_scene *__restrict__ scenes, unsigned short *__restrict__ depth,
+                                                          size_t strideElems, float depthUnits)
+{
+  const int frame = blockIdx.y;
+  const ssd_scene s = scenes[frame];
+  const int n = s.width * s.height;
+  const uint64_t key = synth_frame_key(s);
+  unsigned short *out = depth + static_cast<size_t>(frame) * strideElems;
+  for(int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
+  {
+    const int v = i / s.width, u = i - v * s.width;
+    out[i] = synth_depth_raw(s, key, u, v, depthUnits);
+  }
+}
+
 /* test hook: hypot_ref on the device */
 __global__ void k_hypot(const double *a, const double *b, double *out, int n)
 {
@@ -2077,26 +2136,30 @@ static inline bool aligned16(const float *xyz, size_t strideFloats, int nPoints)
 }
 
 void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned int *tileMasks, size_t tileMaskStride,
-                 int nframes, int chunkPoints, hipStream_t s)
+                 int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
-  if(aligned16(xyz, strideFloats, P.nPoints))
-    hipLaunchKernelGGL(k_hist<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, tileMasks, tileMaskStride, chunkPoints);
+  if(depth)
+    hipLaunchKernelGGL(k_hist<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, tileMasks, tileMaskStride, chunkPoints, *depth);
+  else if(aligned16(xyz, strideFloats, P.nPoints))
+    hipLaunchKernelGGL(k_hist<kSrcF3Aligned>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
   else
-    hipLaunchKernelGGL(k_hist<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, tileMasks, tileMaskStride, chunkPoints);
+    hipLaunchKernelGGL(k_hist<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
 }
 void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s)
 {
   hipLaunchKernelGGL(k_peaks, dim3((nframes + 63) / 64), dim3(64), 0, s, P, st, nframes, dbg);
 }
 void launch_raster(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *stepImg,
-                   const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, hipStream_t s)
+                   const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
-  if(aligned16(xyz, strideFloats, P.nPoints))
-    hipLaunchKernelGGL(k_raster<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints);
+  if(depth)
+    hipLaunchKernelGGL(k_raster<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints, *depth);
+  else if(aligned16(xyz, strideFloats, P.nPoints))
+    hipLaunchKernelGGL(k_raster<kSrcF3Aligned>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
   else
-    hipLaunchKernelGGL(k_raster<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints);
+    hipLaunchKernelGGL(k_raster<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
 }
 void launch_outline(const Params &P, FrameState *st, unsigned long long *stepImg, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
 {
@@ -2108,13 +2171,15 @@ void launch_quads(const Params &P, FrameState *st, int nframes, DebugFrame *dbg,
   hipLaunchKernelGGL(k_quads, dim3((nframes + 63) / 64), dim3(64), 0, s, P, st, nframes, dbg);
 }
 void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *groundImg,
-                   const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, hipStream_t s)
+                   const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
-  if(aligned16(xyz, strideFloats, P.nPoints))
-    hipLaunchKernelGGL(k_inquad<true>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, groundImg, tileMasks, tileMaskStride, chunkPoints);
+  if(depth)
+    hipLaunchKernelGGL(k_inquad<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, groundImg, tileMasks, tileMaskStride, chunkPoints, *depth);
+  else if(aligned16(xyz, strideFloats, P.nPoints))
+    hipLaunchKernelGGL(k_inquad<kSrcF3Aligned>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, groundImg, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
   else
-    hipLaunchKernelGGL(k_inquad<false>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, groundImg, tileMasks, tileMaskStride, chunkPoints);
+    hipLaunchKernelGGL(k_inquad<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, groundImg, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
 }
 void launch_final(const Params &P, FrameState *st, unsigned long long *groundImg, ssd_frame_result *results, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
 {
@@ -2126,6 +2191,13 @@ void launch_synth(const ssd_scene *dScenes, float *xyz, size_t strideFloats, int
   if(bx > 2048) bx = 2048;
   if(bx < 1) bx = 1;
   hipLaunchKernelGGL(k_synth, dim3(bx, nframes), dim3(kThreads), 0, s, dScenes, xyz, strideFloats);
+}
+void launch_synth_depth(const ssd_scene *dScenes, unsigned short *depth, size_t strideElems, float depthUnits, int nframes, int nPoints, hipStream_t s)
+{
+  int bx = (nPoints + kThreads * 4 - 1) / (kThreads * 4);
+  if(bx > 2048) bx = 2048;
+  if(bx < 1) bx = 1;
+  hipLaunchKernelGGL(k_synth_depth, dim3(bx, nframes), dim3(kThreads), 0, s, dScenes, depth, strideElems, depthUnits);
 }
 void launch_hypot(const double *a, const double *b, double *out, int n, hipStream_t s)
 {

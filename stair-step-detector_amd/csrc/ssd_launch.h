@@ -10,16 +10,17 @@ constexpr int kTileHost = 1024;
 constexpr int kMaxTilesPerBlockHost = 256;  /* K1 keeps one mask per wave tile of its chunk in LDS */   /* = kThreads * kPts of ssd_kernels.hip: chunk sizes are multiples of it */
 
 void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned int *tileMasks, size_t tileMaskStride,
-                 int nframes, int chunkPoints, hipStream_t s);
+                 int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s);
 void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s);
 void launch_raster(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *stepImg,
-                   const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, hipStream_t s);
+                   const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s);
 void launch_outline(const Params &P, FrameState *st, unsigned long long *stepImg, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s);
 void launch_quads(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s);
 void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *groundImg,
-                   const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, hipStream_t s);
+                   const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s);
 void launch_final(const Params &P, FrameState *st, unsigned long long *groundImg, ssd_frame_result *results, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s);
 void launch_synth(const ssd_scene *dScenes, float *xyz, size_t strideFloats, int nframes, int nPoints, hipStream_t s);
+void launch_synth_depth(const ssd_scene *dScenes, unsigned short *depth, size_t strideElems, float depthUnits, int nframes, int nPoints, hipStream_t s);
 void launch_hypot(const double *a, const double *b, double *out, int n, hipStream_t s);
 double hypot_ref_host(double a, double b);
 }

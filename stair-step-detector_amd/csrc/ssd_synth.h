@@ -126,6 +126,17 @@ __host__ __device__ inline void synth_pixel(const ssd_scene &s, uint64_t frame_k
   out[2] = float(z);
 }
 
+/* the same pixel as the sensor would report it: camera depth z in units of depth_units, 0 = invalid */
+__host__ __device__ inline unsigned short synth_depth_raw(const ssd_scene &s, uint64_t frame_key, int u, int v, float depthUnits)
+{
+  float p[3];
+  synth_pixel(s, frame_key, u, v, p);
+  if(!(p[2] > 0.0f))
+    return 0;
+  const float q = p[2] / depthUnits + 0.5f;
+  return q >= 65535.0f ? static_cast<unsigned short>(65535) : static_cast<unsigned short>(static_cast<int>(q));
+}
+
 __host__ __device__ inline uint64_t synth_frame_key(const ssd_scene &s)
 {
   return synth_mix(s.seed * 0x2545F4914F6CDD1Dull + 0x632BE59BD9B4E019ull);

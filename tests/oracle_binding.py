@@ -81,6 +81,7 @@ class Oracle:
         lib.ssdo_hypot.argtypes = [C.c_double, C.c_double]
         lib.ssdo_best_line.argtypes = [vp, i32, vp]
         lib.ssdo_calibration_load.argtypes = [C.c_char_p, C.c_char_p, vp, vp]
+        lib.ssdo_deproject.argtypes = [C.c_float] * 5 + [i32, i32, vp, vp]
 
     def config(self, width, height):
         cfg = Config()
@@ -93,6 +94,13 @@ class Oracle:
         c = (C.c_double * 9)(*np.asarray(cam, dtype=np.float64).reshape(9))
         rc = self.lib.ssdo_calibration_from_points(w, c, C.byref(cal))
         return rc, cal
+
+    def deproject(self, intr, depth):
+        a = np.ascontiguousarray(depth, dtype=np.uint16)
+        out = np.empty(a.shape + (3,), dtype=np.float32)
+        self.lib.ssdo_deproject(intr.fx, intr.fy, intr.ppx, intr.ppy, intr.depth_units, a.shape[1], a.shape[0],
+                                a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        return out
 
     def calibration_load(self, directory):
         w, c = np.zeros(9), np.zeros(9)

@@ -114,13 +114,19 @@ def compare_result(ssd, fr, res, report):
     report["line"] = line
 
 
-def check_frame(ssd, oracle, det, cfg, cal, xyz, images=True, report=None):
+def check_frame(ssd, oracle, det, cfg, cal, xyz, images=True, report=None, depth_intr=None):
     """Runs one frame through the HIP path (debug capture on) and the oracle and compares everything.
-    Returns the report dict; raises Mismatch on the first difference."""
+    With depth_intr, `xyz` is a uint16 depth frame: the HIP path deprojects on the fly (ssd_process_depth_host),
+    the oracle deprojects first.  Returns the report dict; raises Mismatch on the first difference."""
     report = {} if report is None else report
     ocfg, ocal = ob.to_oracle_config(cfg), ob.to_oracle_calibration(cal)
     det.set_debug(True)
-    fr = det.process_host(xyz)[0]
+    if depth_intr is not None:
+        det.set_intrinsics(depth_intr)
+        fr = det.process_depth_host(xyz)[0]
+        xyz = oracle.deproject(depth_intr, xyz)
+    else:
+        fr = det.process_host(xyz)[0]
     dbg = det.debug(0)
     n_img = ssd.MAX_STEP_IMAGES if images else 0
     res, raw, closed, graw, gclosed = oracle.process(ocfg, ocal, xyz, images=n_img, ground_images=images)

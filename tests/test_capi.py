@@ -232,3 +232,25 @@ def test_calibration_loader_falls_back_to_identity_like_the_reference(ssd, oracl
         assert ref.load_triangle(str(tmp_path))[0] == 2                      # loaded but not valid
     _write_calibration(tmp_path, ssd)                                        # and a good pair loads again
     assert ssd.GeometricCalibration.load(str(tmp_path))[1]
+
+
+# ------------------------------------------------------------------ 16-bit depth input
+def test_deprojection_matches_oracle_bitwise(ssd, oracle):
+    sc = scenes.make(ssd, "vga_3steps_noise2mm")
+    intr = ssd.intrinsics_for_scene(sc)
+    depth = ssd.synth_depth_host([sc])[0]
+    assert depth.dtype == np.uint16 and (depth > 0).mean() > 0.95
+    assert np.array_equal(depth, ssd.synth_depth_host([sc])[0])
+    a, b = ssd.deproject_host(intr, depth), oracle.deproject(intr, depth)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # the documented formula on a few pixels, and zero depth -> the invalid point
+    z = np.float32(depth[100, 200]) * np.float32(intr.depth_units)
+    assert a[100, 200, 2] == z and a[100, 200, 0] == z * ((np.float32(200) - np.float32(intr.ppx)) / np.float32(intr.fx))
+    d0 = depth.copy()
+    d0[5, 7] = 0
+    assert tuple(ssd.deproject_host(intr, d0)[5, 7]) == (0.0, 0.0, 0.0)
+    # the depth frame is the float frame quantised to 0.25 mm: same staircase through the oracle
+    t = ssd.transformation_for_scene(sc)
+    cfg = ssd.default_config(640, 480)
+    res, *_ = oracle.process(ob.to_oracle_config(cfg), ob.to_oracle_calibration(t.constants), a)
+    assert res.n_steps == 4

@@ -177,3 +177,38 @@ def test_detect_stairs_driver_prints_the_reference_line(ssd, oracle, gpu_device)
         cfg = ssd.default_config(640, 480)
         res, *_ = oracle.process(ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants), ssd.synth_host([sc])[0])
         assert out[f] == res.line.decode()
+
+
+DEPTH_SCENES = ["vga_3steps_noise2mm", "xga_config1", "xga_yaw_p8", "vga_8steps_outliers", "fhd_3steps_noise2mm", "xga_no_stairs"]
+
+
+@pytest.mark.parametrize("name", DEPTH_SCENES)
+def test_depth_input_parity_all_intermediates(ssd, oracle, gpu_device, name):
+    """16-bit depth frames deprojected on the fly by the kernels vs the oracle deprojecting first: every intermediate."""
+    sc, trans, cfg = _setup(ssd, name)
+    depth = ssd.synth_depth_host([sc])[0]
+    det = ssd.Detector(cfg, trans, gpu_device)
+    rep = parity.check_frame(ssd, oracle, det, cfg, trans.constants, depth, images=True, depth_intr=ssd.intrinsics_for_scene(sc))
+    det.close()
+    assert rep.get("max_height_err", 0.0) <= parity.TOL_HEIGHT
+
+
+def test_depth_path_equals_float_path_on_the_deprojected_cloud(ssd, gpu_device):
+    """Same handle, same frames: depth input (device-generated, in HBM) and float input (host-deprojected) give bitwise equal results."""
+    sc_list = scenes.batch_scenes(ssd, 640, 480, 6, base_seed=321)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    cfg = ssd.default_config(640, 480, max_frames_per_batch=8)
+    intr = ssd.intrinsics_for_scene(sc_list[0])
+    depth = ssd.synth_depth_host(sc_list)
+    buf = ssd.DeviceBuffer(depth.nbytes, gpu_device)
+    ssd.synth_depth_device(sc_list, buf.ptr, device=gpu_device)
+    assert np.array_equal(buf.download(depth.nbytes, dtype=np.uint16).reshape(depth.shape), depth)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    det.set_intrinsics(intr)
+    det.enqueue_depth(buf.ptr, 6)
+    got = det.fetch(6)
+    want = det.process_host(np.stack([ssd.deproject_host(intr, d) for d in depth]))
+    assert [bytes(x) for x in got] == [bytes(x) for x in want]
+    assert sum(1 for r in got if r.n_steps >= 3) >= 3
+    det.close()
+    buf.free()
