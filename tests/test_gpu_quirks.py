@@ -1,0 +1,163 @@
+"""GPU parity on hand-built clouds that force the reference's quirks and the histogram / peak edge cases
+(thresholds of pointcloud.cpp:243-256, non-finite input), with a calibration that is
+the identity rotation plus a shift of -0.5 m in z (camera z = world z + 0.5 > 0, so that negative world heights exist);
+`cloud()` takes world coordinates."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import parity
+
+pytestmark = pytest.mark.gpu
+
+W, H = 640, 480
+
+
+def cloud(planes, extra=None, seed=0):
+    """planes: list of (z, n_points, (x0, x1), (y0, y1)) -> float32 [H, W, 3]; points of a plane lie on a regular
+    grid inside its rectangle (so that they rasterise to a solid block); the rest of the frame is invalid (0,0,0)."""
+    rng = np.random.default_rng(seed)
+    pts = []
+    for z, n, (x0, x1), (y0, y1) in planes:
+        nx = max(1, int(round(np.sqrt(n * (x1 - x0) / max(y1 - y0, 1e-9)))))
+        ny = (n + nx - 1) // nx
+        gx, gy = np.meshgrid(np.linspace(x0, x1, nx), np.linspace(y0, y1, ny))
+        p = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, z)], 1)[:n]
+        pts.append(p)
+    if extra is not None:
+        pts.append(np.asarray(extra, dtype=np.float64))
+    p = np.concatenate(pts) if pts else np.zeros((0, 3))
+    assert len(p) <= W * H
+    out = np.zeros((W * H, 3), dtype=np.float32)
+    idx = rng.permutation(W * H)[:len(p)]
+    p = p.copy()
+    p[:, 2] += Z_SHIFT                                  # world -> camera
+    out[np.sort(idx)] = p.astype(np.float32)
+    return out.reshape(H, W, 3)
+
+
+Z_SHIFT = 0.5
+
+
+def calibration(ssd):
+    t = ssd.GeometricTransformation()                   # identity (transformation.h:51-55) ...
+    t.constants.b[2] = -Z_SHIFT                         # ... with the camera half a metre below the world origin
+    return t
+
+
+def run(ssd, oracle, gpu_device, xyz):
+    trans = calibration(ssd)
+    cfg = ssd.default_config(W, H, max_frames_per_batch=1)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    rep = parity.check_frame(ssd, oracle, det, cfg, trans.constants, xyz, images=True)
+    dbg_res = oracle.process(ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants), xyz)[0]
+    det.close()
+    return rep, dbg_res
+
+
+GROUND = (0.005, 60000, (-0.55, 0.55), (0.15, 0.45))          # bins 10/11 with float rounding: a ground plateau
+STEP1 = (0.1755, 30000, (-0.4, 0.4), (0.5, 0.75))
+STEP2 = (0.3455, 25000, (-0.4, 0.4), (0.8, 1.05))
+
+
+def test_plain_two_steps_hand_built(ssd, oracle, gpu_device):
+    rep, res = run(ssd, oracle, gpu_device, cloud([GROUND, STEP1, STEP2]))
+    assert res.n_plateaus == 3 and res.n_steps >= 2
+
+
+def test_q1_flat_top_peak_reports_its_last_index(ssd, oracle, gpu_device):
+    """Two neighbouring bins with exactly equal counts: findPeaks pushes the LAST flat index (pointcloud.cpp:227-238)."""
+    half = 9000
+    planes = [GROUND, (0.2055, half, (-0.4, 0.4), (0.5, 0.7)), (0.2155, half, (-0.4, 0.4), (0.7, 0.9)),
+              (0.1955, 1000, (-0.4, 0.4), (0.95, 1.0)), (0.2255, 1000, (-0.4, 0.4), (1.0, 1.05))]
+    rep, res = run(ssd, oracle, gpu_device, cloud(planes))
+    hist = list(res.hist[:res.n_bins])
+    assert hist[30] == hist[31] == half
+    assert 31 in list(res.peaks[:res.n_peaks]) and 30 not in list(res.peaks[:res.n_peaks])
+
+
+def test_q2_threshold_2000_is_absolute_and_sharpness_rule(ssd, oracle, gpu_device):
+    """A peak of 1999 points is dropped, one of 2000 kept; a blunt peak ((2p-l-r)*2 <= p) is dropped (pointcloud.cpp:250-253)."""
+    planes = [GROUND,
+              (0.2055, 1999, (-0.3, 0.3), (0.5, 0.6)),                     # bin 30: below the threshold
+              (0.4055, 2000, (-0.3, 0.3), (0.65, 0.75)),                   # bin 50: exactly at it
+              (0.6055, 4000, (-0.3, 0.3), (0.8, 0.9)), (0.5955, 3000, (-0.3, 0.3), (0.9, 1.0)), (0.6155, 3001, (-0.3, 0.3), (1.0, 1.1))]
+    rep, res = run(ssd, oracle, gpu_device, cloud(planes))
+    peaks = list(res.peaks[:res.n_peaks])
+    assert 30 not in peaks and 50 in peaks
+    assert 70 in list(res.peaks_raw[:res.n_peaks_raw]) and 70 not in peaks      # (8000-3000-3001)*2 = 3998 <= 4000
+
+
+def test_q3_pair_selection_tie_goes_up(ssd, oracle, gpu_device):
+    """hist[h-1] == hist[h+1]: the strict '>' picks [h, h+1] (pointcloud.cpp:307-316)."""
+    planes = [GROUND, (0.3055, 20000, (-0.4, 0.4), (0.5, 0.8)), (0.2955, 3000, (-0.4, 0.4), (0.85, 0.9)), (0.3155, 3000, (-0.4, 0.4), (0.95, 1.0))]
+    rep, res = run(ssd, oracle, gpu_device, cloud(planes))
+    k = [i for i in range(res.n_plateaus) if res.plateaus[i].peak_bin == 40]
+    assert k and (res.plateaus[k[0]].bin_lo, res.plateaus[k[0]].bin_hi) == (40, 41)
+
+
+def test_q4_pair_starting_at_bin_zero_swallows_everything(ssd, oracle, gpu_device):
+    """Peak in bin 1 with hist[0] > hist[2]: Height_t(heightMin - 1) wraps, every point goes to the remainder and all
+    later plateaus are empty (pointcloud.cpp:324, 337-343) -> no steps at all."""
+    planes = [(-0.0945, 9000, (-0.5, 0.5), (0.15, 0.3)),       # bin 0
+              (-0.0845, 20000, (-0.5, 0.5), (0.3, 0.5)),       # bin 1: the peak
+              (-0.0745, 3000, (-0.5, 0.5), (0.5, 0.55)),       # bin 2
+              STEP1, STEP2]
+    rep, res = run(ssd, oracle, gpu_device, cloud(planes))
+    assert res.plateaus[0].peak_bin == 1 and res.plateaus[0].bin_lo == 0
+    assert all(res.plateaus[i].n_points == 0 for i in range(res.n_plateaus))
+    assert res.n_steps == 0 and rep["line"] == '["stairs",["stairSteps",0]]'
+
+
+def test_overlapping_pairs_later_plateau_gets_what_is_left(ssd, oracle, gpu_device):
+    """Peaks two bins apart share the bin between them: the lower plateau takes it (extractPlateauPoints consumes in order)."""
+    planes = [GROUND, (0.2055, 12000, (-0.4, 0.4), (0.5, 0.7)), (0.2155, 6000, (-0.4, 0.4), (0.7, 0.8)), (0.2255, 12001, (-0.4, 0.4), (0.8, 1.0)),
+              (0.1955, 100, (-0.4, 0.4), (1.05, 1.1)), (0.2355, 100, (-0.4, 0.4), (1.1, 1.15))]
+    rep, res = run(ssd, oracle, gpu_device, cloud(planes))
+    pl = {res.plateaus[i].peak_bin: res.plateaus[i] for i in range(res.n_plateaus)}
+    assert 30 in pl and 32 in pl
+    assert (pl[30].bin_lo, pl[30].bin_hi) == (30, 31) and (pl[32].bin_lo, pl[32].bin_hi) == (31, 32)
+    assert pl[30].n_points == 18000 and pl[32].n_points == 12001
+
+
+def test_non_finite_and_huge_coordinates_are_dropped_like_the_reference(ssd, oracle, gpu_device):
+    """NaN / inf / 1e30 coordinates fail the same strict compares in both implementations."""
+    bad = np.array([[np.nan, 0.5, 0.2], [0.1, np.nan, 0.2], [0.1, 0.5, np.nan], [np.inf, 0.5, 0.2], [0.1, -np.inf, 0.2],
+                    [0.1, 0.5, np.inf], [1e30, 0.5, 0.2], [0.1, 0.5, 1e30], [0.1, 0.5, -Z_SHIFT], [-0.0, 0.5, 3e-45 - Z_SHIFT], [0.1, 0.5, -0.7]] * 50)
+    rep, res = run(ssd, oracle, gpu_device, cloud([GROUND, STEP1, STEP2], extra=bad))
+    assert res.n_nonzero > res.n_inrange
+
+
+def test_points_exactly_on_the_range_limits_are_outside(ssd, oracle, gpu_device):
+    """All six limits are strict (configuration.h:44-46, pointcloud.cpp:157-162): 0.1 m and 1.3 m in y, 1.1 in z as
+    float32 are a hair beyond/below the double limits; neighbours one float ulp inside are kept."""
+    f = np.float32
+    edge = []
+    for v in (f(-0.6), f(0.6), np.nextafter(f(-0.6), f(0)), np.nextafter(f(0.6), f(0))):
+        edge.append([v, 0.5, 0.2])
+    for v in (f(0.1), f(1.3), np.nextafter(f(0.1), f(1)), np.nextafter(f(1.3), f(0))):
+        edge.append([0.0, v, 0.2])
+    for v in (1.1, 1.1 - 1e-7, -0.1, -0.1 + 1e-7, -0.1 - 1e-7):
+        edge.append([0.0, 0.5, v])
+    rep, res = run(ssd, oracle, gpu_device, cloud([GROUND, STEP1], extra=np.array(edge * 20, dtype=np.float64)))
+    assert res.n_inrange < res.n_nonzero
+
+
+def test_more_step_plateaus_than_image_slots_is_flagged(ssd, gpu_device):
+    """The reference has no limit on plateaus; the workspace holds max_step_plateaus images per frame: a frame with more
+    is processed up to the limit and flagged SSD_ST_OVERFLOW (never silently)."""
+    planes = [GROUND] + [(0.1055 + 0.05 * k, 2500, (-0.4, 0.0), (0.5, 1.2)) for k in range(19)]
+    xyz = cloud(planes)
+    trans = calibration(ssd)
+    cfg = ssd.default_config(W, H, max_frames_per_batch=1)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    det.set_debug(True)
+    fr = det.process_host(xyz)[0]
+    dbg = det.debug(0)
+    det.close()
+    assert dbg.n_plateaus == 20 and (fr.status & ssd.ST_OVERFLOW)
+    cfg2 = ssd.default_config(W, H, max_frames_per_batch=1)
+    det = ssd.Detector(cfg2, trans, gpu_device)
+    ok = det.process_host(cloud(planes[:17]))[0]                # ground + 16 step plateaus fit
+    det.close()
+    assert not (ok.status & ssd.ST_OVERFLOW)
