@@ -29,6 +29,12 @@ def scene_params():
     p["xga_invalid10"] = ("xga", dict(n_steps=3, sigma=0.001, seed=16, invalid_frac=0.10))
     p["vga_yaw_outliers"] = ("vga", dict(n_steps=4, sigma=0.003, seed=17, yaw_deg=6.0, outlier_frac=0.02, rise=0.15, tread=0.26))
     p["xga_low_camera"] = ("xga", dict(n_steps=2, sigma=0.001, seed=18, cam_height=0.8, pitch_deg=40.0, first_riser_y=0.6))
+    # strong yaw: quadrilaterals far from axis-aligned (quirk Q9 territory); at 40-50 degrees the reference's
+    # QuadrilateralTest constructor throws (quirk Q7 / quadrilateralTest.cpp:283-288): the frame has no line
+    p["xga_yaw20"] = ("xga", dict(n_steps=3, sigma=0.001, seed=20, yaw_deg=20.0))
+    p["vga_yaw30_narrow"] = ("vga", dict(n_steps=3, sigma=0.002, seed=100, yaw_deg=30.0, stair_width=0.5))
+    p["vga_yaw40_wide_throws"] = ("vga", dict(n_steps=3, sigma=0.002, seed=100, yaw_deg=40.0, stair_width=1.1))
+    p["vga_yaw50_throws"] = ("vga", dict(n_steps=3, sigma=0.002, seed=101, yaw_deg=50.0, stair_width=0.8))
     p["xga_2steps_deep"] = ("xga", dict(n_steps=2, sigma=0.002, seed=19, tread=0.4, rise=0.19, first_riser_y=0.35))
     return p
 

@@ -44,6 +44,10 @@ def test_scene_set_covers_the_interesting_outcomes(ssd, oracle):
     d = dict(outcomes)
     assert d["xga_config1"] == 4
     assert d["xga_no_stairs"] == 0 and d["vga_empty"] == 0
+    for name in ("vga_yaw40_wide_throws", "vga_yaw50_throws"):
+        sc, trans, cfg = _setup(ssd, name)
+        n, steps, status = oracle.process_lean(ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants), ssd.synth_host([sc])[0])
+        assert status & ob.ST_THROW and n == 0
 
 
 def test_device_generator_matches_host_generator(ssd, gpu_device):

@@ -1,3 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_quirks.py -m gpu -q 2>&1 | tail -30
+python -m pytest tests -m gpu -q -x 2>&1 | tail -8
