@@ -216,3 +216,28 @@ def test_depth_path_equals_float_path_on_the_deprojected_cloud(ssd, gpu_device):
     assert sum(1 for r in got if r.n_steps >= 3) >= 3
     det.close()
     buf.free()
+
+
+@pytest.mark.parametrize("variant", ["coarse_bins", "shifted_range", "fine_bins"])
+def test_non_default_configuration(ssd, oracle, gpu_device, variant):
+    """The reference's Configuration is compile-time (configuration.h:27-52); here it is a run-time struct: other
+    measuring ranges, bin widths and thresholds must give the oracle's results too (derived constants of
+    pointcloud.cpp:99-106 included)."""
+    sc = scenes.make(ssd, "xga_yaw_p8")
+    trans = ssd.transformation_for_scene(sc)
+    cfg = ssd.default_config(sc.width, sc.height, max_frames_per_batch=1)
+    if variant == "coarse_bins":
+        cfg.height_interval = 0.02                      # 61 bins
+        cfg.min_height_above_ground = 0.08
+    elif variant == "shifted_range":
+        cfg.x_min, cfg.x_max = -0.45, 0.7
+        cfg.y_min, cfg.y_max = 0.25, 1.15
+        cfg.z_min, cfg.z_max = -0.05, 0.9
+        cfg.min_step_depth = 0.15
+    else:
+        cfg.height_interval = 0.0095                    # 127 bins: just inside SSD_MAX_BINS
+    xyz = ssd.synth_host([sc])[0]
+    det = ssd.Detector(cfg, trans, gpu_device)
+    rep = parity.check_frame(ssd, oracle, det, cfg, trans.constants, xyz, images=True)
+    det.close()
+    assert rep["n_steps"] >= 2
