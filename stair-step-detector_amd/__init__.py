@@ -305,9 +305,16 @@ class Detector:
                                         C.c_void_p(stream or 0), stages))
 
     def fetch(self, nframes, stream=None):
-        res = (FrameResult * nframes)()
-        _check(lib().ssd_fetch(self._h, res, nframes, C.c_void_p(stream or 0)))
-        return list(res)
+        """Waits for the last enqueue and returns its results (an indexable ctypes array of FrameResult; the
+        buffer is reused by the next fetch of the same size)."""
+        if getattr(self, "_res_n", 0) != nframes:
+            self._res, self._res_n = (FrameResult * nframes)(), nframes
+        _check(lib().ssd_fetch(self._h, self._res, nframes, C.c_void_p(stream or 0)))
+        return self._res
+
+    def fetch_list(self, nframes, stream=None):
+        """fetch() as a list of independent FrameResult copies."""
+        return [FrameResult.from_buffer_copy(r) for r in self.fetch(nframes, stream)]
 
     def set_timing(self, on=True):
         _check(lib().ssd_set_timing(self._h, 1 if on else 0))

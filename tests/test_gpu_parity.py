@@ -91,7 +91,7 @@ def test_device_resident_enqueue_fetch(ssd, oracle, gpu_device):
     det = ssd.Detector(cfg, trans, gpu_device)
     det.set_timing(True)
     det.enqueue(buf.ptr, 5, stride_bytes=stride)
-    res = det.fetch(5)
+    res = det.fetch_list(5)
     times = det.stage_times_ms()
     assert all(t >= 0.0 for t in times.values()) and times["hist"] > 0.0
     host = ssd.synth_host(sc_list)
@@ -116,7 +116,7 @@ def test_unaligned_frames_take_the_12_byte_load_path(ssd, oracle, gpu_device):
     for i in range(3):
         buf.upload(host[i], offset=4 + i * stride)          # base pointer 4 (not 16) byte aligned as well
     det.enqueue(buf.ptr + 4, 3, stride_bytes=stride)
-    got = det.fetch(3)
+    got = det.fetch_list(3)
     assert [bytes(x) for x in got] == [bytes(x) for x in want]
     det.close()
     buf.free()
@@ -147,14 +147,14 @@ def test_full_size_properties_xga_batch(ssd, oracle, gpu_device):
     ssd.synth_device(sc_list, buf.ptr, device=gpu_device)
     det = ssd.Detector(cfg, trans, gpu_device)
     det.enqueue(buf.ptr, n)
-    r1 = det.fetch(n)
+    r1 = det.fetch_list(n)
     det.enqueue(buf.ptr, n)
-    r2 = det.fetch(n)
+    r2 = det.fetch_list(n)
     assert [bytes(x) for x in r1] == [bytes(x) for x in r2]
     perm = list(reversed(range(n)))
     ssd.synth_device([sc_list[i] for i in perm], buf.ptr, device=gpu_device)
     det.enqueue(buf.ptr, n)
-    r3 = det.fetch(n)
+    r3 = det.fetch_list(n)
     assert [bytes(r3[j]) for j in range(n)] == [bytes(r1[perm[j]]) for j in range(n)]
     assert sum(1 for r in r1 if r.n_steps >= 3) >= n // 2
     host = ssd.synth_host([sc_list[i] for i in range(0, n, 8)])
@@ -210,7 +210,7 @@ def test_depth_path_equals_float_path_on_the_deprojected_cloud(ssd, gpu_device):
     det = ssd.Detector(cfg, trans, gpu_device)
     det.set_intrinsics(intr)
     det.enqueue_depth(buf.ptr, 6)
-    got = det.fetch(6)
+    got = det.fetch_list(6)
     want = det.process_host(np.stack([ssd.deproject_host(intr, d) for d in depth]))
     assert [bytes(x) for x in got] == [bytes(x) for x in want]
     assert sum(1 for r in got if r.n_steps >= 3) >= 3
