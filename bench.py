@@ -178,12 +178,15 @@ def main():
             rep = {}
             cdt = 0.0
             checked = 0
+            keep = []                                       # host copies for the all-cores leg below
             for i in idx:                                   # one frame at a time: download (untimed), oracle (timed)
                 x = frames[i * frame_bytes:(i + 1) * frame_bytes].cpu().numpy()
                 x = oracle.deproject(intr, x.view(np.uint16).reshape(H, W)) if depth_in else x.view(np.float32)
                 c0 = time.perf_counter()
                 oracle.process_lean(ocfg, ocal, x)
                 cdt += time.perf_counter() - c0
+                if len(keep) < (64 if fhd else 256):
+                    keep.append(x)
                 if i % 64 == 0 or i == idx[-1]:
                     parity.check_results_only(ssd, oracle, cfg, trans.constants, x, res[i], rep)
                     checked += 1
@@ -191,6 +194,18 @@ def main():
                                    "sample": "%d of the %d frames of rank 0's batch (evenly spaced), the whole per-frame path in "
                                              "oracle/ssd_oracle.cpp (CPU restatement of the reference, one thread as the reference runs), "
                                              "%.1f s of CPU time" % (n_cpu, F, cdt)}
+            # the same port on all host cores, one frame per thread (ctypes drops the GIL)
+            cores = len(os.sched_getaffinity(0))
+            if cores > 1 and len(keep) > 1:
+                from concurrent.futures import ThreadPoolExecutor
+                reps = max(1, (4 * cores + len(keep) - 1) // len(keep))
+                work = keep * reps
+                with ThreadPoolExecutor(cores) as pool:
+                    c0 = time.perf_counter()
+                    list(pool.map(lambda a: oracle.process_lean(ocfg, ocal, a), work))
+                    adt = time.perf_counter() - c0
+                out["cpu_baseline_all_cores"] = {"value": len(work) / adt, "unit": "frames/s", "cores": cores, "kind": "port",
+                                                 "sample": "%d frames (%d distinct), one frame per thread, %.1f s wall" % (len(work), len(keep), adt)}
             out["parity"] = {"frames_checked_against_oracle": checked, "max_abs_height_err_m": rep.get("max_height_err", 0.0),
                              "max_abs_corner_err_m": rep.get("max_corner_err", 0.0), "bar_m": 1e-4}
         print(json.dumps(out), flush=True)

@@ -241,3 +241,19 @@ def test_non_default_configuration(ssd, oracle, gpu_device, variant):
     rep = parity.check_frame(ssd, oracle, det, cfg, trans.constants, xyz, images=True)
     det.close()
     assert rep["n_steps"] >= 2
+
+
+def test_hip_path_reproduces_the_surveys_observed_run(ssd, gpu_device, tmp_path):
+    """SURVEY.md Appendix A's frame through the HIP path, against the values the survey observed from the reference
+    (a sanity anchor, see tests/survey_anchor.py): corners bit-exact, heights to 1e-9 m, the line byte for byte."""
+    import survey_anchor as sa
+    xyz, cam = sa.frame(tmp_path)
+    trans = ssd.GeometricTransformation(sa.WORLD_POINTS.reshape(3, 3), cam.reshape(3, 3))
+    det = ssd.Detector(ssd.default_config(1024, 768, max_frames_per_batch=1), trans, gpu_device)
+    fr = det.process_host(xyz)[0]
+    det.close()
+    assert (fr.n_steps, fr.status) == (4, 0)
+    for i in range(4):
+        assert abs(fr.steps[i].height - sa.OBSERVED[i, 0]) <= parity.TOL_HEIGHT
+        assert list(fr.steps[i].quad) == list(sa.OBSERVED[i, 1:])
+    assert ssd.Stairs(fr).serialize() == sa.OBSERVED_LINE

@@ -15,6 +15,20 @@ def _unhex(lst, shape):
     return np.array([float.fromhex(x) for x in lst], dtype=np.float64).reshape(shape)
 
 
+# ------------------------------------------------------------------ sanity anchor: the survey's probe run
+def test_oracle_reproduces_the_surveys_observed_run(oracle, tmp_path):
+    """SURVEY.md Appendix A's frame through the oracle: every printed digit of the values the survey observed from the
+    reference (stand-in build; an anchor, not a pin — see tests/survey_anchor.py)."""
+    import survey_anchor as sa
+    xyz, cam = sa.frame(tmp_path)
+    rc, cal = oracle.calibration(sa.WORLD_POINTS, cam)
+    assert rc == 0
+    n, steps, status = oracle.process_lean(oracle.config(1024, 768), cal, xyz)
+    assert (n, status) == (4, 0)
+    assert ["%.17g" % v for v in steps.reshape(-1)] == ["%.17g" % v for v in sa.OBSERVED.reshape(-1)]
+    assert oracle.serialize(steps) == sa.OBSERVED_LINE
+
+
 # ------------------------------------------------------------------ golden vectors from the real reference
 def test_serialize_matches_reference_goldens(oracle):
     cases = json.load(open(os.path.join(HERE, "golden", "ref_serialize.json")))
