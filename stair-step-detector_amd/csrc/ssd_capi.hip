@@ -340,6 +340,20 @@ static int make_params(const ssd_config &c, const ssd_calibration &k, Params &P)
   P.px.xToImage = P.xToImage; P.px.yToImage = P.yToImage;
   P.px.W = P.W; P.px.H = P.H; P.px.W64 = P.W64;
   P.px.maxStepImages = P.maxStepImages;
+  /* Shape of the waves' write-combining windows (ssd_kernels.hip, WaveWindow).  A wave takes the same 256 pixels of
+   * every block tile of 1024: when a camera row is a whole number of block tiles (XGA) it walks down one 256-pixel
+   * column strip and a tall narrow window (32 rows x 8 words) follows it; otherwise (VGA, FHD) its strip jumps along
+   * the row from tile to tile and only a window as wide as the image row keeps the hits in LDS. */
+  P.px.winShift = 3;
+  if(c.width % 1024 != 0 && P.W64 <= 32)
+    while((1 << P.px.winShift) < P.W64)
+      P.px.winShift++;
+  if(const char *e = getenv("SSD_WIN_SHIFT"))
+  {
+    const int v = atoi(e);
+    if(v >= 2 && v <= 6)
+      P.px.winShift = v;
+  }
   if((c.width - 1) / 25 + 2 > SSD_MAX_SCANS)
     return fail(SSD_E_ARG, "config: width needs more scan columns than SSD_MAX_SCANS");
   return SSD_OK;

@@ -43,6 +43,7 @@ struct PixelParams
   double xToImage, yToImage;                  /* Projection2D (pointcloud.cpp:73-74) */
   int W, H, W64;                              /* W64 = 64-bit words per image row */
   int maxStepImages;
+  int winShift;                               /* the waves' LDS image windows are (256 >> winShift) rows x (1 << winShift) words */
 };
 
 /* what the 16-bit depth source needs beside the depth image: rs2::pointcloud's pre-computed maps

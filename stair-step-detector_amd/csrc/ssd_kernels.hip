@@ -420,7 +420,7 @@ __global__ void k_peaks(Params P, FrameState *__restrict__ st, int nframes, Debu
  * window moves and at the end.  Bits outside the window go straight to memory, so the result never depends
  * on where the window is; when more lanes missed than hit during a tile the wave flushes and re-anchors at
  * the lowest missing (image, row).  Everything is decided with ballots and shuffles inside the wave. */
-constexpr int kWinRows = 32, kWinCols = 8, kWinWords = kWinRows * kWinCols;      /* 2 KiB per wave */
+constexpr int kWinWords = 256;      /* 2 KiB per wave; shaped (256 >> winShift) rows x (1 << winShift) word columns, see PixelParams::winShift */
 
 struct ImageBox { int yMin, yMax, xMin, xMax; };
 
@@ -473,7 +473,7 @@ __device__ __forceinline__ int wave_max_i(int v)
 
 /* writes the wave's window out (non-zero words only), clears it, extends the image's bounding box; all 64 lanes */
 __device__ __forceinline__ void wavewin_flush(unsigned long long *ww, const WaveWindow &w, unsigned long long *__restrict__ images,
-                                              unsigned int imgWords, int W64, ImageBox *boxes, int lane)
+                                              unsigned int imgWords, int W64, int winShift, ImageBox *boxes, int lane)
 {
   if(w.slot < 0)
     return;
@@ -486,7 +486,7 @@ __device__ __forceinline__ void wavewin_flush(unsigned long long *ww, const Wave
     const unsigned long long v = ww[i];
     if(v)
     {
-      const int y = w.row0 + i / kWinCols, x = w.col0 + i % kWinCols;
+      const int y = w.row0 + (i >> winShift), x = w.col0 + (i & ((1 << winShift) - 1));
       atomicOr(img + static_cast<size_t>(y) * W64 + x, v);
       ww[i] = 0ull;
       y0 = min(y0, y); y1 = max(y1, y);
@@ -515,13 +515,13 @@ struct MissInfo
 
 /* one word's worth of bits of image `slot`: into the window when it is inside, straight to memory otherwise */
 __device__ __forceinline__ void wavewin_or(unsigned long long *ww, const WaveWindow &w, unsigned long long *__restrict__ images,
-                                           unsigned int imgWords, int W64, ImageBox *boxes, MissBox &mb, MissInfo &mi,
+                                           unsigned int imgWords, int W64, int winShift, ImageBox *boxes, MissBox &mb, MissInfo &mi,
                                            int slot, int iy, int xw, unsigned long long mask)
 {
   const unsigned int r = static_cast<unsigned int>(iy - w.row0), c = static_cast<unsigned int>(xw - w.col0);
-  if(slot == w.slot && r < static_cast<unsigned int>(kWinRows) && c < static_cast<unsigned int>(kWinCols))
+  if(slot == w.slot && r < (static_cast<unsigned int>(kWinWords) >> winShift) && c < (1u << winShift))
   {
-    atomicOr(&ww[r * kWinCols + c], mask);
+    atomicOr(&ww[(r << winShift) + c], mask);
     mi.hit = true;
   }
   else
@@ -536,14 +536,14 @@ __device__ __forceinline__ void wavewin_or(unsigned long long *ww, const WaveWin
 
 /* end of a tile, all 64 lanes: nothing to do unless some lane missed; re-anchor when misses outnumber hits */
 __device__ __forceinline__ void wavewin_end_of_tile(unsigned long long *ww, WaveWindow &w, unsigned long long *__restrict__ images,
-                                                    unsigned int imgWords, int W64, ImageBox *boxes, const MissInfo &mi, int lane)
+                                                    unsigned int imgWords, int W64, int winShift, ImageBox *boxes, const MissInfo &mi, int lane)
 {
   const unsigned long long missing = __ballot(mi.miss);
   if(missing == 0ull)
     return;
   if(__popcll(missing) <= __popcll(__ballot(mi.hit)))
     return;
-  wavewin_flush(ww, w, images, imgWords, W64, boxes, lane);
+  wavewin_flush(ww, w, images, imgWords, W64, winShift, boxes, lane);
   const unsigned int key = static_cast<unsigned int>(wave_min_i(static_cast<int>(mi.key >> 1))) ;   /* keys are < 2^31 after >> 1 */
   /* recover the exact minimum: the lanes whose key >> 1 equals the minimum vote with their low bit */
   const unsigned int lowBit = (__ballot((mi.key >> 1) == key && !(mi.key & 1u)) != 0ull) ? 0u : 1u;
@@ -553,7 +553,7 @@ __device__ __forceinline__ void wavewin_end_of_tile(unsigned long long *ww, Wave
   const int col = wave_min_i((mi.miss && static_cast<int>(mi.key >> 16) == slot) ? mi.col : 0x7fffffff);
   w.slot = slot;
   w.row0 = static_cast<int>(full & 0xffffu);
-  w.col0 = max(0, min(col - 1, W64 - kWinCols));
+  w.col0 = max(0, min(col - 1, W64 - (1 << winShift)));
 }
 
 /* Projection2D::worldToImage (pointcloud.cpp:79-83); false = outside the image (quirk Q5) */
@@ -644,14 +644,14 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
         continue;
       }
       if(pSlot >= 0)
-        wavewin_or(ww, win, frameImg, imgWords, X.W64, boxes, mb, mi, pSlot, pY, pXw, pMask);
+        wavewin_or(ww, win, frameImg, imgWords, X.W64, X.winShift, boxes, mb, mi, pSlot, pY, pXw, pMask);
       pSlot = slot; pY = iy; pXw = ix >> 6; pMask = bit;
     }
     if(pSlot >= 0)
-      wavewin_or(ww, win, frameImg, imgWords, X.W64, boxes, mb, mi, pSlot, pY, pXw, pMask);
-    wavewin_end_of_tile(ww, win, frameImg, imgWords, X.W64, boxes, mi, lane);
+      wavewin_or(ww, win, frameImg, imgWords, X.W64, X.winShift, boxes, mb, mi, pSlot, pY, pXw, pMask);
+    wavewin_end_of_tile(ww, win, frameImg, imgWords, X.W64, X.winShift, boxes, mi, lane);
   }
-  wavewin_flush(ww, win, frameImg, imgWords, X.W64, boxes, lane);
+  wavewin_flush(ww, win, frameImg, imgWords, X.W64, X.winShift, boxes, lane);
   missbox_flush(mb, boxes);
   if(oob)
     atomicAdd(&lOob, oob);
@@ -685,19 +685,25 @@ __device__ __forceinline__ unsigned long long raw_word(const BitImg &im, int y, 
 /* word c of row y of the image after cv::morphologyEx(MORPH_CLOSE, 3x3 rect, 1 iteration, default
  * border): dilation = OR over the in-image 3x3 neighbours, erosion = AND over them (pixels outside
  * the image never win; segmentation.cpp:888,928).  Needs raw rows y-2..y+2, words c-1..c+1. */
-__device__ unsigned long long closed_word(const BitImg &im, int y, int c)
+struct HRow
 {
-  unsigned long long hc[5];
-  unsigned int hl[5], hr[5];
-#pragma unroll
-  for(int r = 0; r < 5; r++)
-  {
-    const int yy = y - 2 + r;
-    const unsigned long long L = raw_word(im, yy, c - 1), w = raw_word(im, yy, c), R = raw_word(im, yy, c + 1);
-    hc[r] = w | (w << 1) | (w >> 1) | (L >> 63) | (R << 63);
-    hl[r] = static_cast<unsigned int>(((L >> 63) | (L >> 62) | w) & 1ull);        /* dilated pixel x = 64c-1 */
-    hr[r] = static_cast<unsigned int>((R | (R >> 1) | (w >> 63)) & 1ull);         /* dilated pixel x = 64c+64 */
-  }
+  unsigned long long c;          /* word c of a row, dilated horizontally */
+  unsigned int l, r;             /* the dilated pixels x = 64c-1 and x = 64c+64 */
+};
+
+__device__ __forceinline__ HRow hdilated_row(const BitImg &im, int yy, int c)
+{
+  const unsigned long long L = raw_word(im, yy, c - 1), w = raw_word(im, yy, c), R = raw_word(im, yy, c + 1);
+  HRow h;
+  h.c = w | (w << 1) | (w >> 1) | (L >> 63) | (R << 63);
+  h.l = static_cast<unsigned int>(((L >> 63) | (L >> 62) | w) & 1ull);
+  h.r = static_cast<unsigned int>((R | (R >> 1) | (w >> 63)) & 1ull);
+  return h;
+}
+
+/* h[r] = hdilated_row(y - 2 + r) */
+__device__ __forceinline__ unsigned long long closed_from_rows(const BitImg &im, int y, int c, const HRow h[5])
+{
   const int rem = im.W - 64 * c;
   const unsigned long long vm = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);        /* pixels of this word inside the image */
   unsigned long long res = vm;
@@ -707,15 +713,45 @@ __device__ unsigned long long closed_word(const BitImg &im, int y, int c)
     const int yy = y - 1 + r;
     if(yy < 0 || yy >= im.H)
       continue;                                   /* row outside the image: ignored by the erosion */
-    unsigned long long dc = hc[r] | hc[r + 1] | hc[r + 2];
-    unsigned int dl = hl[r] | hl[r + 1] | hl[r + 2];
-    unsigned int dr = hr[r] | hr[r + 1] | hr[r + 2];
+    unsigned long long dc = h[r].c | h[r + 1].c | h[r + 2].c;
+    unsigned int dl = h[r].l | h[r + 1].l | h[r + 2].l;
+    unsigned int dr = h[r].r | h[r + 1].r | h[r + 2].r;
     dc |= ~vm;
     if(c == 0) dl = 1u;
     if(rem <= 64) dr = 1u;
     res &= dc & ((dc << 1) | dl) & ((dc >> 1) | (static_cast<unsigned long long>(dr) << 63));
   }
   return res;
+}
+
+__device__ unsigned long long closed_word(const BitImg &im, int y, int c)
+{
+  HRow h[5];
+#pragma unroll
+  for(int r = 0; r < 5; r++)
+    h[r] = hdilated_row(im, y - 2 + r, c);
+  return closed_from_rows(im, y, c, h);
+}
+
+/* closed words of column c, rows [yA, yB), top to bottom with a rolling window of five dilated rows
+ * (3 word loads per row instead of 15); calls visit(y, closedWord) for the non-zero ones (all with `all`) */
+template<typename Visit>
+__device__ __forceinline__ void closed_column(const BitImg &im, int c, int yA, int yB, bool all, Visit visit)
+{
+  HRow h[5];
+#pragma unroll
+  for(int r = 1; r < 5; r++)
+    h[r] = hdilated_row(im, yA - 3 + r, c);
+  for(int y = yA; y < yB; y++)
+  {
+#pragma unroll
+    for(int r = 0; r < 4; r++)
+      h[r] = h[r + 1];
+    h[4] = hdilated_row(im, y + 2, c);
+    if(!all && (h[0].c | h[1].c | h[2].c | h[3].c | h[4].c) == 0ull)
+      continue;                                   /* nothing lit within two rows: the closing has nothing either */
+    visit(y, closed_from_rows(im, y, c, h));
+  }
 }
 
 /* ========================================================================= */
@@ -806,7 +842,7 @@ __device__ __forceinline__ bool intersect60(const LineD &l, const LineD &o, doub
 
 /* residual of the line through points p and q: sum of the n smallest |a x + b y + c| of the other
  * points, over n * hypot(a, b) */
-__device__ double line_residual(const int *px, const int *py, int m, int p, int q, LineI &line)
+__device__ double line_residual_generic(const int *px, const int *py, int m, int p, int q, LineI &line)
 {
   line = line_through_i(px[p], py[p], px[q], py[q]);
   if(m <= 2)
@@ -835,8 +871,48 @@ __device__ double line_residual(const int *px, const int *py, int m, int p, int 
   return sum / (n * hypot_ref(static_cast<double>(line.a), static_cast<double>(line.b)));
 }
 
+__device__ __forceinline__ unsigned int umed3(unsigned int a, unsigned int b, unsigned int c)
+{
+  return max(min(a, b), min(max(a, b), c));       /* v_med3_u32 */
+}
+
+/* The same sum for images with 3 W H < 2^25 and m <= 128 (every distance fits 25 bits: |a| <= H, |b| <= W,
+ * |c| <= W H).  The two points of the pair lie on their line exactly (integer arithmetic), so the n smallest
+ * distances of the others are the n + 2 smallest of all m, minus two zeros: no exclusion tests.  Distances
+ * become distinct keys (d << 7 | i) + 1 and every pass over the points extracts the next FOUR smallest keys
+ * with a min / med3 insertion network, in registers. */
+__device__ double line_residual_keys(const int *px, const int *py, int m, int p, int q, LineI &line)
+{
+  line = line_through_i(px[p], py[p], px[q], py[q]);
+  if(m <= 2)
+    return 0.0;
+  const int nd = m - 2;
+  const int n = nd > 4 ? (nd - 1) / 2 : 1;
+  int need = n + 2;
+  unsigned int sum = 0, last = 0;
+  while(need > 0)
+  {
+    unsigned int b1 = 0xffffffffu, b2 = 0xffffffffu, b3 = 0xffffffffu, b4 = 0xffffffffu;
+    for(int i = 0; i < m; i++)
+    {
+      const unsigned int d = static_cast<unsigned int>(abs(px[i] * line.a + py[i] * line.b + line.c));
+      unsigned int k = ((d << 7) | static_cast<unsigned int>(i)) + 1u;
+      k = k > last ? k : 0xffffffffu;
+      const unsigned int n4 = umed3(b3, b4, k), n3 = umed3(b2, b3, k), n2 = umed3(b1, b2, k);
+      b1 = min(b1, k); b2 = n2; b3 = n3; b4 = n4;
+    }
+    /* need <= number of keys above `last`, so the ones taken are real */
+    sum += (b1 - 1u) >> 7; last = b1;
+    if(need > 1) { sum += (b2 - 1u) >> 7; last = b2; }
+    if(need > 2) { sum += (b3 - 1u) >> 7; last = b3; }
+    if(need > 3) { sum += (b4 - 1u) >> 7; last = b4; }
+    need -= 4;
+  }
+  return static_cast<int>(sum) / (n * hypot_ref(static_cast<double>(line.a), static_cast<double>(line.b)));
+}
+
 /* all 64 lanes of the calling wave take part; result is returned in every lane */
-__device__ LineI wave_best_line(const int *px, const int *py, int m, int lane)
+__device__ LineI wave_best_line(const int *px, const int *py, int m, int lane, bool smallImage)
 {
   const int nPairs = m * (m - 1) / 2;
   double bestRes = 1.0e300;
@@ -853,7 +929,7 @@ __device__ LineI wave_best_line(const int *px, const int *py, int m, int lane)
     }
     const int q = p + 1 + rem;
     LineI l;
-    const double r = line_residual(px, py, m, p, q, l);
+    const double r = smallImage && m <= 128 ? line_residual_keys(px, py, m, p, q, l) : line_residual_generic(px, py, m, p, q, l);
     if(bestT == 0x7fffffff || r < bestRes)     /* min_element: first of equal minima (t ascends per lane) */
     {
       bestRes = r;
@@ -961,26 +1037,32 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
     by0 = 0; by1 = P.H - 1; bc0 = 0; bc1 = P.W64 - 1;
   }
   const int bw = emptyImg && !dbgImg ? 0 : bc1 - bc0 + 1, bh = emptyImg && !dbgImg ? 0 : by1 - by0 + 1;
-  for(int idx = tid; idx < bw * bh; idx += kThreads)
+  /* thread -> (word column, band of rows): neighbouring threads read neighbouring words */
+  const int nBands = bw > 0 ? max(1, kThreads / bw) : 0;
+  const int bandRows = nBands > 0 ? (bh + nBands - 1) / nBands : 0;
+  for(int t = tid; t < bw * nBands; t += kThreads)
   {
-    const int ry = idx / bw;
-    const int y = by0 + ry, c = bc0 + (idx - ry * bw);
-    const unsigned long long cw = closed_word(im, y, c);
-    if(dbgImg)
+    const int band = t / bw;
+    const int c = bc0 + (t - band * bw);
+    const int yA = by0 + band * bandRows, yB = min(yA + bandRows, by1 + 1);
+    closed_column(im, c, yA, yB, dbgImg != nullptr, [&](int y, unsigned long long cw)
     {
-      dbgRaw[y * P.W64 + c] = img[y * P.W64 + c];
-      dbgClosed[y * P.W64 + c] = cw;
-    }
-    if(cw == 0ull)
-      continue;
-    const int x0 = 64 * c;
-    int j = x0 <= xr0 ? 0 : (x0 - xr0 + xStep - 1) / xStep;
-    for(int x = xr0 + xStep * j; x < x0 + 64 && j < nCols; x += xStep, j++)
-      if((cw >> (x - x0)) & 1ull)
+      if(dbgImg)
       {
-        atomicMin(&S.yFirst[j], y);
-        atomicMax(&S.ySecond[j], y);
+        dbgRaw[y * P.W64 + c] = img[y * P.W64 + c];
+        dbgClosed[y * P.W64 + c] = cw;
       }
+      if(cw == 0ull)
+        return;
+      const int x0 = 64 * c;
+      int j = x0 <= xr0 ? 0 : (x0 - xr0 + xStep - 1) / xStep;
+      for(int x = xr0 + xStep * j; x < x0 + 64 && j < nCols; x += xStep, j++)
+        if((cw >> (x - x0)) & 1ull)
+        {
+          atomicMin(&S.yFirst[j], y);
+          atomicMax(&S.ySecond[j], y);
+        }
+    });
   }
   __syncthreads();
 
@@ -1056,7 +1138,7 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
   {
     /* ---- BestLine per horizontal edge: wave w takes edge w (HorizontalEdges::Edge :570-583) ---- */
     {
-      const LineI l = wave_best_line(S.ex[wave], S.ey[wave], S.en[wave], lane);
+      const LineI l = wave_best_line(S.ex[wave], S.ey[wave], S.en[wave], lane, 3ll * P.W * P.H < (1ll << 25));
       if(lane == 0)
         S.line[wave] = l;
     }
@@ -1786,15 +1868,15 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
           continue;
         }
         if(pY >= 0)
-          wavewin_or(ww, win, gimg, imgWords, X.W64, box, mb, mi, 0, pY, pXw, pMask);
+          wavewin_or(ww, win, gimg, imgWords, X.W64, X.winShift, box, mb, mi, 0, pY, pXw, pMask);
         pY = iy; pXw = ix >> 6; pMask = bit;
       }
     }
     if(pY >= 0)
-      wavewin_or(ww, win, gimg, imgWords, X.W64, box, mb, mi, 0, pY, pXw, pMask);
-    wavewin_end_of_tile(ww, win, gimg, imgWords, X.W64, box, mi, lane);
+      wavewin_or(ww, win, gimg, imgWords, X.W64, X.winShift, box, mb, mi, 0, pY, pXw, pMask);
+    wavewin_end_of_tile(ww, win, gimg, imgWords, X.W64, X.winShift, box, mi, lane);
   }
-  wavewin_flush(ww, win, gimg, imgWords, X.W64, box, lane);
+  wavewin_flush(ww, win, gimg, imgWords, X.W64, X.winShift, box, lane);
   missbox_flush(mb, box);
   flushAcc();
   if(oob)
@@ -1892,23 +1974,28 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
     else if(by0 <= yStop)
       by0 = yStop + 1;                               /* only rows below the image centre are probed */
     const int bw = (emptyImg && !dbgImg) || by1 < by0 ? 0 : bc1 - bc0 + 1, bh = by1 - by0 + 1;
-    for(int idx = tid; idx < bw * bh; idx += kThreads)
+    const int nBands = bw > 0 ? max(1, kThreads / bw) : 0;
+    const int bandRows = nBands > 0 ? (bh + nBands - 1) / nBands : 0;
+    for(int t = tid; t < bw * nBands; t += kThreads)
     {
-      const int ry = idx / bw;
-      const int y = by0 + ry, c = bc0 + (idx - ry * bw);
-      const unsigned long long cw = closed_word(im, y, c);
-      if(dbgImg)
+      const int band = t / bw;
+      const int c = bc0 + (t - band * bw);
+      const int yA = by0 + band * bandRows, yB = min(yA + bandRows, by1 + 1);
+      closed_column(im, c, yA, yB, dbgImg != nullptr, [&](int y, unsigned long long cw)
       {
-        dbgRaw[y * P.W64 + c] = img[y * P.W64 + c];
-        dbgClosed[y * P.W64 + c] = cw;
-      }
-      if(cw == 0ull || y <= yStop)
-        continue;
-      const int x0 = 64 * c;
-      int j = x0 <= xr0 ? 0 : (x0 - xr0 + xStep - 1) / xStep;
-      for(int x = xr0 + xStep * j; x < x0 + 64 && j < nCols; x += xStep, j++)
-        if((cw >> (x - x0)) & 1ull)
-          atomicMax(&S.yEdge[j], y);
+        if(dbgImg)
+        {
+          dbgRaw[y * P.W64 + c] = img[y * P.W64 + c];
+          dbgClosed[y * P.W64 + c] = cw;
+        }
+        if(cw == 0ull || y <= yStop)
+          return;
+        const int x0 = 64 * c;
+        int j = x0 <= xr0 ? 0 : (x0 - xr0 + xStep - 1) / xStep;
+        for(int x = xr0 + xStep * j; x < x0 + 64 && j < nCols; x += xStep, j++)
+          if((cw >> (x - x0)) & 1ull)
+            atomicMax(&S.yEdge[j], y);
+      });
     }
     __syncthreads();
 
@@ -1937,7 +2024,7 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
     __syncthreads();
     if(S.n >= 2 && wave == 0)
     {
-      const LineI l = wave_best_line(S.px, S.py, S.n, lane);
+      const LineI l = wave_best_line(S.px, S.py, S.n, lane, 3ll * P.W * P.H < (1ll << 25));
       if(lane == 0)
         S.line = l;
     }
