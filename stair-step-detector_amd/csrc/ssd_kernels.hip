@@ -1633,93 +1633,90 @@ __device__ __forceinline__ bool quad_test(const QuadTest &t, double x, double y)
   return ok;
 }
 
-__global__ void k_quads(Params P, FrameState *__restrict__ st, int nframes, DebugFrame *__restrict__ dbg)
+/* one wave per frame: lane k < kMaxPlateaus builds the test of plateau k, lane kGroundAcc the ground's */
+__global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__ st, int nframes, DebugFrame *__restrict__ dbg)
 {
-  const int frame = blockIdx.x * blockDim.x + threadIdx.x;
+  static_assert(kMaxPlateaus + 1 <= 64, "one lane per accumulator");
+  const int frame = blockIdx.x, lane = threadIdx.x;
   if(frame >= nframes)
     return;
   FrameState &fs = st[frame];
-  for(int k = 0; k <= kMaxPlateaus; k++)
+  if(lane <= kMaxPlateaus)
   {
-    fs.accActive[k] = 0;
-    fs.sumZ[k] = 0;
-    fs.cnt[k] = 0;
+    fs.sumZ[lane] = 0;
+    fs.cnt[lane] = 0;
   }
   const int first = fs.firstStep, last = fs.firstStep + fs.nStepImages;
-  int firstValid = -1;
-  for(int k = first; k < last; k++)
-    if(fs.pl[k].valid)
-    {
-      firstValid = k;
-      break;
-    }
-  fs.firstValidInd = firstValid;
-  bool threw = false;
-  if(firstValid >= 0)
+  const int groundInd = fs.groundInd;
+  const bool valid = lane >= first && lane < last && lane < kMaxPlateaus && fs.pl[lane].valid;
+  const unsigned long long validMask = __ballot(valid);
+  const int firstValid = validMask ? __ffsll(static_cast<long long>(validMask)) - 1 : -1;
+  const bool groundLane = lane == kGroundAcc && firstValid >= 0 && groundInd >= 0;
+  int err = 0;
+  if(groundLane)
   {
-    if(fs.groundInd >= 0)
+    /* calcGroundQuadrilateral (pointcloud.cpp:489-512) */
+    const double *q = fs.pl[firstValid].quadWorld;
+    const double yMin = P.yMin;
+    double *g = fs.groundQuadWorld;
+    if(q[1] < q[3])
     {
-      /* calcGroundQuadrilateral (pointcloud.cpp:489-512) */
-      const double *q = fs.pl[firstValid].quadWorld;
-      const double yMin = P.yMin;
-      double *g = fs.groundQuadWorld;
-      if(q[1] < q[3])
-      {
-        g[0] = q[0]; g[1] = yMin;
-        g[2] = q[2] + (q[3] - yMin) * (q[3] - q[1]) / (q[2] - q[0]); g[3] = yMin;
-      }
-      else
-      {
-        g[0] = q[0] + (q[1] - yMin) * (q[1] - q[3]) / (q[0] - q[2]); g[1] = yMin;
-        g[2] = q[2]; g[3] = yMin;
-      }
-      g[4] = q[0]; g[5] = q[1];
-      g[6] = q[2]; g[7] = q[3];
-      build_quad_test(g, fs.qt[kGroundAcc]);
-      if(fs.qt[kGroundAcc].err)
-        threw = true;
-      else
-        fs.accActive[kGroundAcc] = 1;
+      g[0] = q[0]; g[1] = yMin;
+      g[2] = q[2] + (q[3] - yMin) * (q[3] - q[1]) / (q[2] - q[0]); g[3] = yMin;
     }
-    for(int k = firstValid; k < last; k++)
+    else
     {
-      if(!fs.pl[k].valid)
-        continue;
-      build_quad_test(fs.pl[k].quadWorld, fs.qt[k]);
-      if(fs.qt[k].err)
-        threw = true;
-      else
-        fs.accActive[k] = 1;
+      g[0] = q[0] + (q[1] - yMin) * (q[1] - q[3]) / (q[0] - q[2]); g[1] = yMin;
+      g[2] = q[2]; g[3] = yMin;
     }
+    g[4] = q[0]; g[5] = q[1];
+    g[6] = q[2]; g[7] = q[3];
+    build_quad_test(g, fs.qt[kGroundAcc]);
+    err = fs.qt[kGroundAcc].err;
   }
-  if(threw)
+  else if(valid)
   {
-    fs.status |= SSD_ST_THROW;
-    for(int k = 0; k <= kMaxPlateaus; k++)
-      fs.accActive[k] = 0;
+    build_quad_test(fs.pl[lane].quadWorld, fs.qt[lane]);
+    err = fs.qt[lane].err;
   }
+  /* one quadrilateral the reference would throw on ends the frame (quadrilateralTest.cpp:283-372) */
+  const bool threw = __ballot(err != 0) != 0ull;
+  const bool active = (groundLane || valid) && !threw;
+  if(lane <= kMaxPlateaus)
+    fs.accActive[lane] = active ? 1 : 0;
+  const unsigned long long activeMask = __ballot(active);
+
+  unsigned int wanted = 0u;
+  for(int b = lane; b < P.nBins; b += 64)
   {
-    unsigned int wanted = 0u, any = 0u;
-    for(int k = 0; k <= kMaxPlateaus; k++)
-      any |= fs.accActive[k];
-    for(int b = 0; b < P.nBins; b++)
-    {
-      const int p = fs.lut[b];
-      if(p != 0xff && fs.accActive[p == fs.groundInd ? kGroundAcc : p])
-        wanted |= 1u << (b / kBinsPerGroup);
-    }
+    const int p = fs.lut[b];
+    if(p != 0xff && ((activeMask >> (p == groundInd ? kGroundAcc : p)) & 1ull))
+      wanted |= 1u << (b / kBinsPerGroup);
+  }
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1)
+    wanted |= __shfl_xor(wanted, o);
+  if(lane == 0)
+  {
+    fs.firstValidInd = firstValid;
+    if(threw)
+      fs.status |= SSD_ST_THROW;
     fs.wantedQuads = wanted;
-    fs.anyActive = any;
+    fs.anyActive = activeMask != 0ull ? 1u : 0u;
   }
   if(dbg)
   {
     ssd_debug_frame &d = dbg[frame].d;
-    d.first_valid_ind = firstValid;
-    for(int k = 0; k < 8; k++)
-      d.ground_quad_world[k] = (firstValid >= 0 && fs.groundInd >= 0) ? fs.groundQuadWorld[k] : 0.0;
-    d.ground_quad_err = (firstValid >= 0 && fs.groundInd >= 0) ? fs.qt[kGroundAcc].err : 0;
-    for(int k = first; k < last; k++)
-      d.plateaus[k].quad_err = (firstValid >= 0 && k >= firstValid && fs.pl[k].valid) ? fs.qt[k].err : 0;
+    if(lane == 0)
+      d.first_valid_ind = firstValid;
+    if(lane == kGroundAcc)
+    {
+      for(int k = 0; k < 8; k++)
+        d.ground_quad_world[k] = groundLane ? fs.groundQuadWorld[k] : 0.0;
+      d.ground_quad_err = groundLane ? err : 0;
+    }
+    if(lane >= first && lane < last && lane < kMaxPlateaus)
+      d.plateaus[lane].quad_err = valid ? err : 0;
   }
 }
 
@@ -2255,7 +2252,7 @@ void launch_outline(const Params &P, FrameState *st, unsigned long long *stepImg
 }
 void launch_quads(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_quads, dim3((nframes + 63) / 64), dim3(64), 0, s, P, st, nframes, dbg);
+  hipLaunchKernelGGL(k_quads, dim3(nframes), dim3(64), 0, s, P, st, nframes, dbg);
 }
 void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *groundImg,
                    const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
