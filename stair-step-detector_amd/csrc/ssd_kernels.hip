@@ -252,156 +252,197 @@ __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ 
 /* ========================================================================= */
 /* K1b: peaks, plateaus, LUT — one thread per frame (121 bins: trivial)        */
 
-__global__ void k_peaks(Params P, FrameState *__restrict__ st, int nframes, DebugFrame *__restrict__ dbg)
+/* one wave per frame: the histogram is staged in LDS, lane 0 walks it (the peak / plateau logic is a
+ * sequential scan with carried state), all lanes write the tables out */
+__global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__ st, int nframes, DebugFrame *__restrict__ dbg)
 {
-  const int frame = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ unsigned int hist[kMaxBins + 1];
+  __shared__ unsigned char lut[kMaxBins];
+  __shared__ int plPeak[kMaxPlateaus], plLo[kMaxPlateaus], plHi[kMaxPlateaus], plEffLo[kMaxPlateaus], plEffHi[kMaxPlateaus], plN[kMaxPlateaus];
+  __shared__ int dbgPeaks[kMaxPlateaus];
+  __shared__ int sNPl, sNPeaks, sOverflow, sGround, sFirstStep, sNImg;
+
+  const int frame = blockIdx.x, lane = threadIdx.x;
   if(frame >= nframes)
     return;
   FrameState &fs = st[frame];
-  const unsigned int *hist = fs.hist;
   const int nb = P.nBins;
 
   unsigned int total = 0;
-  for(int i = 0; i < nb; i++)
-    total += hist[i];
-  fs.nInRange = total;
-  for(int i = 0; i < kMaxBins; i++)
-    fs.lut[i] = 0xff;
-
-  /* findPeaks (pointcloud.cpp:214-241) + filterPeaks (:243-256) */
-  int nPl = 0;
-  int consumedUpTo = -1;           /* every bin <= this has already left pointsHt */
-  bool ascending = false, overflow = false;
-  int nPeaksDbg = 0;
-  for(int i = 0; i < nb - 1; i++)
+  for(int b = lane; b <= kMaxBins; b += 64)
   {
-    const unsigned int curr = hist[i], succ = hist[i + 1];
-    if(curr < succ)
+    const unsigned int v = b < nb ? fs.hist[b] : 0u;
+    hist[b] = v;
+    total += v;
+    if(b < kMaxBins)
+      lut[b] = 0xff;
+  }
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1)
+    total += __shfl_xor(total, o);
+  __syncthreads();
+
+  if(lane == 0)
+  {
+    /* findPeaks (pointcloud.cpp:214-241) + filterPeaks (:243-256) */
+    int nPl = 0;
+    int consumedUpTo = -1;           /* every bin <= this has already left pointsHt */
+    bool ascending = false, overflow = false;
+    int nPeaksDbg = 0;
+    unsigned int curr = hist[0];
+    for(int i = 0; i < nb - 1; i++)
     {
-      ascending = true;
-      continue;
-    }
-    if(curr > succ)
-    {
-      if(ascending)
+      const unsigned int succ = hist[i + 1];
+      const unsigned int c = curr;
+      curr = succ;
+      if(c < succ)
       {
-        const unsigned int np = curr;
-        if(np >= 2000u && (np * 2u - hist[i - 1] - hist[i + 1]) * 2u > np)
+        ascending = true;
+        continue;
+      }
+      if(c > succ)
+      {
+        if(ascending)
         {
-          if(dbg && nPeaksDbg < kMaxPlateaus)
-            dbg[frame].d.peaks[nPeaksDbg] = i;
-          nPeaksDbg++;
-          if(nPl >= kMaxPlateaus)
-            overflow = true;
-          else
+          const unsigned int np = c;
+          if(np >= 2000u && (np * 2u - hist[i - 1] - succ) * 2u > np)
           {
-            /* extractPlateauPoints (:300-335): choose the pair, then take what is left of it */
-            PlateauState &pl = fs.pl[nPl];
-            int hMin, hMax;
-            if(hist[i - 1] > hist[i + 1]) { hMin = i - 1; hMax = i; }
-            else { hMin = i; hMax = i + 1; }
-            pl.peakBin = i;
-            pl.binLo = hMin;
-            pl.binHi = hMax;
-            int lo, hi;
-            if(hMin == 0)
-            {
-              /* quirk Q4: Height_t(heightMin - 1) wraps to 65535: everything goes to the remainder */
-              lo = 1; hi = 0;
-              consumedUpTo = nb;
-            }
+            if(nPeaksDbg < kMaxPlateaus)
+              dbgPeaks[nPeaksDbg] = i;
+            nPeaksDbg++;
+            if(nPl >= kMaxPlateaus)
+              overflow = true;
             else
             {
-              lo = max(hMin, consumedUpTo + 1);
-              hi = hMax;
-              consumedUpTo = max(consumedUpTo, hMax);
+              /* extractPlateauPoints (:300-335): choose the pair, then take what is left of it */
+              int hMin, hMax;
+              if(hist[i - 1] > succ) { hMin = i - 1; hMax = i; }
+              else { hMin = i; hMax = i + 1; }
+              int lo, hi;
+              if(hMin == 0)
+              {
+                /* quirk Q4: Height_t(heightMin - 1) wraps to 65535: everything goes to the remainder */
+                lo = 1; hi = 0;
+                consumedUpTo = nb;
+              }
+              else
+              {
+                lo = max(hMin, consumedUpTo + 1);
+                hi = hMax;
+                consumedUpTo = max(consumedUpTo, hMax);
+              }
+              unsigned int cnt = 0;
+              for(int b = lo; b <= hi; b++)
+              {
+                cnt += hist[b];
+                lut[b] = static_cast<unsigned char>(nPl);
+              }
+              plPeak[nPl] = i; plLo[nPl] = hMin; plHi[nPl] = hMax; plEffLo[nPl] = lo; plEffHi[nPl] = hi;
+              plN[nPl] = static_cast<int>(cnt);
+              nPl++;
             }
-            pl.effLo = lo;
-            pl.effHi = hi;
-            unsigned int cnt = 0;
-            for(int b = lo; b <= hi; b++)
-            {
-              cnt += hist[b];
-              fs.lut[b] = static_cast<unsigned char>(nPl);
-            }
-            pl.nPoints = static_cast<int>(cnt);
-            pl.isStep = i >= P.minHeight ? 1 : 0;
-            pl.outlineFound = 0;
-            pl.valid = 0;
-            for(int k = 0; k < 8; k++) { pl.quadImg[k] = 0.0; pl.quadWorld[k] = 0.0; }
-            nPl++;
           }
         }
+        ascending = false;
       }
-      ascending = false;
     }
-  }
-  fs.nPlateaus = nPl;
 
-  /* ground = most populous plateau below minHeight (pointcloud.cpp:402-418) */
-  int groundInd = -1, i = 0;
-  unsigned int maxGround = 0;
-  for( ; i < nPl; i++)
-  {
-    if(fs.pl[i].peakBin >= P.minHeight)
-      break;
-    if(maxGround < static_cast<unsigned int>(fs.pl[i].nPoints))
+    /* ground = most populous plateau below minHeight (pointcloud.cpp:402-418) */
+    int groundInd = -1, i = 0;
+    unsigned int maxGround = 0;
+    for( ; i < nPl; i++)
     {
-      maxGround = static_cast<unsigned int>(fs.pl[i].nPoints);
-      groundInd = i;
+      if(plPeak[i] >= P.minHeight)
+        break;
+      if(maxGround < static_cast<unsigned int>(plN[i]))
+      {
+        maxGround = static_cast<unsigned int>(plN[i]);
+        groundInd = i;
+      }
     }
-  }
-  fs.groundInd = groundInd;
-  fs.firstStep = i;
-  int nImg = nPl - i;
-  if(nImg > P.maxStepImages)
-  {
-    nImg = P.maxStepImages;
-    overflow = true;
-  }
-  fs.nStepImages = nImg;
-  fs.firstValidInd = -1;
-  {
-    unsigned int wanted = 0u;
-    for(int b = 0; b < nb; b++)
+    int nImg = nPl - i;
+    if(nImg > P.maxStepImages)
     {
-      const int slot = static_cast<int>(fs.lut[b]) - i;
-      if(fs.lut[b] != 0xff && slot >= 0 && slot < nImg)
-        wanted |= 1u << (b / kBinsPerGroup);
+      nImg = P.maxStepImages;
+      overflow = true;
     }
+    sNPl = nPl; sNPeaks = nPeaksDbg; sOverflow = overflow ? 1 : 0; sGround = groundInd; sFirstStep = i; sNImg = nImg;
+  }
+  __syncthreads();
+
+  const int nPl = sNPl, firstStep = sFirstStep, nImg = sNImg;
+  unsigned int wanted = 0u;
+  for(int b = lane; b < kMaxBins; b += 64)
+  {
+    const unsigned char l = lut[b];
+    fs.lut[b] = l;
+    const int slot = static_cast<int>(l) - firstStep;
+    if(b < nb && l != 0xff && slot >= 0 && slot < nImg)
+      wanted |= 1u << (b / kBinsPerGroup);
+  }
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1)
+    wanted |= __shfl_xor(wanted, o);
+  if(lane < nPl)
+  {
+    PlateauState &pl = fs.pl[lane];
+    pl.peakBin = plPeak[lane];
+    pl.binLo = plLo[lane];
+    pl.binHi = plHi[lane];
+    pl.effLo = plEffLo[lane];
+    pl.effHi = plEffHi[lane];
+    pl.nPoints = plN[lane];
+    pl.isStep = plPeak[lane] >= P.minHeight ? 1 : 0;
+    pl.outlineFound = 0;
+    pl.valid = 0;
+    for(int k = 0; k < 8; k++) { pl.quadImg[k] = 0.0; pl.quadWorld[k] = 0.0; }
+  }
+  if(lane <= kMaxStepImages)                          /* [kMaxStepImages] = the ground image */
+  {
+    fs.imgYMin[lane] = 0x7fffffff; fs.imgYMax[lane] = -1;
+    fs.imgXMin[lane] = 0x7fffffff; fs.imgXMax[lane] = -1;
+  }
+  if(lane == 0)
+  {
+    fs.nInRange = total;
+    fs.nPlateaus = nPl;
+    fs.groundInd = sGround;
+    fs.firstStep = firstStep;
+    fs.nStepImages = nImg;
+    fs.firstValidInd = -1;
     fs.wantedSteps = wanted;
     fs.wantedQuads = 0u;
     fs.anyActive = 0u;
+    if(sOverflow)
+      fs.status |= SSD_ST_OVERFLOW;
   }
-  for(int k = 0; k <= kMaxStepImages; k++)          /* [kMaxStepImages] = the ground image */
-  {
-    fs.imgYMin[k] = 0x7fffffff; fs.imgYMax[k] = -1;
-    fs.imgXMin[k] = 0x7fffffff; fs.imgXMax[k] = -1;
-  }
-  if(overflow)
-    fs.status |= SSD_ST_OVERFLOW;
 
   if(dbg)
   {
     ssd_debug_frame &d = dbg[frame].d;
-    d.n_nonzero = static_cast<int>(fs.nNonZero);
-    d.n_inrange = static_cast<int>(total);
-    d.n_bins = nb;
-    d.min_height = P.minHeight;
-    d.min_img_y_extent = P.minImgYExtent;
-    for(int b = 0; b < kMaxBins; b++)
-      d.hist[b] = b < nb ? hist[b] : 0u;
-    d.n_peaks = nPeaksDbg;
-    d.n_plateaus = nPl;
-    d.first_step = i;
-    d.ground_ind = groundInd;
-    for(int k = 0; k < nPl; k++)
+    for(int b = lane; b < kMaxBins; b += 64)
+      d.hist[b] = hist[b];
+    if(lane < min(sNPeaks, kMaxPlateaus))
+      d.peaks[lane] = dbgPeaks[lane];
+    if(lane < nPl)
     {
-      ssd_debug_plateau &p = d.plateaus[k];
-      p.peak_bin = fs.pl[k].peakBin; p.bin_lo = fs.pl[k].binLo; p.bin_hi = fs.pl[k].binHi;
-      p.eff_lo = fs.pl[k].effLo; p.eff_hi = fs.pl[k].effHi;
-      p.n_points = fs.pl[k].nPoints;
-      p.is_step = fs.pl[k].isStep;
+      ssd_debug_plateau &p = d.plateaus[lane];
+      p.peak_bin = plPeak[lane]; p.bin_lo = plLo[lane]; p.bin_hi = plHi[lane];
+      p.eff_lo = plEffLo[lane]; p.eff_hi = plEffHi[lane];
+      p.n_points = plN[lane];
+      p.is_step = plPeak[lane] >= P.minHeight ? 1 : 0;
+    }
+    if(lane == 0)
+    {
+      d.n_nonzero = static_cast<int>(fs.nNonZero);
+      d.n_inrange = static_cast<int>(total);
+      d.n_bins = nb;
+      d.min_height = P.minHeight;
+      d.min_img_y_extent = P.minImgYExtent;
+      d.n_peaks = sNPeaks;
+      d.n_plateaus = nPl;
+      d.first_step = firstStep;
+      d.ground_ind = sGround;
     }
   }
 }
@@ -2232,7 +2273,7 @@ void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameSt
 }
 void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_peaks, dim3((nframes + 63) / 64), dim3(64), 0, s, P, st, nframes, dbg);
+  hipLaunchKernelGGL(k_peaks, dim3(nframes), dim3(64), 0, s, P, st, nframes, dbg);
 }
 void launch_raster(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *stepImg,
                    const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
