@@ -1697,7 +1697,9 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
   if(groundLane)
   {
     /* calcGroundQuadrilateral (pointcloud.cpp:489-512) */
-    const double *q = fs.pl[firstValid].quadWorld;
+    double q[4];
+    for(int k = 0; k < 4; k++)
+      q[k] = fs.pl[firstValid].quadWorld[k];
     const double yMin = P.yMin;
     double *g = fs.groundQuadWorld;
     if(q[1] < q[3])
@@ -1712,13 +1714,18 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
     }
     g[4] = q[0]; g[5] = q[1];
     g[6] = q[2]; g[7] = q[3];
-    build_quad_test(g, fs.qt[kGroundAcc]);
-    err = fs.qt[kGroundAcc].err;
   }
-  else if(valid)
+  if(groundLane || valid)
   {
-    build_quad_test(fs.pl[lane].quadWorld, fs.qt[lane]);
-    err = fs.qt[lane].err;
+    /* built in private memory, stored once: the builder re-reads what it writes */
+    double quad[8];
+    QuadTest t;
+    const double *src = groundLane ? fs.groundQuadWorld : fs.pl[lane].quadWorld;
+    for(int k = 0; k < 8; k++)
+      quad[k] = src[k];
+    build_quad_test(quad, t);
+    err = t.err;
+    fs.qt[groundLane ? kGroundAcc : lane] = t;
   }
   /* one quadrilateral the reference would throw on ends the frame (quadrilateralTest.cpp:283-372) */
   const bool threw = __ballot(err != 0) != 0ull;
