@@ -409,7 +409,7 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   HIP_TRY_H(hipMemset(h->dResults, 0, sizeof(ssd_frame_result) * h->F));
   HIP_TRY_H(hipDeviceSynchronize());
 #undef HIP_TRY_H
-  h->bytes = sizeof(FrameState) * h->F + stepBytes + groundBytes + sizeof(ssd_frame_result) * h->F;
+  h->bytes = sizeof(FrameState) * h->F + stepBytes + groundBytes + h->tileMaskStride * 4 * h->F + sizeof(ssd_frame_result) * h->F;
   *out = h;
   return SSD_OK;
 }
@@ -463,9 +463,21 @@ int ssd_set_timing(ssd_handle *h, int enable)
   HIP_TRY(hipSetDevice(h->device));
   if(enable && h->ev.empty())
   {
-    h->ev.resize(static_cast<size_t>(SSD_TIMING_SLOTS) * 8);
-    for(hipEvent_t &e : h->ev)
-      HIP_TRY(hipEventCreate(&e));
+    std::vector<hipEvent_t> ev;
+    ev.reserve(static_cast<size_t>(SSD_TIMING_SLOTS) * 8);
+    for(size_t i = 0; i < static_cast<size_t>(SSD_TIMING_SLOTS) * 8; i++)
+    {
+      hipEvent_t e;
+      const hipError_t rc = hipEventCreate(&e);
+      if(rc != hipSuccess)
+      {
+        for(hipEvent_t made : ev)
+          (void)hipEventDestroy(made);
+        return fail(SSD_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(rc));
+      }
+      ev.push_back(e);
+    }
+    h->ev.swap(ev);
   }
   h->timing = enable != 0;
   h->timedFrom = h->enqueueCount;

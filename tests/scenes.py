@@ -1,6 +1,9 @@
 """Named synthetic scenes shared by the CPU and GPU tests (SURVEY.md section 8(c) fixture set, BASELINE.json configs)."""
 
-RES = {"vga": (640, 480), "xga": (1024, 768), "fhd": (1920, 1080)}
+RES = {"vga": (640, 480), "xga": (1024, 768), "fhd": (1920, 1080),
+       # ragged: width not a multiple of 64 (partial last image word), point count not a multiple of the 1024-point
+       # block tile / of 4 (12-byte load path, partial last tile)
+       "r600": (600, 450), "r427": (427, 321), "r1100": (1100, 700)}
 
 
 def scene_params():
@@ -35,6 +38,9 @@ def scene_params():
     p["vga_yaw30_narrow"] = ("vga", dict(n_steps=3, sigma=0.002, seed=100, yaw_deg=30.0, stair_width=0.5))
     p["vga_yaw40_wide_throws"] = ("vga", dict(n_steps=3, sigma=0.002, seed=100, yaw_deg=40.0, stair_width=1.1))
     p["vga_yaw50_throws"] = ("vga", dict(n_steps=3, sigma=0.002, seed=101, yaw_deg=50.0, stair_width=0.8))
+    p["ragged_600x450"] = ("r600", dict(n_steps=3, sigma=0.001, seed=21))
+    p["ragged_427x321_yaw"] = ("r427", dict(n_steps=3, sigma=0.001, seed=22, yaw_deg=5.0))
+    p["ragged_1100x700_outliers"] = ("r1100", dict(n_steps=4, sigma=0.002, seed=23, outlier_frac=0.03, rise=0.15, tread=0.26))
     p["xga_2steps_deep"] = ("xga", dict(n_steps=2, sigma=0.002, seed=19, tread=0.4, rise=0.19, first_riser_y=0.35))
     return p
 

@@ -183,7 +183,7 @@ def test_detect_stairs_driver_prints_the_reference_line(ssd, oracle, gpu_device)
         assert out[f] == res.line.decode()
 
 
-DEPTH_SCENES = ["vga_3steps_noise2mm", "xga_config1", "xga_yaw_p8", "vga_8steps_outliers", "fhd_3steps_noise2mm", "xga_no_stairs"]
+DEPTH_SCENES = ["vga_3steps_noise2mm", "xga_config1", "xga_yaw_p8", "vga_8steps_outliers", "fhd_3steps_noise2mm", "xga_no_stairs", "ragged_600x450"]
 
 
 @pytest.mark.parametrize("name", DEPTH_SCENES)
