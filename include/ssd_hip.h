@@ -268,6 +268,10 @@ int ssd_device_sync(int device);
 /* test hooks: std::hypot as the kernels compute it (glibc 2.35 algorithm restated), host and device */
 double ssd_test_hypot_host(double a, double b);
 int ssd_test_hypot_device(int device, const double *a, const double *b, double *out, int n);
+/* test hook: the raw per-frame device state after the last enqueue (layout private to the library; layout[0..7] =
+ * sizeof state, offsets of hist, lut, image boxes, plateau table, quadrilateral tests, sums, counts); returns the
+ * number of bytes copied or a negative error */
+long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, long long layout[8]);
 
 #ifdef __cplusplus
 }

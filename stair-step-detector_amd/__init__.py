@@ -120,7 +120,7 @@ EXPORTS = [
     "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
     "ssd_synth_generate_host", "ssd_synth_generate_device", "ssd_synth_scene_to_camera",
     "ssd_device_count", "ssd_device_alloc", "ssd_device_free", "ssd_device_upload", "ssd_device_download",
-    "ssd_device_sync", "ssd_test_hypot_host", "ssd_test_hypot_device",
+    "ssd_device_sync", "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state",
 ]
 
 _lib = None
@@ -174,6 +174,8 @@ def lib():
     L.ssd_test_hypot_host.restype = C.c_double
     L.ssd_test_hypot_host.argtypes = [C.c_double, C.c_double]
     L.ssd_test_hypot_device.argtypes = [i32, vp, vp, vp, i32]
+    L.ssd_test_frame_state.argtypes = [vp, i32, vp, C.c_size_t, vp]
+    L.ssd_test_frame_state.restype = C.c_longlong
     _lib = L
     return L
 
@@ -332,6 +334,16 @@ class Detector:
         d = DebugFrame()
         _check(lib().ssd_get_debug(self._h, frame, C.byref(d)))
         return d
+
+    def frame_state(self, frame):
+        """test hook: raw device state of one frame after the last enqueue -> (bytes, layout dict)"""
+        lay = (C.c_longlong * 8)()
+        buf = C.create_string_buffer(1 << 16)
+        n = lib().ssd_test_frame_state(self._h, frame, buf, len(buf), lay)
+        if n < 0:
+            raise RuntimeError(last_error())
+        names = ("size", "hist", "lut", "boxes", "plateaus", "quad_tests", "sum_z", "cnt")
+        return buf.raw[:n], dict(zip(names, [int(x) for x in lay]))
 
     def debug_image(self, frame, step_slot, closed):
         out = np.empty((self.cfg.height, self.cfg.width), dtype=np.uint8)

@@ -9,6 +9,7 @@
 #include "ssd_synth.h"
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -975,6 +976,28 @@ double ssd_test_hypot_host(double a, double b)
 {
   return hypot_ref_host(a, b);
 }
+long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, long long layout[8])
+{
+  if(!h || !out || frame < 0 || frame >= h->F)
+    return fail(SSD_E_ARG, "ssd_test_frame_state: bad argument");
+  if(layout)
+  {
+    layout[0] = sizeof(FrameState);
+    layout[1] = offsetof(FrameState, hist);
+    layout[2] = offsetof(FrameState, lut);
+    layout[3] = offsetof(FrameState, imgYMin);
+    layout[4] = offsetof(FrameState, pl);
+    layout[5] = offsetof(FrameState, qt);
+    layout[6] = offsetof(FrameState, sumZ);
+    layout[7] = offsetof(FrameState, cnt);
+  }
+  const size_t n = cap < sizeof(FrameState) ? cap : sizeof(FrameState);
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, h->dState + frame, n, hipMemcpyDeviceToHost));
+  return static_cast<long long>(n);
+}
+
 int ssd_test_hypot_device(int device, const double *a, const double *b, double *out, int n)
 {
   if(ssd_device_count() <= 0)

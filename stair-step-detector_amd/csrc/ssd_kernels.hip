@@ -765,6 +765,21 @@ __device__ __forceinline__ unsigned long long closed_from_rows(const BitImg &im,
   return res;
 }
 
+/* a bounding box of raw bits (rows by0..by1, word columns ..bc1; word column 0 holds x = 0 and x = 1 alike) ->
+ * the box its closing can reach: one more row / the last word column when the bits come within one pixel of
+ * the image border, where the erosion has no out-of-image neighbour to veto it */
+__device__ __forceinline__ void grow_box_to_border(int W, int H, int W64, int &by0, int &by1, int &bc1)
+{
+  if(by1 < by0)
+    return;
+  if(by0 == 1)
+    by0 = 0;
+  if(by1 == H - 2)
+    by1 = H - 1;
+  if(bc1 == W64 - 2 && ((W - 1) & 63) == 0)
+    bc1 = W64 - 1;
+}
+
 __device__ unsigned long long closed_word(const BitImg &im, int y, int c)
 {
   HRow h[5];
@@ -1069,10 +1084,13 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
     dbgRaw = dbgImg + ((static_cast<size_t>(frame) * (P.maxStepImages + 1) + slot) * 2) * imgWords;
     dbgClosed = dbgRaw + imgWords;
   }
-  /* the closing of a set never leaves the bounding box of the set: only that window is visited
-   * (with debug capture on, the whole image, so that the captured images are complete) */
+  /* Only the bounding box of the raw bits is visited (with debug capture on, the whole image, so that the
+   * captured images are complete).  The closing of a set stays inside the set's bounding box — except along
+   * the image border: the erosion ignores out-of-image pixels (segmentation.cpp:888,928, default border), so a
+   * lit pixel one row / column away from the border closes the border pixel next to it as well. */
   int by0 = fs.imgYMin[slot], by1 = fs.imgYMax[slot], bc0 = fs.imgXMin[slot], bc1 = fs.imgXMax[slot];
   const bool emptyImg = by1 < by0;
+  grow_box_to_border(P.W, P.H, P.W64, by0, by1, bc1);
   if(dbgImg)
   {
     by0 = 0; by1 = P.H - 1; bc0 = 0; bc1 = P.W64 - 1;
@@ -2012,6 +2030,7 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
     int by0 = fs.imgYMin[kMaxStepImages], by1 = fs.imgYMax[kMaxStepImages];
     int bc0 = fs.imgXMin[kMaxStepImages], bc1 = fs.imgXMax[kMaxStepImages];
     const bool emptyImg = by1 < by0;
+    grow_box_to_border(P.W, P.H, P.W64, by0, by1, bc1);
     if(dbgImg)
     {
       by0 = 0; by1 = P.H - 1; bc0 = 0; bc1 = P.W64 - 1;

@@ -158,11 +158,12 @@ def check_results_only(ssd, oracle, cfg, cal, xyz, fr, report=None):
     n, steps, status = oracle.process_lean(ocfg, ocal, xyz)
     _eq("status", fr.status, status)
     _eq("n_steps", fr.n_steps, n)
+    for i in range(n):                       # corners first: a moved corner also moves the height, not the other way round
+        report["max_corner_err"] = max(report.get("max_corner_err", 0.0),
+                                       _close("step[%d].quad" % i, list(fr.steps[i].quad), list(steps[i][1:9]), 1e-9))
     for i in range(n):
         report["max_height_err"] = max(report.get("max_height_err", 0.0),
                                        _close("step[%d].height" % i, fr.steps[i].height, steps[i][0], TOL_HEIGHT))
-        report["max_corner_err"] = max(report.get("max_corner_err", 0.0),
-                                       _close("step[%d].quad" % i, list(fr.steps[i].quad), list(steps[i][1:9]), 1e-9))
     if not (status & ob.ST_THROW):
         _eq("line", ssd.Stairs(fr).serialize(), oracle.serialize(steps) if n else '["stairs",["stairSteps",0]]')
     return report

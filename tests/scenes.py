@@ -41,6 +41,11 @@ def scene_params():
     p["ragged_600x450"] = ("r600", dict(n_steps=3, sigma=0.001, seed=21))
     p["ragged_427x321_yaw"] = ("r427", dict(n_steps=3, sigma=0.001, seed=22, yaw_deg=5.0))
     p["ragged_1100x700_outliers"] = ("r1100", dict(n_steps=4, sigma=0.002, seed=23, outlier_frac=0.03, rise=0.15, tread=0.26))
+    # found by tools/fuzz.py (seed 20261003): an outlier pixel on image row 1 / H-2 of a scan column — the 3x3 closing
+    # also lights the border pixel next to it (the erosion ignores out-of-image neighbours), i.e. a pixel OUTSIDE
+    # the bounding box of the raw bits
+    p["fuzz_border_closing_0"] = ("vga", dict(n_steps=7, seed=753523895, cam_height=1.136752425315668, pitch_deg=38.99284936887012, roll_deg=2.1667327820945097, first_riser_y=0.4482937595916664, tread=0.27404233006301326, rise=0.08003462791607925, stair_width=0.9418650935580659, yaw_deg=1.4481814211961677, sigma=0.0028683304688289285, outlier_frac=0.15, invalid_frac=0.0))
+    p["fuzz_border_closing_1"] = ("r600", dict(n_steps=5, seed=80944533, cam_height=1.263229686152806, pitch_deg=39.68055021127778, roll_deg=1.3312143909189542, first_riser_y=0.2255171024398212, tread=0.34592134937750907, rise=0.10170513268147316, stair_width=1.2994579211897062, yaw_deg=-3.5375798031106402, sigma=0.0029247316800371462, outlier_frac=0.05, invalid_frac=0.0))
     p["xga_2steps_deep"] = ("xga", dict(n_steps=2, sigma=0.002, seed=19, tread=0.4, rise=0.19, first_riser_y=0.35))
     return p
 

@@ -33,6 +33,20 @@ def test_frame_parity_all_intermediates(ssd, oracle, gpu_device, name):
     assert rep.get("max_corner_err", 0.0) <= 1e-9
 
 
+@pytest.mark.parametrize("name", SCENES)
+def test_frame_results_without_debug_capture(ssd, oracle, gpu_device, name):
+    """The production path (no debug capture: closing and scans only inside the bounding boxes of the raw bits, images
+    never copied out) against the oracle's result: status, steps, heights, corners, serialized line."""
+    sc, trans, cfg = _setup(ssd, name)
+    xyz = ssd.synth_host([sc])[0]
+    det = ssd.Detector(cfg, trans, gpu_device)
+    fr = det.process_host(xyz)[0]
+    det.close()
+    rep = parity.check_results_only(ssd, oracle, cfg, trans.constants, xyz, fr)
+    assert rep.get("max_height_err", 0.0) <= parity.TOL_HEIGHT
+    assert rep.get("max_corner_err", 0.0) == 0.0
+
+
 def test_scene_set_covers_the_interesting_outcomes(ssd, oracle):
     """Guards the fixture set itself (oracle only): it must contain N=0 lines, ground+steps, invalid plateaus."""
     outcomes = set()

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""tools/fuzz.py [N_POSES] [FRAMES_PER_POSE] [SEED] — randomised parity sweep on the GPU box: random camera poses, stair
+geometries, yaw up to +-45 degrees, roll, noise, outliers, invalid pixels, 0-8 steps, three resolutions (incl. a ragged
+one); every frame's HIP result (batch path) against the CPU oracle's.  TEST INFRASTRUCTURE (uses oracle/)."""
+import importlib
+import json
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+ssd = importlib.import_module("stair-step-detector_amd")
+import oracle_binding as ob  # noqa: E402
+import parity  # noqa: E402
+
+
+def main():
+    n_poses = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    per_pose = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    rng = np.random.default_rng(seed)
+    oracle = ob.load_oracle()
+    cores = len(os.sched_getaffinity(0))
+    total = bad = thrown = 0
+    hist = {}
+    worst = {"max_height_err": 0.0, "max_corner_err": 0.0}
+    failures = []
+    for pose in range(n_poses):
+        W, H = [(640, 480), (1024, 768), (600, 450), (1920, 1080)][pose % 4]
+        F = per_pose if W < 1920 else max(8, per_pose // 8)
+        cam_height = float(rng.uniform(0.7, 1.5))
+        pitch = float(rng.uniform(35.0, 62.0))
+        roll = float(rng.uniform(-4.0, 4.0))
+        kws = []
+        for i in range(F):
+            kws.append(dict(n_steps=int(rng.integers(0, 9)), seed=int(rng.integers(1, 2**31)), cam_height=cam_height, pitch_deg=pitch,
+                            roll_deg=roll, first_riser_y=float(rng.uniform(0.15, 0.7)), tread=float(rng.uniform(0.12, 0.4)),
+                            rise=float(rng.uniform(0.08, 0.22)), stair_width=float(rng.uniform(0.4, 1.5)),
+                            yaw_deg=float(rng.uniform(-45.0, 45.0)) if rng.random() < 0.5 else float(rng.uniform(-10.0, 10.0)),
+                            sigma=float(rng.uniform(0.0, 0.004)), outlier_frac=float(rng.choice([0.0, 0.0, 0.01, 0.05, 0.15])),
+                            invalid_frac=float(rng.choice([0.0, 0.0, 0.02, 0.2]))))
+        scenes = [ssd.make_scene(W, H, **kw) for kw in kws]
+        trans = ssd.transformation_for_scene(scenes[0])
+        cfg = ssd.default_config(W, H, max_frames_per_batch=F)
+        det = ssd.Detector(cfg, trans, 0)
+        buf = ssd.DeviceBuffer(F * W * H * 12, 0)
+        ssd.synth_device(scenes, buf.ptr, device=0)
+        det.enqueue(buf.ptr, F)
+        res = det.fetch_list(F)
+        host = ssd.synth_host(scenes)            # bit-identical to the device generator (tested)
+        ocfg, ocal = ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants)
+
+        def check(i):
+            rep = {}
+            try:
+                parity.check_results_only(ssd, oracle, cfg, trans.constants, host[i], res[i], rep)
+                return i, None, rep
+            except parity.Mismatch as e:
+                return i, str(e), rep
+        with ThreadPoolExecutor(min(cores, 64)) as pool:
+            for i, err, rep in pool.map(check, range(F)):
+                total += 1
+                key = "throw" if res[i].status & 1 else str(res[i].n_steps)
+                hist[key] = hist.get(key, 0) + 1
+                thrown += 1 if res[i].status & 1 else 0
+                for k in worst:
+                    worst[k] = max(worst[k], rep.get(k, 0.0))
+                if err:
+                    bad += 1
+                    failures.append({"pose": pose, "res": [W, H], "frame": i, "scene": kws[i], "cam": [cam_height, pitch, roll], "error": err[:300]})
+        det.close()
+        buf.free()
+        print("pose %d %dx%d x%d: cam %.2f m, pitch %.1f, roll %.1f -> %d mismatches so far" % (pose, W, H, F, cam_height, pitch, roll, bad), flush=True)
+    out = {"frames": total, "mismatches": bad, "would_have_thrown": thrown, "steps_histogram": hist, **worst, "failures": failures[:20]}
+    print(json.dumps(out))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
