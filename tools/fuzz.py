@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""tools/fuzz.py [N_POSES] [FRAMES_PER_POSE] [SEED] — randomised parity sweep on the GPU box: random camera poses, stair
-geometries, yaw up to +-45 degrees, roll, noise, outliers, invalid pixels, 0-8 steps, three resolutions (incl. a ragged
-one); every frame's HIP result (batch path) against the CPU oracle's.  TEST INFRASTRUCTURE (uses oracle/)."""
+"""tools/fuzz.py [N_POSES] [FRAMES_PER_POSE] [SEED] [MODE] — randomised parity sweep on the GPU box: random camera poses, stair
+geometries, yaw up to +-45 degrees, roll, noise, outliers, invalid pixels, 0-8 steps, four resolutions (incl. a ragged
+one); every frame's HIP result (batch path) against the CPU oracle's.  MODE "mixed" also draws, per pose, the input
+format (float xyz or 16-bit depth) and a non-default configuration (measuring range, bin width, thresholds).
+TEST INFRASTRUCTURE (uses oracle/)."""
 import importlib
 import json
 import os
@@ -22,6 +24,7 @@ def main():
     n_poses = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     per_pose = int(sys.argv[2]) if len(sys.argv) > 2 else 128
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    mixed = len(sys.argv) > 4 and sys.argv[4] == "mixed"
     rng = np.random.default_rng(seed)
     oracle = ob.load_oracle()
     cores = len(os.sched_getaffinity(0))
@@ -46,12 +49,33 @@ def main():
         scenes = [ssd.make_scene(W, H, **kw) for kw in kws]
         trans = ssd.transformation_for_scene(scenes[0])
         cfg = ssd.default_config(W, H, max_frames_per_batch=F)
+        depth_in = False
+        if mixed:
+            depth_in = W % 4 == 0 and rng.random() < 0.4
+            if rng.random() < 0.6:
+                half = float(rng.uniform(0.45, 0.9))
+                cfg.x_min, cfg.x_max = -half, half + float(rng.uniform(-0.05, 0.05))
+                cfg.y_min = float(rng.uniform(0.05, 0.3)); cfg.y_max = cfg.y_min + float(rng.uniform(0.9, 1.6))
+                cfg.z_min = float(rng.uniform(-0.2, -0.03)); cfg.z_max = cfg.z_min + float(rng.uniform(0.7, 1.25))
+                cfg.height_interval = float(rng.choice([0.01, 0.01, 0.0125, 0.015, 0.02]))
+                cfg.min_height_above_ground = float(rng.uniform(0.03, 0.09))
+                cfg.min_step_depth = float(rng.uniform(0.05, 0.2))
         det = ssd.Detector(cfg, trans, 0)
-        buf = ssd.DeviceBuffer(F * W * H * 12, 0)
-        ssd.synth_device(scenes, buf.ptr, device=0)
-        det.enqueue(buf.ptr, F)
-        res = det.fetch_list(F)
-        host = ssd.synth_host(scenes)            # bit-identical to the device generator (tested)
+        if depth_in:
+            intr = ssd.intrinsics_for_scene(scenes[0])
+            det.set_intrinsics(intr)
+            buf = ssd.DeviceBuffer(F * W * H * 2, 0)
+            ssd.synth_depth_device(scenes, buf.ptr, device=0)
+            det.enqueue_depth(buf.ptr, F)
+            res = det.fetch_list(F)
+            depth = ssd.synth_depth_host(scenes)
+            host = [oracle.deproject(intr, depth[i]) for i in range(F)]
+        else:
+            buf = ssd.DeviceBuffer(F * W * H * 12, 0)
+            ssd.synth_device(scenes, buf.ptr, device=0)
+            det.enqueue(buf.ptr, F)
+            res = det.fetch_list(F)
+            host = ssd.synth_host(scenes)            # bit-identical to the device generator (tested)
         ocfg, ocal = ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants)
 
         def check(i):
@@ -71,10 +95,12 @@ def main():
                     worst[k] = max(worst[k], rep.get(k, 0.0))
                 if err:
                     bad += 1
-                    failures.append({"pose": pose, "res": [W, H], "frame": i, "scene": kws[i], "cam": [cam_height, pitch, roll], "error": err[:300]})
+                    failures.append({"pose": pose, "res": [W, H], "frame": i, "scene": kws[i], "cam": [cam_height, pitch, roll], "depth_input": bool(depth_in),
+                                     "config": {k: getattr(cfg, k) for k in ("x_min", "x_max", "y_min", "y_max", "z_min", "z_max", "height_interval",
+                                                                               "min_height_above_ground", "min_step_depth")}, "error": err[:300]})
         det.close()
         buf.free()
-        print("pose %d %dx%d x%d: cam %.2f m, pitch %.1f, roll %.1f -> %d mismatches so far" % (pose, W, H, F, cam_height, pitch, roll, bad), flush=True)
+        print("pose %d %dx%d x%d%s: cam %.2f m, pitch %.1f, roll %.1f -> %d mismatches so far" % (pose, W, H, F, " depth16" if depth_in else "", cam_height, pitch, roll, bad), flush=True)
     out = {"frames": total, "mismatches": bad, "would_have_thrown": thrown, "steps_histogram": hist, **worst, "failures": failures[:20]}
     print(json.dumps(out))
     return 1 if bad else 0
