@@ -271,3 +271,18 @@ def test_hip_path_reproduces_the_surveys_observed_run(ssd, gpu_device, tmp_path)
         assert abs(fr.steps[i].height - sa.OBSERVED[i, 0]) <= parity.TOL_HEIGHT
         assert list(fr.steps[i].quad) == list(sa.OBSERVED[i, 1:])
     assert ssd.Stairs(fr).serialize() == sa.OBSERVED_LINE
+
+
+def test_randomised_sweep_small(ssd, gpu_device):
+    """tools/fuzz.py at test size: 8 random poses x 32 frames (four resolutions, depth input and non-default
+    configurations included), every frame of the batch path against the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "8", "32", "4242", "mixed"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    summary = json.loads(p.stdout.strip().splitlines()[-1])
+    assert summary["mismatches"] == 0 and summary["frames"] >= 8 * 32 // 2
