@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--input", choices=["float3", "depth16"], default="float3",
                     help="float3 = xyz vertices (the metric's input); depth16 = 16-bit depth frames deprojected on the fly (SURVEY 8f rank 1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--risers", action="store_true",
+                    help="also gather the evidence of the vertical faces (extension beyond the reference, SURVEY 8f rank 4); off for the metric")
     args = ap.parse_args()
 
     import numpy as np
@@ -91,6 +93,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     det = ssd.Detector(cfg, trans, local_rank)
     det.set_timing(True)
+    if args.risers:
+        det.set_risers(True, tolerance=0.03, min_support=200)
     intr = ssd.intrinsics_for_scene(sc_list[0])
     if depth_in:
         ssd.synth_depth_device(sc_list, frames.data_ptr(), device=local_rank, stream=stream)
@@ -158,7 +162,7 @@ def main():
                                     if fhd else
                                     "BASELINE configs[2]: batch of %d synthetic %dx%d frames (3-step staircases, randomised rise/"
                                     "tread/yaw/noise) resident in HBM, streamed through the whole per-frame path; per GPU") % (F, W, H),
-                       "frames_per_gpu_per_step": F, "width": W, "height": H, "input": args.input, "parallelism": "frame-sharded x%d, no collective" % world},
+                       "frames_per_gpu_per_step": F, "width": W, "height": H, "input": args.input, "risers": bool(args.risers), "parallelism": "frame-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "kernel": "k_hist (K1: transform+crop+bin+histogram)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms},

@@ -143,6 +143,38 @@ int ssd_process_depth_host(ssd_handle *h, const uint16_t *depth, int nframes, ss
 int ssd_enqueue_depth(ssd_handle *h, const void *d_depth, size_t frame_stride_bytes, int nframes, void *stream);
 /* host restatement of the deprojection (no GPU needed): depth image -> width*height xyz floats */
 int ssd_deproject_host(const ssd_intrinsics *intr, int width, int height, const uint16_t *depth, float *xyz);
+
+/* ---- vertical faces -------------------------------------------------------
+ * EXTENSION: the reference has no counterpart — it discards the points that belong to no plateau (`remainder`)
+ * with a TODO to find the vertical faces in them (pointcloud.cpp:285-294).  Nothing here changes the results above.
+ * Between two vertically consecutive emitted surfaces (ground, valid steps; in output order) lies one riser: the
+ * vertical rectangle under the FRONT edge of the upper surface, from the lower surface's height to the upper's.
+ * Its evidence are the in-range points of no plateau whose height lies strictly between the two surfaces (one
+ * height interval away from either), within `tolerance` metres (horizontally) of that front edge's line and
+ * between its end points.  DESIGN.md section 7 states the arithmetic; oracle/ holds the same on the CPU. */
+#define SSD_MAX_RISERS (SSD_MAX_STEPS - 1)
+typedef struct
+{
+  int32_t n_points;          /* evidence points */
+  int32_t detected;          /* n_points >= min_support */
+  double height_bottom, height_top;   /* heights of the lower / upper surface (as ssd_step.height) */
+  double left[2], right[2];  /* the upper surface's front-left / front-right corner, external world x,y */
+  double mean_offset;        /* mean signed horizontal distance of the evidence from the edge line, metres
+                                (positive: on the left of the direction front-left -> front-right) */
+} ssd_riser;
+
+typedef struct
+{
+  int32_t n_risers;          /* emitted surfaces - 1, or 0 */
+  int32_t reserved;
+  ssd_riser risers[SSD_MAX_RISERS];
+} ssd_frame_risers;
+
+/* enable != 0: every later ssd_enqueue / ssd_process_* also gathers riser evidence (one more pass over the points
+ * of the bins between the surfaces).  tolerance in (0, 1] metres, min_support >= 1. */
+int ssd_set_risers(ssd_handle *h, int enable, double tolerance, int min_support);
+/* risers of the last enqueue (after ssd_fetch, or instead of it: synchronises `stream`) */
+int ssd_fetch_risers(ssd_handle *h, ssd_frame_risers *out, int nframes, void *stream);
 /* stage selector for profiling / roofline measurement: runs only the chosen stage(s) of the pipeline */
 #define SSD_STAGE_HIST 1       /* K1: transform + crop + bin + histogram */
 #define SSD_STAGE_PEAKS 2

@@ -27,6 +27,7 @@
 #include <optional>
 #include <sstream>
 #include <string>
+#include <memory>
 #include <vector>
 
 namespace
@@ -1452,6 +1453,112 @@ void ssdo_deproject(float fx, float fy, float ppx, float ppy, float depth_units,
       xyz[3 * i + 1] = d * y;
       xyz[3 * i + 2] = d;
     }
+}
+
+/* EXTENSION (see ssd_oracle.h): riser evidence.  Spec, in the camera-dependent world frame:
+ *   surfaces S_0..S_{n-1} = the emitted steps in output order (mean height z_i, corners FL, FR, BL, BR);
+ *   riser i (0 <= i < n-1): edge = FL -> FR of S_{i+1}; len = sqrt(dx*dx + dy*dy); u = (dx, dy) / len;
+ *     height interval (zLo, zHi) = (z_i + heightInterval, z_{i+1} - heightInterval); usable iff len > 0 and zLo < zHi;
+ *   a bin of no plateau belongs to the lowest usable riser whose bins int((zLo - zMin) * recip) .. int((zHi - zMin) * recip)
+ *     (clamped to the histogram) contain it;
+ *   a point (in range, in such a bin, zLo < z < zHi) is evidence iff |s| <= tol and 0 <= t <= len with
+ *     a = x - FL.x, b = y - FL.y, s = b*u.x - a*u.y, t = a*u.x + b*u.y;
+ *   mean_offset = (sum of round(s * 2^40)) / 2^40 / count. */
+int ssdo_risers(const ssdo_config *cfg, const ssdo_calibration *cal, const float *xyz, double tolerance, int min_support,
+                ssdo_riser *out)
+{
+  std::unique_ptr<ssdo_result> res(new ssdo_result);
+  const int rc = ssdo_process(cfg, cal, xyz, res.get(), nullptr, nullptr, 0, nullptr, nullptr);
+  if(rc < 0)
+    return rc;
+  const int n = (res->status & SSDO_ST_THROW) ? 0 : res->n_steps;
+  const int nR = n > 1 ? n - 1 : 0;
+  const double recip = 1.0 / cfg->height_interval;
+  const int nBins = res->n_bins;
+
+  /* bin -> plateau, as the plateaus consume the bins in ascending order (pointcloud.cpp:300-343, quirk Q4) */
+  std::vector<int> lut(size_t(nBins), -1);
+  int consumedUpTo = -1;
+  for(int k = 0; k < res->n_plateaus; k++)
+  {
+    const int hMin = res->plateaus[k].bin_lo, hMax = res->plateaus[k].bin_hi;
+    int lo, hi;
+    if(hMin == 0) { lo = 1; hi = 0; consumedUpTo = nBins; }
+    else { lo = std::max(hMin, consumedUpTo + 1); hi = hMax; consumedUpTo = std::max(consumedUpTo, hMax); }
+    for(int b = lo; b <= hi && b < nBins; b++)
+      lut[size_t(b)] = k;
+  }
+
+  struct R { double ox, oy, ux, uy, len, zLo, zHi; long long sum; unsigned cnt; };
+  std::vector<R> rs(size_t(nR), R{});
+  std::vector<int> riserOfBin(size_t(nBins), -1);
+  for(int i = 0; i < nR; i++)
+  {
+    const double *lower = res->steps_world[i], *upper = res->steps_world[i + 1];
+    const double lx = upper[0], ly = upper[1], rx = upper[3], ry = upper[4];
+    const double dx = rx - lx, dy = ry - ly;
+    const double len = std::sqrt(dx * dx + dy * dy);
+    R &r = rs[size_t(i)];
+    r.ox = lx; r.oy = ly;
+    r.zLo = lower[2] + cfg->height_interval;
+    r.zHi = upper[2] - cfg->height_interval;
+    const bool usable = len > 0.0 && r.zLo < r.zHi;
+    r.ux = usable ? dx / len : 0.0;
+    r.uy = usable ? dy / len : 0.0;
+    r.len = usable ? len : -1.0;
+    if(usable)
+    {
+      int bLo = static_cast<int>((r.zLo - cfg->z_min) * recip), bHi = static_cast<int>((r.zHi - cfg->z_min) * recip);
+      bLo = std::max(0, std::min(bLo, nBins - 1));
+      bHi = std::max(0, std::min(bHi, nBins - 1));
+      for(int b = bLo; b <= bHi; b++)
+        if(lut[size_t(b)] < 0 && riserOfBin[size_t(b)] < 0)
+          riserOfBin[size_t(b)] = i;
+    }
+    ssdo_riser &o = out[i];
+    o.height_bottom = res->steps_ext[i][0];
+    o.height_top = res->steps_ext[i + 1][0];
+    o.left[0] = res->steps_ext[i + 1][1]; o.left[1] = res->steps_ext[i + 1][2];
+    o.right[0] = res->steps_ext[i + 1][3]; o.right[1] = res->steps_ext[i + 1][4];
+  }
+
+  const size_t nPoints = size_t(cfg->width) * size_t(cfg->height);
+  for(size_t p = 0; p < nPoints && nR > 0; p++)
+  {
+    const float fx = xyz[3 * p], fy = xyz[3 * p + 1], fz = xyz[3 * p + 2];
+    if(!(fz > 0.0f))
+      continue;
+    const double x = fx, y = fy, z = fz;
+    double wx = (cal->a[0] * x + cal->a[1] * y) + cal->a[2] * z;
+    double wy = (cal->a[3] * x + cal->a[4] * y) + cal->a[5] * z;
+    double wz = (cal->a[6] * x + cal->a[7] * y) + cal->a[8] * z;
+    wx = wx + cal->b[0]; wy = wy + cal->b[1]; wz = wz + cal->b[2];
+    if(!(wx > cfg->x_min && wx < cfg->x_max && wy > cfg->y_min && wy < cfg->y_max && wz > cfg->z_min && wz < cfg->z_max))
+      continue;
+    const int bin = static_cast<int>((wz - cfg->z_min) * recip);
+    if(bin < 0 || bin >= nBins)
+      continue;
+    const int i = riserOfBin[size_t(bin)];
+    if(i < 0)
+      continue;
+    R &r = rs[size_t(i)];
+    if(!(wz > r.zLo && wz < r.zHi))
+      continue;
+    const double a = wx - r.ox, b = wy - r.oy;
+    const double sd = b * r.ux - a * r.uy;
+    const double t = a * r.ux + b * r.uy;
+    if(!(std::fabs(sd) <= tolerance && t >= 0.0 && t <= r.len))
+      continue;
+    r.sum += std::llrint(sd * 1099511627776.0);
+    r.cnt++;
+  }
+  for(int i = 0; i < nR; i++)
+  {
+    out[i].n_points = int(rs[size_t(i)].cnt);
+    out[i].detected = rs[size_t(i)].cnt >= unsigned(min_support) ? 1 : 0;
+    out[i].mean_offset = rs[size_t(i)].cnt ? (double(rs[size_t(i)].sum) / 1099511627776.0) / rs[size_t(i)].cnt : 0.0;
+  }
+  return nR;
 }
 
 void ssdo_close3x3(uint8_t *img, int width, int height)

@@ -144,6 +144,20 @@ int ssdo_process_lean(const ssdo_config *cfg, const ssdo_calibration *cal, const
 void ssdo_deproject(float fx, float fy, float ppx, float ppy, float depth_units, int width, int height,
                     const uint16_t *depth, float *xyz);
 
+/* EXTENSION — no reference counterpart (the reference leaves the vertical faces as a TODO, pointcloud.cpp:285-294):
+ * the CPU statement of the riser evidence that libssd_hip.so gathers with ssd_set_risers (include/ssd_hip.h,
+ * DESIGN.md section 7), to check the HIP kernel against.  Runs ssdo_process first. */
+typedef struct
+{
+  int32_t n_points, detected;
+  double height_bottom, height_top;
+  double left[2], right[2];
+  double mean_offset;
+} ssdo_riser;
+/* returns the number of risers (emitted surfaces - 1, or 0) or <0; out has room for SSDO_MAX_STEPS entries */
+int ssdo_risers(const ssdo_config *cfg, const ssdo_calibration *cal, const float *xyz, double tolerance, int min_support,
+                ssdo_riser *out);
+
 /* pieces exposed for unit tests */
 void ssdo_close3x3(uint8_t *img, int width, int height);
 int ssdo_serialize(int n_steps, const double *steps_ext /* n x 9 */, char *buf, int cap);

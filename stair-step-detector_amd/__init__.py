@@ -54,12 +54,22 @@ class Calibration(C.Structure):
                 ("world_z", C.c_double)]
 
 
+class Riser(C.Structure):
+    """ssd_riser (extension: vertical faces, include/ssd_hip.h)"""
+    _fields_ = [("n_points", C.c_int32), ("detected", C.c_int32), ("height_bottom", C.c_double), ("height_top", C.c_double),
+                ("left", C.c_double * 2), ("right", C.c_double * 2), ("mean_offset", C.c_double)]
+
+
 class Step(C.Structure):
     _fields_ = [("height", C.c_double), ("quad", C.c_double * 8)]
 
 
 class FrameResult(C.Structure):
     _fields_ = [("n_steps", C.c_int32), ("status", C.c_int32), ("steps", Step * MAX_STEPS)]
+
+
+class FrameRisers(C.Structure):
+    _fields_ = [("n_risers", C.c_int32), ("reserved", C.c_int32), ("risers", Riser * (MAX_STEPS - 1))]
 
 
 class DebugPlateau(C.Structure):
@@ -116,7 +126,7 @@ EXPORTS = [
     "ssd_process_host", "ssd_enqueue", "ssd_fetch", "ssd_enqueue_stages",
     "ssd_set_intrinsics", "ssd_process_depth_host", "ssd_enqueue_depth", "ssd_deproject_host",
     "ssd_synth_depth_host", "ssd_synth_depth_device",
-    "ssd_set_timing", "ssd_get_stage_times", "ssd_get_stage_times_back", "ssd_serialize",
+    "ssd_set_risers", "ssd_fetch_risers", "ssd_set_timing", "ssd_get_stage_times", "ssd_get_stage_times_back", "ssd_serialize",
     "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
     "ssd_synth_generate_host", "ssd_synth_generate_device", "ssd_synth_scene_to_camera",
     "ssd_device_count", "ssd_device_alloc", "ssd_device_free", "ssd_device_upload", "ssd_device_download",
@@ -157,6 +167,8 @@ def lib():
     L.ssd_synth_depth_host.argtypes = [C.POINTER(Scene), i32, C.c_float, vp]
     L.ssd_synth_depth_device.argtypes = [C.POINTER(Scene), i32, C.c_float, vp, sz, i32, vp]
     L.ssd_set_timing.argtypes = [vp, i32]
+    L.ssd_set_risers.argtypes = [vp, i32, C.c_double, i32]
+    L.ssd_fetch_risers.argtypes = [vp, C.POINTER(FrameRisers), i32, vp]
     L.ssd_get_stage_times.argtypes = [vp, C.POINTER(C.c_float)]
     L.ssd_get_stage_times_back.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.ssd_serialize.argtypes = [C.POINTER(FrameResult), C.c_char_p, sz]
@@ -317,6 +329,16 @@ class Detector:
     def fetch_list(self, nframes, stream=None):
         """fetch() as a list of independent FrameResult copies."""
         return [FrameResult.from_buffer_copy(r) for r in self.fetch(nframes, stream)]
+
+    def set_risers(self, on=True, tolerance=0.03, min_support=200):
+        """extension: also gather the evidence of the vertical faces (ssd_set_risers)"""
+        _check(lib().ssd_set_risers(self._h, 1 if on else 0, tolerance, min_support))
+
+    def fetch_risers(self, nframes, stream=None):
+        """-> list of FrameRisers (independent copies) of the last enqueue / process_host batch"""
+        arr = (FrameRisers * nframes)()
+        _check(lib().ssd_fetch_risers(self._h, arr, nframes, C.c_void_p(stream or 0)))
+        return [FrameRisers.from_buffer_copy(bytes(r)) for r in arr]
 
     def set_timing(self, on=True):
         _check(lib().ssd_set_timing(self._h, 1 if on else 0))

@@ -63,6 +63,8 @@ struct ssd_handle
   bool haveIntr = false;
   ssd_frame_result *dResults = nullptr;
   ssd_frame_result *hResults = nullptr;     /* pinned */
+  ssd_frame_risers *dRisers = nullptr;      /* vertical faces (extension), allocated by ssd_set_risers */
+  ssd_frame_risers *hRisers = nullptr;      /* pinned */
   float *dFrames = nullptr;                 /* staging for ssd_process_host */
   size_t dFramesCap = 0;                    /* frames */
   DebugFrame *dDebug = nullptr;
@@ -341,6 +343,8 @@ static int make_params(const ssd_config &c, const ssd_calibration &k, Params &P)
   P.px.xToImage = P.xToImage; P.px.yToImage = P.yToImage;
   P.px.W = P.W; P.px.H = P.H; P.px.W64 = P.W64;
   P.px.maxStepImages = P.maxStepImages;
+  P.risers = 0; P.riserMinSupport = 1; P.riserTol = 0.0;
+  P.heightInterval = c.height_interval;
   /* Shape of the waves' write-combining windows (ssd_kernels.hip, WaveWindow).  A wave takes the same 256 pixels of
    * every block tile of 1024: when a camera row is a whole number of block tiles (XGA) it walks down one 256-pixel
    * column strip and a tall narrow window (32 rows x 8 words) follows it; otherwise (VGA, FHD) its strip jumps along
@@ -428,6 +432,8 @@ int ssd_destroy(ssd_handle *h)
   if(h->dResults) (void)hipFree(h->dResults);
   if(h->hResults) (void)hipHostFree(h->hResults);
   if(h->dFrames) (void)hipFree(h->dFrames);
+  if(h->dRisers) (void)hipFree(h->dRisers);
+  if(h->hRisers) (void)hipHostFree(h->hRisers);
   if(h->dDebug) (void)hipFree(h->dDebug);
   if(h->dDebugImg) (void)hipFree(h->dDebugImg);
   for(hipEvent_t e : h->ev)
@@ -454,6 +460,46 @@ int ssd_set_debug(ssd_handle *h, int enable)
     h->bytes += sizeof(DebugFrame) * h->F + imgBytes;
   }
   h->debug = enable != 0;
+  return SSD_OK;
+}
+
+int ssd_set_risers(ssd_handle *h, int enable, double tolerance, int min_support)
+{
+  if(!h)
+    return fail(SSD_E_ARG, "ssd_set_risers: null handle");
+  if(enable && (!(tolerance > 0.0) || tolerance > 1.0 || min_support < 1))
+    return fail(SSD_E_ARG, "ssd_set_risers: tolerance must be in (0, 1] m, min_support >= 1");
+  HIP_TRY(hipSetDevice(h->device));
+  if(enable && !h->dRisers)
+  {
+    const size_t bytes = sizeof(ssd_frame_risers) * h->F;
+    HIP_TRY(hipMalloc(&h->dRisers, bytes));
+    HIP_TRY(hipMemset(h->dRisers, 0, bytes));
+    HIP_TRY(hipHostMalloc(&h->hRisers, bytes, hipHostMallocDefault));
+    h->bytes += bytes;
+  }
+  h->P.risers = enable ? 1 : 0;
+  if(enable)
+  {
+    h->P.riserTol = tolerance;
+    h->P.riserMinSupport = min_support;
+  }
+  return SSD_OK;
+}
+
+int ssd_fetch_risers(ssd_handle *h, ssd_frame_risers *out, int nframes, void *stream)
+{
+  if(!h || !out)
+    return fail(SSD_E_ARG, "ssd_fetch_risers: null argument");
+  if(!h->P.risers || !h->dRisers)
+    return fail(SSD_E_ARG, "ssd_fetch_risers: call ssd_set_risers(h, 1, ...) before the enqueue");
+  if(nframes < 1 || nframes > h->F)
+    return fail(SSD_E_ARG, "ssd_fetch_risers: nframes out of range");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(h->hRisers, h->dRisers, sizeof(ssd_frame_risers) * nframes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  std::memcpy(out, h->hRisers, sizeof(ssd_frame_risers) * nframes);
   return SSD_OK;
 }
 
@@ -572,7 +618,11 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
     launch_inquad(xyz, strideFloats, P, h->dState, h->dGroundImg, h->dTileMasks, h->tileMaskStride, nframes, chunk, depth, s);
   mark();
   if(stages & SSD_STAGE_FINAL)
+  {
     launch_final(P, h->dState, h->dGroundImg, h->dResults, nframes, dbg, dbgImg, s);
+    if(P.risers)
+      launch_risers(xyz, strideFloats, P, h->dState, h->dTileMasks, h->tileMaskStride, h->dRisers, nframes, chunk, depth, s);
+  }
   mark();
   HIP_TRY(hipGetLastError());
   /* a raster without its consumer leaves bits behind */

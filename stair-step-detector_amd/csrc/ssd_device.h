@@ -22,6 +22,7 @@ constexpr int kMaxBins = SSD_MAX_BINS;
 constexpr int kMaxPlateaus = SSD_MAX_PLATEAUS;
 constexpr int kMaxStepImages = SSD_MAX_STEP_IMAGES;
 constexpr int kGroundAcc = kMaxPlateaus;          /* accumulator slot of the ground quadrilateral */
+constexpr int kMaxRisers = SSD_MAX_RISERS;
 constexpr int kZFixShift = 40;                    /* mean z accumulates round(z * 2^40) in int64 */
 
 /* the four horizontal edges of a plateau outline, in this order everywhere (segmentation.cpp:585-589) */
@@ -67,6 +68,9 @@ struct Params
   double xToImage, yToImage, xToWorld, yToWorld, xyRatio;
   int nBins, minHeight, minImgYExtent;
   int maxStepImages;
+  /* vertical faces (extension, ssd_set_risers) */
+  int risers, riserMinSupport;
+  double riserTol, heightInterval;
 };
 
 /* strict point-in-quadrilateral test prepared once per quadrilateral
@@ -98,6 +102,14 @@ struct PlateauState
   double quadWorld[8];
 };
 
+/* one riser (extension): the front edge of the upper surface as origin + unit direction + length, and the open
+ * height interval of its evidence */
+struct RiserState
+{
+  double ox, oy, ux, uy, len, zLo, zHi;
+  double leftX, leftY, rightX, rightY, zBottom, zTop;   /* camera-dependent world, for the result */
+};
+
 struct FrameState
 {
   unsigned int hist[kMaxBins];
@@ -118,6 +130,13 @@ struct FrameState
   unsigned int wantedSteps, wantedQuads, anyActive;
   long long sumZ[kMaxPlateaus + 1];
   unsigned int cnt[kMaxPlateaus + 1];
+  /* vertical faces (extension): written by k_final, accumulated by k_risers */
+  int nRisers;
+  unsigned int wantedRisers;
+  signed char riserOfBin[kMaxBins];      /* bin -> riser whose height interval it overlaps, -1 = none */
+  RiserState riser[kMaxRisers];
+  long long rSum[kMaxRisers];
+  unsigned int rCnt[kMaxRisers];
 };
 
 struct DebugFrame

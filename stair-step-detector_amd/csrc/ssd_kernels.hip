@@ -2200,6 +2200,50 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
       dbg[frame].d.status = static_cast<int>(fs.status);
       dbg[frame].d.n_oob = static_cast<int>(fs.nOob);
     }
+    if(P.risers)
+    {
+      /* vertical faces (extension, include/ssd_hip.h): one riser under the front edge of every emitted surface but
+       * the lowest; its evidence is gathered by k_risers from the bins of no plateau between the two heights */
+      for(int b = 0; b < kMaxBins; b++)
+        fs.riserOfBin[b] = -1;
+      unsigned int wanted = 0u;
+      const int nR = n > 1 ? n - 1 : 0;
+      for(int i = 0; i < nR; i++)
+      {
+        const double *lower = stepsWorld[i], *upper = stepsWorld[i + 1];
+        RiserState &R = fs.riser[i];
+        R.leftX = upper[1]; R.leftY = upper[2]; R.rightX = upper[3]; R.rightY = upper[4];
+        R.zBottom = lower[0]; R.zTop = upper[0];
+        const double dx = R.rightX - R.leftX, dy = R.rightY - R.leftY;
+        const double len = sqrt(dx * dx + dy * dy);
+        R.ox = R.leftX; R.oy = R.leftY;
+        R.zLo = lower[0] + P.heightInterval;
+        R.zHi = upper[0] - P.heightInterval;
+        const bool usable = len > 0.0 && R.zLo < R.zHi;
+        R.ux = usable ? dx / len : 0.0;
+        R.uy = usable ? dy / len : 0.0;
+        R.len = usable ? len : -1.0;                        /* no point has 0 <= t <= -1 */
+        if(usable)
+        {
+          int bLo = static_cast<int>((R.zLo - P.zMin) * P.pt.recip), bHi = static_cast<int>((R.zHi - P.zMin) * P.pt.recip);
+          bLo = max(0, min(bLo, P.nBins - 1));
+          bHi = max(0, min(bHi, P.nBins - 1));
+          for(int b = bLo; b <= bHi; b++)
+            if(fs.lut[b] == 0xff && fs.riserOfBin[b] < 0)
+            {
+              fs.riserOfBin[b] = static_cast<signed char>(i);
+              wanted |= 1u << (b / kBinsPerGroup);
+            }
+        }
+      }
+      for(int i = 0; i < kMaxRisers; i++)
+      {
+        fs.rSum[i] = 0;
+        fs.rCnt[i] = 0u;
+      }
+      fs.nRisers = nR;
+      fs.wantedRisers = wanted;
+    }
   }
   __syncthreads();
 
@@ -2215,6 +2259,144 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
       if(img[o])
         img[o] = 0ull;
     }
+  }
+}
+
+/* ========================================================================= */
+/* K6 (extension): evidence of the vertical faces                              */
+
+template<int SRC>
+__global__ __launch_bounds__(kThreads, 8) void k_risers(const float *__restrict__ xyz, size_t strideFloats, PointParams P, double tol,
+                                                        FrameState *__restrict__ st, const unsigned int *__restrict__ tileMasks,
+                                                        size_t tileMaskStride, int chunkPoints, DepthSrc D)
+{
+  __shared__ RiserState rs[kMaxRisers];
+  __shared__ signed char riserOfBin[kMaxBins];
+  __shared__ unsigned long long lsum[kMaxRisers][8];
+  __shared__ unsigned int lcnt[kMaxRisers][8];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int frame = blockIdx.x;
+  FrameState &fs = st[frame];
+  const unsigned int wanted = fs.wantedRisers;
+  if(wanted == 0u)                                          /* block-uniform: set by k_final */
+    return;
+  const int nR = fs.nRisers;
+  if(tid < kMaxBins)
+    riserOfBin[tid] = fs.riserOfBin[tid];
+  if(tid < nR)
+    rs[tid] = fs.riser[tid];
+  for(int i = tid; i < kMaxRisers * 8; i += kThreads)
+  {
+    (&lsum[0][0])[i] = 0ull;
+    (&lcnt[0][0])[i] = 0u;
+  }
+  __syncthreads();
+
+  const float *base = SRC == kSrcDepth16
+    ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(xyz) + static_cast<size_t>(frame) * strideFloats)
+    : xyz + static_cast<size_t>(frame) * strideFloats;
+  const int begin = blockIdx.y * chunkPoints;
+  const int end = min(begin + chunkPoints, P.nPoints);
+  const unsigned int *masks = tileMasks + static_cast<size_t>(frame) * tileMaskStride + (tid >> 6);
+  const int copy = lane & 7;
+
+  int curR = -1;
+  long long accS = 0;
+  unsigned int accN = 0;
+  auto flushAcc = [&]()
+  {
+    if(curR >= 0 && accN)
+    {
+      atomicAdd(&lsum[curR][copy], static_cast<unsigned long long>(accS));
+      atomicAdd(&lcnt[curR][copy], accN);
+    }
+  };
+
+  for(int i0 = begin; i0 < end; i0 += kTile)
+  {
+    if(!(masks[static_cast<size_t>(i0 / kTile) * kWavesPerBlock] & wanted))
+      continue;
+    F3 v[kPts];
+    load_points<SRC>(base, i0 + kPts * tid, end, v, D);
+    #pragma unroll
+    for(int j = 0; j < kPts; j++)
+    {
+      double wx, wy, wz;
+      if(!world_z(P, v[j], wz))
+        continue;
+      const int r = riserOfBin[height_bin(P, wz)];
+      if(r < 0)
+        continue;
+      const RiserState &R = rs[r];
+      if(!(wz > R.zLo && wz < R.zHi))
+        continue;
+      if(!world_xy(P, v[j], wx, wy))
+        continue;
+      const double a = wx - R.ox, b = wy - R.oy;
+      const double sd = b * R.ux - a * R.uy;                 /* signed distance from the edge line */
+      const double t = a * R.ux + b * R.uy;                  /* position along the edge */
+      if(!(fabs(sd) <= tol && t >= 0.0 && t <= R.len))
+        continue;
+      if(r != curR)
+      {
+        flushAcc();
+        curR = r; accS = 0; accN = 0;
+      }
+      accS += z_to_fixed(sd);
+      accN++;
+    }
+  }
+  flushAcc();
+  __syncthreads();
+  if(tid < nR)
+  {
+    unsigned long long sum = 0;
+    unsigned int c = 0;
+    for(int k = 0; k < 8; k++)
+    {
+      sum += lsum[tid][k];
+      c += lcnt[tid][k];
+    }
+    if(c)
+    {
+      atomicAdd(reinterpret_cast<unsigned long long *>(&fs.rSum[tid]), sum);
+      atomicAdd(&fs.rCnt[tid], c);
+    }
+  }
+}
+
+/* one thread per frame: the riser records in external world coordinates (ToExternalWorld as in k_final) */
+__global__ void k_riser_results(Params P, const FrameState *__restrict__ st, ssd_frame_risers *__restrict__ out, int nframes)
+{
+  const int frame = blockIdx.x * blockDim.x + threadIdx.x;
+  if(frame >= nframes)
+    return;
+  const FrameState &fs = st[frame];
+  ssd_frame_risers &o = out[frame];
+  const int nR = fs.nRisers;
+  o.n_risers = nR;
+  o.reserved = 0;
+  for(int i = 0; i < kMaxRisers; i++)
+  {
+    ssd_riser &q = o.risers[i];
+    if(i >= nR)
+    {
+      q.n_points = 0; q.detected = 0; q.height_bottom = 0.0; q.height_top = 0.0;
+      q.left[0] = q.left[1] = q.right[0] = q.right[1] = 0.0; q.mean_offset = 0.0;
+      continue;
+    }
+    const RiserState &R = fs.riser[i];
+    const unsigned int c = fs.rCnt[i];
+    q.n_points = static_cast<int>(c);
+    q.detected = c >= static_cast<unsigned int>(P.riserMinSupport) ? 1 : 0;
+    q.height_bottom = P.worldZ + R.zBottom;
+    q.height_top = P.worldZ + R.zTop;
+    double ex = P.r2[0] * R.leftX + P.r2[1] * R.leftY, ey = P.r2[2] * R.leftX + P.r2[3] * R.leftY;
+    q.left[0] = ex + P.t2[0]; q.left[1] = ey + P.t2[1];
+    ex = P.r2[0] * R.rightX + P.r2[1] * R.rightY; ey = P.r2[2] * R.rightX + P.r2[3] * R.rightY;
+    q.right[0] = ex + P.t2[0]; q.right[1] = ey + P.t2[1];
+    q.mean_offset = c ? (static_cast<double>(fs.rSum[i]) / static_cast<double>(1ll << kZFixShift)) / c : 0.0;
   }
 }
 
@@ -2335,6 +2517,18 @@ void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, Frame
 void launch_final(const Params &P, FrameState *st, unsigned long long *groundImg, ssd_frame_result *results, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
 {
   hipLaunchKernelGGL(k_final, dim3(nframes), dim3(kThreads), 0, s, P, st, groundImg, results, dbg, dbgImg);
+}
+void launch_risers(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, const unsigned int *tileMasks, size_t tileMaskStride,
+                   ssd_frame_risers *out, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
+{
+  dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
+  if(depth)
+    hipLaunchKernelGGL(k_risers<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.riserTol, st, tileMasks, tileMaskStride, chunkPoints, *depth);
+  else if(aligned16(xyz, strideFloats, P.nPoints))
+    hipLaunchKernelGGL(k_risers<kSrcF3Aligned>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.riserTol, st, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
+  else
+    hipLaunchKernelGGL(k_risers<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.riserTol, st, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
+  hipLaunchKernelGGL(k_riser_results, dim3((nframes + 63) / 64), dim3(64), 0, s, P, st, out, nframes);
 }
 void launch_synth(const ssd_scene *dScenes, float *xyz, size_t strideFloats, int nframes, int nPoints, hipStream_t s)
 {

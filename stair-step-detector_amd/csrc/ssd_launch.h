@@ -19,6 +19,8 @@ void launch_quads(const Params &P, FrameState *st, int nframes, DebugFrame *dbg,
 void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *groundImg,
                    const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s);
 void launch_final(const Params &P, FrameState *st, unsigned long long *groundImg, ssd_frame_result *results, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s);
+void launch_risers(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, const unsigned int *tileMasks, size_t tileMaskStride,
+                   ssd_frame_risers *out, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s);
 void launch_synth(const ssd_scene *dScenes, float *xyz, size_t strideFloats, int nframes, int nPoints, hipStream_t s);
 void launch_synth_depth(const ssd_scene *dScenes, unsigned short *depth, size_t strideElems, float depthUnits, int nframes, int nPoints, hipStream_t s);
 void launch_hypot(const double *a, const double *b, double *out, int n, hipStream_t s);

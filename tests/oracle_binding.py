@@ -66,6 +66,11 @@ def build_oracle():
     subprocess.run(["make", "-C", ORACLE_DIR], check=True, stdout=subprocess.DEVNULL)
 
 
+class Riser(C.Structure):
+    _fields_ = [("n_points", C.c_int32), ("detected", C.c_int32), ("height_bottom", C.c_double), ("height_top", C.c_double),
+                ("left", C.c_double * 2), ("right", C.c_double * 2), ("mean_offset", C.c_double)]
+
+
 class Oracle:
     def __init__(self, lib):
         self.lib = lib
@@ -82,6 +87,7 @@ class Oracle:
         lib.ssdo_best_line.argtypes = [vp, i32, vp]
         lib.ssdo_calibration_load.argtypes = [C.c_char_p, C.c_char_p, vp, vp]
         lib.ssdo_deproject.argtypes = [C.c_float] * 5 + [i32, i32, vp, vp]
+        lib.ssdo_risers.argtypes = [C.POINTER(Config), C.POINTER(Calibration), vp, C.c_double, i32, C.POINTER(Riser)]
 
     def config(self, width, height):
         cfg = Config()
@@ -94,6 +100,15 @@ class Oracle:
         c = (C.c_double * 9)(*np.asarray(cam, dtype=np.float64).reshape(9))
         rc = self.lib.ssdo_calibration_from_points(w, c, C.byref(cal))
         return rc, cal
+
+    def risers(self, cfg, cal, xyz, tolerance=0.03, min_support=200):
+        """extension (no reference counterpart): riser evidence -> list of Riser"""
+        a = np.ascontiguousarray(xyz, dtype=np.float32)
+        out = (Riser * MAX_STEPS)()
+        n = self.lib.ssdo_risers(C.byref(cfg), C.byref(cal), a.ctypes.data_as(C.c_void_p), tolerance, min_support, out)
+        if n < 0:
+            raise RuntimeError("ssdo_risers failed: %d" % n)
+        return [out[i] for i in range(n)]
 
     def deproject(self, intr, depth):
         a = np.ascontiguousarray(depth, dtype=np.uint16)

@@ -167,3 +167,20 @@ def check_results_only(ssd, oracle, cfg, cal, xyz, fr, report=None):
     if not (status & ob.ST_THROW):
         _eq("line", ssd.Stairs(fr).serialize(), oracle.serialize(steps) if n else '["stairs",["stairSteps",0]]')
     return report
+
+
+def compare_risers(dev, ora, report=None):
+    """ssd.FrameRisers vs the oracle's list of Riser (extension: vertical faces).  Counts exact; geometry is the steps'
+    (identical doubles expected); mean offset: fixed-point sum on both sides."""
+    report = {} if report is None else report
+    _eq("n_risers", dev.n_risers, len(ora))
+    for i, o in enumerate(ora):
+        d = dev.risers[i]
+        tag = "riser[%d]" % i
+        _eq(tag + ".n_points", d.n_points, o.n_points)
+        _eq(tag + ".detected", d.detected, o.detected)
+        _close(tag + ".heights", [d.height_bottom, d.height_top], [o.height_bottom, o.height_top], TOL_HEIGHT)
+        _close(tag + ".edge", list(d.left) + list(d.right), list(o.left) + list(o.right), 1e-9)
+        report["max_offset_err"] = max(report.get("max_offset_err", 0.0), _close(tag + ".mean_offset", d.mean_offset, o.mean_offset, 1e-12))
+    report["risers_detected"] = sum(1 for o in ora if o.detected)
+    return report

@@ -273,6 +273,45 @@ def test_hip_path_reproduces_the_surveys_observed_run(ssd, gpu_device, tmp_path)
     assert ssd.Stairs(fr).serialize() == sa.OBSERVED_LINE
 
 
+@pytest.mark.parametrize("name", SCENES)
+def test_riser_evidence_matches_the_cpu_statement(ssd, oracle, gpu_device, name):
+    """Extension (no reference counterpart): the evidence of the vertical faces gathered by
+    k_risers against oracle/'s statement of the same spec; and switching it on must not change the reference results."""
+    sc, trans, cfg = _setup(ssd, name)
+    xyz = ssd.synth_host([sc])[0]
+    det = ssd.Detector(cfg, trans, gpu_device)
+    plain = bytes(det.process_host(xyz)[0])
+    det.set_risers(True, tolerance=0.03, min_support=200)
+    fr = det.process_host(xyz)[0]
+    assert bytes(fr) == plain
+    dev = det.fetch_risers(1)[0]
+    det.close()
+    ora = oracle.risers(ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants), xyz, 0.03, 200)
+    rep = parity.compare_risers(dev, ora)
+    if name in ("xga_config1", "xga_yaw_p8", "fhd_3steps_clean"):
+        assert rep["risers_detected"] == 3
+
+
+def test_risers_in_a_batch_and_with_depth_input(ssd, oracle, gpu_device):
+    sc_list = scenes.batch_scenes(ssd, 640, 480, 6, base_seed=555)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    cfg = ssd.default_config(640, 480, max_frames_per_batch=6)
+    ocfg, ocal = ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    det.set_risers(True, tolerance=0.02, min_support=500)
+    host = ssd.synth_host(sc_list)
+    det.process_host(host)
+    for i, fr in enumerate(det.fetch_risers(6)):
+        parity.compare_risers(fr, oracle.risers(ocfg, ocal, host[i], 0.02, 500))
+    intr = ssd.intrinsics_for_scene(sc_list[0])
+    det.set_intrinsics(intr)
+    depth = ssd.synth_depth_host(sc_list)
+    det.process_depth_host(depth)
+    for i, fr in enumerate(det.fetch_risers(6)):
+        parity.compare_risers(fr, oracle.risers(ocfg, ocal, oracle.deproject(intr, depth[i]), 0.02, 500))
+    det.close()
+
+
 def test_randomised_sweep_small(ssd, gpu_device):
     """tools/fuzz.py at test size: 8 random poses x 32 frames (four resolutions, depth input and non-default
     configurations included), every frame of the batch path against the oracle."""
