@@ -61,6 +61,10 @@ def main():
                 cfg.min_height_above_ground = float(rng.uniform(0.03, 0.09))
                 cfg.min_step_depth = float(rng.uniform(0.05, 0.2))
         det = ssd.Detector(cfg, trans, 0)
+        risers = mixed and rng.random() < 0.5
+        r_tol, r_min = float(rng.uniform(0.01, 0.06)), int(rng.integers(1, 3000))
+        if risers:
+            det.set_risers(True, r_tol, r_min)
         if depth_in:
             intr = ssd.intrinsics_for_scene(scenes[0])
             det.set_intrinsics(intr)
@@ -77,11 +81,14 @@ def main():
             res = det.fetch_list(F)
             host = ssd.synth_host(scenes)            # bit-identical to the device generator (tested)
         ocfg, ocal = ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants)
+        dev_risers = det.fetch_risers(F) if risers else None
 
         def check(i):
             rep = {}
             try:
                 parity.check_results_only(ssd, oracle, cfg, trans.constants, host[i], res[i], rep)
+                if risers:
+                    parity.compare_risers(dev_risers[i], oracle.risers(ocfg, ocal, host[i], r_tol, r_min), rep)
                 return i, None, rep
             except parity.Mismatch as e:
                 return i, str(e), rep
@@ -95,12 +102,12 @@ def main():
                     worst[k] = max(worst[k], rep.get(k, 0.0))
                 if err:
                     bad += 1
-                    failures.append({"pose": pose, "res": [W, H], "frame": i, "scene": kws[i], "cam": [cam_height, pitch, roll], "depth_input": bool(depth_in),
+                    failures.append({"pose": pose, "res": [W, H], "frame": i, "scene": kws[i], "cam": [cam_height, pitch, roll], "depth_input": bool(depth_in), "risers": [r_tol, r_min] if risers else None,
                                      "config": {k: getattr(cfg, k) for k in ("x_min", "x_max", "y_min", "y_max", "z_min", "z_max", "height_interval",
                                                                                "min_height_above_ground", "min_step_depth")}, "error": err[:300]})
         det.close()
         buf.free()
-        print("pose %d %dx%d x%d%s: cam %.2f m, pitch %.1f, roll %.1f -> %d mismatches so far" % (pose, W, H, F, " depth16" if depth_in else "", cam_height, pitch, roll, bad), flush=True)
+        print("pose %d %dx%d x%d%s: cam %.2f m, pitch %.1f, roll %.1f -> %d mismatches so far" % (pose, W, H, F, (" depth16" if depth_in else "") + (" risers" if risers else ""), cam_height, pitch, roll, bad), flush=True)
     out = {"frames": total, "mismatches": bad, "would_have_thrown": thrown, "steps_histogram": hist, **worst, "failures": failures[:20]}
     print(json.dumps(out))
     return 1 if bad else 0
