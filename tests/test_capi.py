@@ -32,6 +32,14 @@ def test_struct_layouts_match_the_header(ssd):
     assert C.sizeof(ssd.Calibration) == 19 * 8
     assert C.sizeof(ssd.Config) == 8 + 9 * 8 + 8
     assert C.sizeof(ssd.Scene) % 8 == 0
+    assert C.sizeof(ssd.Riser) == 8 + 7 * 8
+    assert C.sizeof(ssd.FrameRisers) == 8 + C.sizeof(ssd.Riser) * (ssd.MAX_STEPS - 1)
+
+
+def test_riser_entry_points_validate_their_arguments(ssd):
+    L = ssd.lib()
+    assert L.ssd_set_risers(None, 1, 0.03, 200) == -1            # SSD_E_ARG: null handle
+    assert L.ssd_fetch_risers(None, None, 1, None) == -1
 
 
 def test_default_config_is_the_reference_configuration(ssd):

@@ -312,6 +312,24 @@ def test_risers_in_a_batch_and_with_depth_input(ssd, oracle, gpu_device):
     det.close()
 
 
+def test_host_batches_larger_than_the_workspace_are_processed_in_chunks(ssd, oracle, gpu_device):
+    """ssd_process_host with more frames than max_frames_per_batch loops over chunks (also the 16-bit depth entry)."""
+    sc_list = scenes.batch_scenes(ssd, 640, 480, 5, base_seed=909)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    host = ssd.synth_host(sc_list)
+    big = ssd.Detector(ssd.default_config(640, 480, max_frames_per_batch=8), trans, gpu_device)
+    want = [bytes(r) for r in big.process_host(host)]
+    small = ssd.Detector(ssd.default_config(640, 480, max_frames_per_batch=2), trans, gpu_device)
+    assert [bytes(r) for r in small.process_host(host)] == want
+    intr = ssd.intrinsics_for_scene(sc_list[0])
+    depth = ssd.synth_depth_host(sc_list)
+    big.set_intrinsics(intr)
+    small.set_intrinsics(intr)
+    assert [bytes(r) for r in small.process_depth_host(depth)] == [bytes(r) for r in big.process_depth_host(depth)]
+    big.close()
+    small.close()
+
+
 def test_randomised_sweep_small(ssd, gpu_device):
     """tools/fuzz.py at test size: 8 random poses x 32 frames (four resolutions, depth input and non-default
     configurations included), every frame of the batch path against the oracle."""
