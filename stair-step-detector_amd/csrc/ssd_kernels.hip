@@ -546,55 +546,48 @@ __device__ __forceinline__ void wavewin_flush(unsigned long long *ww, const Wave
   }
 }
 
-/* per-lane record of what missed the window during one tile */
-struct MissInfo
-{
-  bool hit = false, miss = false;
-  unsigned int key = 0xffffffffu;          /* lowest (slot << 16 | row) that missed */
-  int col = 0x7fffffff;                    /* lowest word column that missed */
-};
+/* What missed the window during one tile is noted per WAVE, in two LDS words next to the window (wm[0] = lowest
+ * (slot, row, word column) that missed, packed; wm[1] = number of words that missed): the miss path is rare and
+ * per-lane registers for it would have to be merged at every exit of the per-point control flow. */
+constexpr unsigned int kNoMiss = 0xffffffffu;
 
 /* one word's worth of bits of image `slot`: into the window when it is inside, straight to memory otherwise */
-__device__ __forceinline__ void wavewin_or(unsigned long long *ww, const WaveWindow &w, unsigned long long *__restrict__ images,
-                                           unsigned int imgWords, int W64, int winShift, ImageBox *boxes, MissBox &mb, MissInfo &mi,
+__device__ __forceinline__ void wavewin_or(unsigned long long *ww, unsigned int *wm, const WaveWindow &w, unsigned long long *__restrict__ images,
+                                           unsigned int imgWords, int W64, int winShift, ImageBox *boxes, MissBox &mb,
                                            int slot, int iy, int xw, unsigned long long mask)
 {
   const unsigned int r = static_cast<unsigned int>(iy - w.row0), c = static_cast<unsigned int>(xw - w.col0);
   if(slot == w.slot && r < (static_cast<unsigned int>(kWinWords) >> winShift) && c < (1u << winShift))
-  {
     atomicOr(&ww[(r << winShift) + c], mask);
-    mi.hit = true;
-  }
   else
   {
     atomicOr(images + static_cast<size_t>(slot) * imgWords + static_cast<size_t>(iy) * W64 + xw, mask);
     missbox_note(mb, boxes, slot, iy, xw);
-    mi.miss = true;
-    mi.key = min(mi.key, (static_cast<unsigned int>(slot) << 16) | static_cast<unsigned int>(iy));
-    mi.col = min(mi.col, xw);
+    atomicMin(&wm[0], (((static_cast<unsigned int>(slot) << 16) | static_cast<unsigned int>(iy)) << 6) | static_cast<unsigned int>(xw));
+    atomicAdd(&wm[1], 1u);
   }
 }
 
-/* end of a tile, all 64 lanes: nothing to do unless some lane missed; re-anchor when misses outnumber hits */
-__device__ __forceinline__ void wavewin_end_of_tile(unsigned long long *ww, WaveWindow &w, unsigned long long *__restrict__ images,
-                                                    unsigned int imgWords, int W64, int winShift, ImageBox *boxes, const MissInfo &mi, int lane)
+/* end of a tile, all 64 lanes; `emitted` = this lane sent at least one word: nothing to do unless something
+ * missed; re-anchor at the lowest miss when the misses outnumber half of the emitting lanes */
+__device__ __forceinline__ void wavewin_end_of_tile(unsigned long long *ww, unsigned int *wm, WaveWindow &w, unsigned long long *__restrict__ images,
+                                                    unsigned int imgWords, int W64, int winShift, ImageBox *boxes, bool emitted, int lane)
 {
-  const unsigned long long missing = __ballot(mi.miss);
-  if(missing == 0ull)
+  const unsigned int missed = __builtin_amdgcn_readfirstlane(wm[1]);
+  if(missed == 0u)
     return;
-  if(__popcll(missing) <= __popcll(__ballot(mi.hit)))
+  const unsigned int packed = __builtin_amdgcn_readfirstlane(wm[0]);
+  if(lane == 0)
+  {
+    wm[0] = kNoMiss;
+    wm[1] = 0u;
+  }
+  if(2u * missed <= static_cast<unsigned int>(__popcll(__ballot(emitted))))
     return;
   wavewin_flush(ww, w, images, imgWords, W64, winShift, boxes, lane);
-  const unsigned int key = static_cast<unsigned int>(wave_min_i(static_cast<int>(mi.key >> 1))) ;   /* keys are < 2^31 after >> 1 */
-  /* recover the exact minimum: the lanes whose key >> 1 equals the minimum vote with their low bit */
-  const unsigned int lowBit = (__ballot((mi.key >> 1) == key && !(mi.key & 1u)) != 0ull) ? 0u : 1u;
-  const unsigned int full = (key << 1) | lowBit;
-  const int slot = static_cast<int>(full >> 16);
-  /* leftmost missing column of that image */
-  const int col = wave_min_i((mi.miss && static_cast<int>(mi.key >> 16) == slot) ? mi.col : 0x7fffffff);
-  w.slot = slot;
-  w.row0 = static_cast<int>(full & 0xffffu);
-  w.col0 = max(0, min(col - 1, W64 - (1 << winShift)));
+  w.slot = static_cast<int>(packed >> 22);
+  w.row0 = static_cast<int>((packed >> 6) & 0xffffu);
+  w.col0 = max(0, min(static_cast<int>(packed & 63u) - 1, W64 - (1 << winShift)));
 }
 
 /* Projection2D::worldToImage (pointcloud.cpp:79-83); false = outside the image (quirk Q5) */
@@ -612,6 +605,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
                                                         const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
   __shared__ unsigned long long wins[kThreads / 64][kWinWords];
+  __shared__ unsigned int wmiss[kThreads / 64][2];
   __shared__ ImageBox boxes[kMaxStepImages];
   __shared__ unsigned char lut[kMaxBins];
   __shared__ unsigned int lOob;
@@ -631,6 +625,11 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
     lOob = 0;
   for(int i = tid; i < (kThreads / 64) * kWinWords; i += kThreads)
     (&wins[0][0])[i] = 0ull;
+  if(tid < kThreads / 64)
+  {
+    wmiss[tid][0] = kNoMiss;
+    wmiss[tid][1] = 0u;
+  }
   __syncthreads();
 
   /* strideFloats counts floats, or 16-bit depth values for kSrcDepth16 */
@@ -644,6 +643,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
   const unsigned int imgWords = static_cast<unsigned int>(X.H) * X.W64;
   unsigned long long *frameImg = stepImg + static_cast<size_t>(frame) * X.maxStepImages * imgWords;
   unsigned long long *ww = wins[tid >> 6];
+  unsigned int *wm = wmiss[tid >> 6];
   WaveWindow win;
   MissBox mb;
   unsigned int oob = 0;
@@ -656,7 +656,6 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
     F3 v[kPts];
     load_points<SRC>(base, i0 + kPts * tid, end, v, D);
     /* the lane's four neighbouring pixels usually share one 64-bit word: merge them before touching LDS */
-    MissInfo mi;
     int pSlot = -1;
     int pY = 0;
     int pXw = 0;
@@ -685,12 +684,12 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
         continue;
       }
       if(pSlot >= 0)
-        wavewin_or(ww, win, frameImg, imgWords, X.W64, X.winShift, boxes, mb, mi, pSlot, pY, pXw, pMask);
+        wavewin_or(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, boxes, mb, pSlot, pY, pXw, pMask);
       pSlot = slot; pY = iy; pXw = ix >> 6; pMask = bit;
     }
     if(pSlot >= 0)
-      wavewin_or(ww, win, frameImg, imgWords, X.W64, X.winShift, boxes, mb, mi, pSlot, pY, pXw, pMask);
-    wavewin_end_of_tile(ww, win, frameImg, imgWords, X.W64, X.winShift, boxes, mi, lane);
+      wavewin_or(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, boxes, mb, pSlot, pY, pXw, pMask);
+    wavewin_end_of_tile(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, boxes, pSlot >= 0, lane);
   }
   wavewin_flush(ww, win, frameImg, imgWords, X.W64, X.winShift, boxes, lane);
   missbox_flush(mb, boxes);
@@ -1805,6 +1804,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
                                                         const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
   __shared__ unsigned long long wins[kThreads / 64][kWinWords];
+  __shared__ unsigned int wmiss[kThreads / 64][2];
   __shared__ ImageBox box[1];
   __shared__ QuadTest qts[kMaxPlateaus + 1];
   __shared__ unsigned char lut[kMaxBins];
@@ -1835,6 +1835,11 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
   }
   for(int i = tid; i < (kThreads / 64) * kWinWords; i += kThreads)
     (&wins[0][0])[i] = 0ull;
+  if(tid < kThreads / 64)
+  {
+    wmiss[tid][0] = kNoMiss;
+    wmiss[tid][1] = 0u;
+  }
   {
     /* copy the live quadrilateral tests as 32-bit words */
     const unsigned int *src = reinterpret_cast<const unsigned int *>(fs.qt);
@@ -1859,6 +1864,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
   const int copy = lane & 7;
   const unsigned int imgWords = static_cast<unsigned int>(X.H) * X.W64;
   unsigned long long *ww = wins[tid >> 6];
+  unsigned int *wm = wmiss[tid >> 6];
   WaveWindow win;
   MissBox mb;
 
@@ -1884,7 +1890,6 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
       continue;
     F3 v[kPts];
     load_points<SRC>(base, i0 + kPts * tid, end, v, D);
-    MissInfo mi;
     int pY = -1;
     int pXw = 0;
     unsigned long long pMask = 0;
@@ -1931,13 +1936,13 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
           continue;
         }
         if(pY >= 0)
-          wavewin_or(ww, win, gimg, imgWords, X.W64, X.winShift, box, mb, mi, 0, pY, pXw, pMask);
+          wavewin_or(ww, wm, win, gimg, imgWords, X.W64, X.winShift, box, mb, 0, pY, pXw, pMask);
         pY = iy; pXw = ix >> 6; pMask = bit;
       }
     }
     if(pY >= 0)
-      wavewin_or(ww, win, gimg, imgWords, X.W64, X.winShift, box, mb, mi, 0, pY, pXw, pMask);
-    wavewin_end_of_tile(ww, win, gimg, imgWords, X.W64, X.winShift, box, mi, lane);
+      wavewin_or(ww, wm, win, gimg, imgWords, X.W64, X.winShift, box, mb, 0, pY, pXw, pMask);
+    wavewin_end_of_tile(ww, wm, win, gimg, imgWords, X.W64, X.winShift, box, pY >= 0, lane);
   }
   wavewin_flush(ww, win, gimg, imgWords, X.W64, X.winShift, box, lane);
   missbox_flush(mb, box);
