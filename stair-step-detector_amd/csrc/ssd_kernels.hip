@@ -54,6 +54,13 @@ __device__ __forceinline__ bool world_z(const PointParams &P, const F3 &v, doubl
   wz = wz + P.b[2];
   return wz > P.zMin && wz < P.zMax;
 }
+/* world_z without the early exit, for flat code (wz is meaningless when false is returned) */
+__device__ __forceinline__ bool world_z_flat(const PointParams &P, const F3 &v, double &wz)
+{
+  wz = (P.a[6] * static_cast<double>(v.x) + P.a[7] * static_cast<double>(v.y)) + P.a[8] * static_cast<double>(v.z);
+  wz = wz + P.b[2];
+  return v.z > 0.0f && wz > P.zMin && wz < P.zMax;
+}
 __device__ __forceinline__ bool world_xy(const PointParams &P, const F3 &v, double &wx, double &wy)
 {
   const double x = v.x, y = v.y, z = v.z;
@@ -1896,21 +1903,19 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
     #pragma unroll
     for(int j = 0; j < kPts; j++)
     {
+      /* few, flat decisions per point: every nested divergent exit costs exec-mask registers and copies at its
+       * join, more than the handful of predicated instructions it skips */
       double wx, wy, wz;
-      if(!world_z(P, v[j], wz))
-        continue;
-      const int p = lut[height_bin(P, wz)];
-      if(p == 0xff)
-        continue;
-      const int q = p == groundInd ? kGroundAcc : p;
-      if(!active[q])
-        continue;
-      if(!world_xy(P, v[j], wx, wy))
+      const bool okz = world_z_flat(P, v[j], wz);
+      const int p = lut[okz ? height_bin(P, wz) : 0];
+      const int q = p == groundInd ? kGroundAcc : (p == 0xff ? kGroundAcc : p);
+      if(!(okz && p != 0xff && active[q]))
         continue;
       {
+        const bool okxy = world_xy(P, v[j], wx, wy);
         const QuadTest &t = qts[q];
         const bool fast = wx >= t.fx0 && wx < t.fx1 && wy >= t.fy0 && wy < t.fy1;
-        if(!fast && !quad_test(t, wx, wy))
+        if(!okxy || (!fast && !quad_test(t, wx, wy)))
           continue;
       }
       if(q != curQ)
