@@ -670,29 +670,27 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
     #pragma unroll
     for(int j = 0; j < kPts; j++)
     {
+      /* few, flat decisions per point (see k_inquad) */
       double wx, wy, wz;
-      if(!world_z(P, v[j], wz))
-        continue;
-      const int slot = static_cast<int>(lut[height_bin(P, wz)]) - firstStep;   /* 0xff - firstStep >= nImg */
-      if(slot < 0 || slot >= nImg)
-        continue;
-      if(!world_xy(P, v[j], wx, wy))
+      const bool okz = world_z_flat(P, v[j], wz);
+      const int slot = static_cast<int>(lut[okz ? height_bin(P, wz) : 0]) - firstStep;   /* 0xff - firstStep >= nImg */
+      if(!(okz && slot >= 0 && slot < nImg))
         continue;
       int ix, iy;
-      if(!image_pixel(P, X, wx, wy, ix, iy))
-      {
-        oob++;                                              /* quirk Q5 */
+      const bool okxy = world_xy(P, v[j], wx, wy);
+      const bool inside = image_pixel(P, X, wx, wy, ix, iy);
+      if(!okxy)
         continue;
-      }
+      oob += inside ? 0u : 1u;                                /* quirk Q5 */
       const unsigned long long bit = 1ull << (ix & 63);
-      if(slot == pSlot && iy == pY && (ix >> 6) == pXw)
-      {
-        pMask |= bit;
-        continue;
-      }
-      if(pSlot >= 0)
+      const int xw = ix >> 6;
+      const bool same = slot == pSlot && iy == pY && xw == pXw;
+      if(inside && !same && pSlot >= 0)
         wavewin_or(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, boxes, mb, pSlot, pY, pXw, pMask);
-      pSlot = slot; pY = iy; pXw = ix >> 6; pMask = bit;
+      pMask = inside ? (same ? (pMask | bit) : bit) : pMask;
+      pSlot = inside ? slot : pSlot;
+      pY = inside ? iy : pY;
+      pXw = inside ? xw : pXw;
     }
     if(pSlot >= 0)
       wavewin_or(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, boxes, mb, pSlot, pY, pXw, pMask);
@@ -1927,22 +1925,19 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
       accN++;
       if(q == kGroundAcc)
       {
-        /* projectToBinaryImage(pointsInQuadri) (pointcloud.cpp:531) */
+        /* projectToBinaryImage(pointsInQuadri) (pointcloud.cpp:531); the lane's pending word (pY, pXw, pMask) goes
+         * out when the next pixel falls into another word */
         int ix, iy;
-        if(!image_pixel(P, X, wx, wy, ix, iy))
-        {
-          oob++;
-          continue;
-        }
+        const bool inside = image_pixel(P, X, wx, wy, ix, iy);
+        oob += inside ? 0u : 1u;                              /* quirk Q5 */
         const unsigned long long bit = 1ull << (ix & 63);
-        if(iy == pY && (ix >> 6) == pXw)
-        {
-          pMask |= bit;
-          continue;
-        }
-        if(pY >= 0)
+        const int xw = ix >> 6;
+        const bool same = iy == pY && xw == pXw;
+        if(inside && !same && pY >= 0)
           wavewin_or(ww, wm, win, gimg, imgWords, X.W64, X.winShift, box, mb, 0, pY, pXw, pMask);
-        pY = iy; pXw = ix >> 6; pMask = bit;
+        pMask = inside ? (same ? (pMask | bit) : bit) : pMask;
+        pY = inside ? iy : pY;
+        pXw = inside ? xw : pXw;
       }
     }
     if(pY >= 0)
