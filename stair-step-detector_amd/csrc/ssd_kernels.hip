@@ -1801,6 +1801,12 @@ __device__ __forceinline__ long long z_to_fixed(double z)
   const double magic = 6144.0;
   return __double_as_longlong(z + magic) - __double_as_longlong(magic);
 }
+/* the same in two halves for running sums: n values of z_plus_magic_bits minus n * kMagicBits */
+__device__ __forceinline__ long long z_plus_magic_bits(double z)
+{
+  return __double_as_longlong(z + 6144.0);
+}
+constexpr long long kMagicBits = 0x40B8000000000000ll;       /* bits of 6144.0 */
 
 template<int SRC>
 __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
@@ -1830,7 +1836,12 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
   }
 
   if(tid < kMaxBins)
-    lut[tid] = fs.lut[tid];
+  {
+    /* bin -> accumulator of a live quadrilateral, 0xff = nothing to do for this bin */
+    const int p = fs.lut[tid];
+    const int q = p == fs.groundInd ? kGroundAcc : p;
+    lut[tid] = (p != 0xff && fs.accActive[q]) ? static_cast<unsigned char>(q) : static_cast<unsigned char>(0xff);
+  }
   if(tid <= kMaxPlateaus)
     active[tid] = fs.accActive[tid];
   for(int i = tid; i < (kMaxPlateaus + 1) * 8; i += kThreads)
@@ -1856,7 +1867,6 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
   }
   __syncthreads();
 
-  const int groundInd = fs.groundInd;
   /* strideFloats counts floats, or 16-bit depth values for kSrcDepth16 */
   const float *base = SRC == kSrcDepth16
     ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(xyz) + static_cast<size_t>(frame) * strideFloats)
@@ -1877,13 +1887,13 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
    * camera column, so consecutive hits nearly always belong to the same quadrilateral — the running sum
    * stays in registers and goes to LDS only when the quadrilateral changes */
   int curQ = -1;
-  long long accZ = 0;
+  unsigned long long accZ = 0;                               /* modulo 2^64: see z_plus_magic_bits */
   unsigned int accN = 0, oob = 0;
   auto flushAcc = [&]()
   {
     if(curQ >= 0 && accN)
     {
-      atomicAdd(&lsum[curQ][copy], static_cast<unsigned long long>(accZ));
+      atomicAdd(&lsum[curQ][copy], accZ - static_cast<unsigned long long>(accN) * static_cast<unsigned long long>(kMagicBits));
       atomicAdd(&lcnt[curQ][copy], accN);
     }
   };
@@ -1905,9 +1915,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
        * join, more than the handful of predicated instructions it skips */
       double wx, wy, wz;
       const bool okz = world_z_flat(P, v[j], wz);
-      const int p = lut[okz ? height_bin(P, wz) : 0];
-      const int q = p == groundInd ? kGroundAcc : (p == 0xff ? kGroundAcc : p);
-      if(!(okz && p != 0xff && active[q]))
+      const int q = lut[okz ? height_bin(P, wz) : 0];
+      if(!(okz && q != 0xff))
         continue;
       {
         const bool okxy = world_xy(P, v[j], wx, wy);
@@ -1921,7 +1930,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
         flushAcc();
         curQ = q; accZ = 0; accN = 0;
       }
-      accZ += z_to_fixed(wz);
+      accZ += static_cast<unsigned long long>(z_plus_magic_bits(wz));                        /* the constant's bits come off at the flush */
       accN++;
       if(q == kGroundAcc)
       {
