@@ -625,7 +625,11 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
     return;
   const int firstStep = fs.firstStep;
   if(tid < kMaxBins)
-    lut[tid] = fs.lut[tid];
+  {
+    /* bin -> image slot of a step plateau, 0xff = no image for this bin */
+    const int sl = static_cast<int>(fs.lut[tid]) - firstStep;
+    lut[tid] = (fs.lut[tid] != 0xff && sl >= 0 && sl < nImg) ? static_cast<unsigned char>(sl) : static_cast<unsigned char>(0xff);
+  }
   if(tid < kMaxStepImages)
     boxes[tid] = ImageBox{ 0x7fffffff, -1, 0x7fffffff, -1 };
   if(tid == 0)
@@ -673,8 +677,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
       /* few, flat decisions per point (see k_inquad) */
       double wx, wy, wz;
       const bool okz = world_z_flat(P, v[j], wz);
-      const int slot = static_cast<int>(lut[okz ? height_bin(P, wz) : 0]) - firstStep;   /* 0xff - firstStep >= nImg */
-      if(!(okz && slot >= 0 && slot < nImg))
+      const int slot = lut[okz ? height_bin(P, wz) : 0];
+      if(!(okz && slot != 0xff))
         continue;
       int ix, iy;
       const bool okxy = world_xy(P, v[j], wx, wy);
