@@ -300,6 +300,10 @@ int ssd_device_sync(int device);
 /* test hooks: std::hypot as the kernels compute it (glibc 2.35 algorithm restated), host and device */
 double ssd_test_hypot_host(double a, double b);
 int ssd_test_hypot_device(int device, const double *a, const double *b, double *out, int n);
+/* test hook: QuadrilateralTest (quadrilateralTest.cpp:275-451) exactly as the kernels build and evaluate it, for one
+ * quadrilateral (front-left, front-right, back-left, back-right as x,y) and n points; *err = 0 or the code of the
+ * reference's throw (-1..-6), in which case `inside` is left zero */
+int ssd_test_quad_device(int device, const double quad[8], const double *pts_xy, int n, uint8_t *inside, int *err);
 /* test hook: the raw per-frame device state after the last enqueue (layout private to the library; layout[0..7] =
  * sizeof state, offsets of hist, lut, image boxes, plateau table, quadrilateral tests, sums, counts); returns the
  * number of bytes copied or a negative error */

@@ -130,7 +130,7 @@ EXPORTS = [
     "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
     "ssd_synth_generate_host", "ssd_synth_generate_device", "ssd_synth_scene_to_camera",
     "ssd_device_count", "ssd_device_alloc", "ssd_device_free", "ssd_device_upload", "ssd_device_download",
-    "ssd_device_sync", "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state",
+    "ssd_device_sync", "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_quad_device",
 ]
 
 _lib = None
@@ -187,6 +187,7 @@ def lib():
     L.ssd_test_hypot_host.argtypes = [C.c_double, C.c_double]
     L.ssd_test_hypot_device.argtypes = [i32, vp, vp, vp, i32]
     L.ssd_test_frame_state.argtypes = [vp, i32, vp, C.c_size_t, vp]
+    L.ssd_test_quad_device.argtypes = [i32, vp, vp, i32, vp, C.POINTER(C.c_int)]
     L.ssd_test_frame_state.restype = C.c_longlong
     _lib = L
     return L
@@ -395,6 +396,17 @@ class Pointcloud:
 
 
 # --------------------------------------------------------------------------- synthetic frame source
+def quad_test_device(quad, pts, device=0):
+    """test hook: the kernels' QuadrilateralTest on one quadrilateral -> (err code, uint8 inside[n])"""
+    q = np.ascontiguousarray(quad, dtype=np.float64).reshape(8)
+    p = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros(len(p), dtype=np.uint8)
+    err = C.c_int(0)
+    _check(lib().ssd_test_quad_device(device, q.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), len(p),
+                                      out.ctypes.data_as(C.c_void_p), C.byref(err)))
+    return err.value, out
+
+
 def make_scene(width, height, n_steps=3, seed=12345, cam_height=1.0, pitch_deg=50.0, roll_deg=0.0,
                first_riser_y=0.45, tread=0.28, rise=0.17, stair_width=0.8, landing=1.0, yaw_deg=0.0,
                sigma=0.001, outlier_frac=0.0, outlier_min=0.3, outlier_max=3.0, invalid_frac=0.0,

@@ -1048,6 +1048,31 @@ long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, 
   return static_cast<long long>(n);
 }
 
+int ssd_test_quad_device(int device, const double quad[8], const double *pts_xy, int n, uint8_t *inside, int *err)
+{
+  if(!quad || !pts_xy || !inside || !err || n < 1)
+    return fail(SSD_E_ARG, "ssd_test_quad_device: bad argument");
+  if(ssd_device_count() <= 0)
+    return fail(SSD_E_NODEVICE, "ssd_test_quad_device: no HIP device");
+  HIP_TRY(hipSetDevice(device));
+  double *dq = nullptr, *dp = nullptr;
+  unsigned char *di = nullptr;
+  int *de = nullptr;
+  HIP_TRY(hipMalloc(&dq, 8 * sizeof(double)));
+  HIP_TRY(hipMalloc(&dp, static_cast<size_t>(n) * 2 * sizeof(double)));
+  HIP_TRY(hipMalloc(&di, static_cast<size_t>(n)));
+  HIP_TRY(hipMalloc(&de, sizeof(int)));
+  HIP_TRY(hipMemcpy(dq, quad, 8 * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dp, pts_xy, static_cast<size_t>(n) * 2 * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(di, 0, static_cast<size_t>(n)));
+  launch_quadtest(dq, dp, n, di, de, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(inside, di, static_cast<size_t>(n), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(err, de, sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(dq); (void)hipFree(dp); (void)hipFree(di); (void)hipFree(de);
+  return SSD_OK;
+}
+
 int ssd_test_hypot_device(int device, const double *a, const double *b, double *out, int n)
 {
   if(ssd_device_count() <= 0)

@@ -2418,6 +2418,34 @@ __global__ void k_riser_results(Params P, const FrameState *__restrict__ st, ssd
   }
 }
 
+/* test hook: QuadrilateralTest as the kernels build and evaluate it (build_quad_test + the constant cell + quad_test),
+ * one quadrilateral, n points; err = the negative code of the reference's throw or 0 */
+__global__ void k_quadtest(const double *__restrict__ quad, const double *__restrict__ pts, int n, unsigned char *__restrict__ inside,
+                           int *__restrict__ err)
+{
+  __shared__ QuadTest t;
+  if(threadIdx.x == 0)
+  {
+    double q[8];
+    for(int k = 0; k < 8; k++)
+      q[k] = quad[k];
+    QuadTest local;
+    build_quad_test(q, local);
+    t = local;
+    if(blockIdx.x == 0)
+      *err = local.err;
+  }
+  __syncthreads();
+  if(t.err)
+    return;
+  for(int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+  {
+    const double x = pts[2 * i], y = pts[2 * i + 1];
+    const bool fast = x >= t.fx0 && x < t.fx1 && y >= t.fy0 && y < t.fy1;
+    inside[i] = (fast || quad_test(t, x, y)) ? 1 : 0;
+  }
+}
+
 /* ========================================================================= */
 /* synthetic frame source                                                      */
 
@@ -2561,6 +2589,10 @@ void launch_synth_depth(const ssd_scene *dScenes, unsigned short *depth, size_t 
   if(bx > 2048) bx = 2048;
   if(bx < 1) bx = 1;
   hipLaunchKernelGGL(k_synth_depth, dim3(bx, nframes), dim3(kThreads), 0, s, dScenes, depth, strideElems, depthUnits);
+}
+void launch_quadtest(const double *quad, const double *pts, int n, unsigned char *inside, int *err, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_quadtest, dim3(n > 4096 ? 16 : 1), dim3(256), 0, s, quad, pts, n, inside, err);
 }
 void launch_hypot(const double *a, const double *b, double *out, int n, hipStream_t s)
 {

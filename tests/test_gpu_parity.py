@@ -330,6 +330,48 @@ def test_host_batches_larger_than_the_workspace_are_processed_in_chunks(ssd, ora
     small.close()
 
 
+def test_device_quadrilateral_test_against_the_reference_goldens(ssd, gpu_device):
+    """PINNED: the kernels' QuadrilateralTest (cell map, constant cell, throw codes) against vectors produced by the
+    reference's own quadrilateralTest.cpp (tests/golden/ref_quadtest.json, generator make_ref_goldens.py)."""
+    import json
+    import os
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_quadtest.json")))
+    seen = set()
+    for c in cases:
+        quad = np.array([float.fromhex(x) for x in c["quad"]]).reshape(4, 2)
+        pts = np.array([float.fromhex(x) for x in c["pts"]]).reshape(-1, 2)
+        err, inside = ssd.quad_test_device(quad, pts, gpu_device)
+        assert err == c["rc"], (err, c["rc"])
+        seen.add(err)
+        if err == 0:
+            assert "".join(str(int(v)) for v in inside) == c["inside"]
+    assert 0 in seen and -1 in seen
+
+
+def test_device_quadrilateral_test_live_against_the_reference(ssd, ref, gpu_device):
+    """The same against oracle/_ref (the reference's quadrilateralTest.cpp compiled in place), on fresh random
+    quadrilaterals including points one ulp around the corners; skipped where oracle/_ref was not built."""
+    rng = np.random.default_rng(2024)
+    codes = set()
+    for i in range(300):
+        if i % 2:
+            q = rng.uniform(-1, 1, (4, 2))
+        else:
+            a = rng.uniform(0, np.pi)
+            w, d = rng.uniform(0.02, 1.0), rng.uniform(0.02, 0.5)
+            base = np.array([[-w, -d], [w, -d], [-w, d], [w, d]]) * (1 + rng.normal(0, 0.1, (4, 2)))
+            q = base @ np.array([[np.cos(a), np.sin(a)], [-np.sin(a), np.cos(a)]])
+        lo, hi = q.min(0), q.max(0)
+        pts = np.concatenate([rng.uniform(lo - 0.1, hi + 0.1, (400, 2)), q, np.nextafter(q, np.inf), np.nextafter(q, -np.inf)])
+        rc_r, in_r = ref.quad_test(q, pts)
+        rc_d, in_d = ssd.quad_test_device(q, pts, gpu_device)
+        assert rc_d == rc_r
+        codes.add(rc_r)
+        if rc_r == 0:
+            assert np.array_equal(in_d, in_r)
+    assert 0 in codes and -1 in codes
+
+
 def test_randomised_sweep_small(ssd, gpu_device):
     """tools/fuzz.py at test size: 8 random poses x 32 frames (four resolutions, depth input and non-default
     configurations included), every frame of the batch path against the oracle."""
