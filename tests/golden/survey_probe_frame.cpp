@@ -7,8 +7,11 @@
  * tests/test_oracle.py with g++ at test time.  libstdc++'s mt19937 / normal_distribution sequences are what the
  * anchor values were produced with (same image on the GPU box).
  *
- * usage: survey_probe_frame W H out.bin [K sigma]   ->  writes W*H float32 xyz; prints the 3 camera-space
- * calibration points (9 numbers) that go with the world points (-0.5,1.2,0) (0.5,1.2,0) (0.4,0.3,0).
+ * usage: survey_probe_frame W H out.bin [K sigma [camH pitchDeg y0 tread rise halfW outliers]]
+ *        ->  writes W*H float32 xyz; prints the 3 camera-space calibration points (9 numbers) that go with the
+ *            world points (-0.5,1.2,0) (0.5,1.2,0) (0.4,0.3,0).
+ * The optional scene parameters are the probe's knobs (camera height and pitch, first riser distance, tread, rise,
+ * half stair width, fraction of pixels replaced by a uniform depth in [0.3, 3] m).
  */
 #include <cmath>
 #include <cstdio>
@@ -32,13 +35,14 @@ int main(int argc, char **argv)
   const int K = argc > 4 ? atoi(argv[4]) : 3;
   const double sigma = argc > 5 ? atof(argv[5]) : 0.001;
 
+  auto arg = [&](int i, double dflt) { return argc > i ? atof(argv[i]) : dflt; };
   /* camera 1.0 m above the ground, pitched 50 degrees down; 70 x 55 degrees field of view */
-  const double pitch = 50.0 * M_PI / 180;
-  const Vec eye{ 0, 0, 1.0 }, right{ 1, 0, 0 }, fwd{ 0, cos(pitch), -sin(pitch) }, down{ 0, -sin(pitch), -cos(pitch) };
+  const double pitch = arg(7, 50.0) * M_PI / 180;
+  const Vec eye{ 0, 0, arg(6, 1.0) }, right{ 1, 0, 0 }, fwd{ 0, cos(pitch), -sin(pitch) }, down{ 0, -sin(pitch), -cos(pitch) };
   const double fx = (W / 2.0) / tan(35 * M_PI / 180), fy = (H / 2.0) / tan(27.5 * M_PI / 180);
   const double ppx = W / 2.0, ppy = H / 2.0;
   /* stairs: first riser 0.45 m ahead, 0.8 m wide, tread 0.28 m, rise 0.17 m, the last tread unbounded */
-  const double y0 = 0.45, tread = 0.28, rise = 0.17, halfW = 0.4;
+  const double y0 = arg(8, 0.45), tread = arg(9, 0.28), rise = arg(10, 0.17), halfW = arg(11, 0.4), outliers = arg(12, 0.0);
 
   std::mt19937 rng(12345);
   std::normal_distribution<double> noise(0.0, sigma);
@@ -67,7 +71,9 @@ int main(int argc, char **argv)
       }
       if(best < 9.0)
       {
-        const double depth = best + noise(rng);
+        double depth = best + noise(rng);
+        if(outliers > 0 && std::uniform_real_distribution<double>(0, 1)(rng) < outliers)
+          depth = std::uniform_real_distribution<double>(0.3, 3.0)(rng);
         float *o = &xyz[(size_t(v) * W + u) * 3];
         o[0] = float(dx * depth);
         o[1] = float(dy * depth);

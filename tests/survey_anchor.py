@@ -33,12 +33,30 @@ OBSERVED_LINE = ('["stairs",["stairSteps",4],[[["height",0.000],["quadrilateral"
                  '[["height",0.510],["quadrilateral",[-0.400,1.009],[0.398,1.009],[-0.400,1.183],[0.398,1.183]]]]]')
 
 
-def frame(tmp_path, width=1024, height=768):
-    """Compiles tests/golden/survey_probe_frame.cpp, runs it; returns (xyz float32[W*H*3], camera points[9])."""
+def _generator(tmp_path):
     exe = os.path.join(str(tmp_path), "survey_probe_frame")
+    if not os.path.exists(exe):
+        subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(HERE, "golden", "survey_probe_frame.cpp"), "-o", exe], check=True)
+    return exe
+
+
+def frame(tmp_path, width=1024, height=768, case=None):
+    """Compiles tests/golden/survey_probe_frame.cpp (once per tmp_path), runs it; returns (xyz float32[W*H*3], camera
+    points[9]).  `case`: one entry of tests/golden/survey_probe_lines.json (scene knobs)."""
+    exe = _generator(tmp_path)
     out = os.path.join(str(tmp_path), "frame.bin")
-    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(HERE, "golden", "survey_probe_frame.cpp"), "-o", exe], check=True)
-    p = subprocess.run([exe, str(width), str(height), out], check=True, capture_output=True, text=True)
+    args = [exe, str(width), str(height), out]
+    if case is not None:
+        args = [exe, str(case["width"]), str(case["height"]), out, str(case["steps"]), repr(case["sigma"]), repr(case["cam_height"]),
+                repr(case["pitch_deg"]), repr(case["first_riser_y"]), repr(case["tread"]), repr(case["rise"]), repr(case["half_width"]),
+                repr(case["outliers"])]
+    p = subprocess.run(args, check=True, capture_output=True, text=True)
     cam = np.array(p.stdout.split(), dtype=np.float64)
     assert cam.shape == (9,)
     return np.fromfile(out, dtype=np.float32), cam
+
+
+def probe_cases():
+    """The 39 further runs of the survey's probe binaries (see the file's own header): parameters + printed line."""
+    import json
+    return json.load(open(os.path.join(HERE, "golden", "survey_probe_lines.json")))["cases"]

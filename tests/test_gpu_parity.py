@@ -330,6 +330,20 @@ def test_host_batches_larger_than_the_workspace_are_processed_in_chunks(ssd, ora
     small.close()
 
 
+def test_hip_path_reproduces_39_further_lines_of_the_surveys_probe(ssd, gpu_device, tmp_path):
+    """The same 39 anchor lines (tests/golden/survey_probe_lines.json) through the HIP path, production mode."""
+    import survey_anchor as sa
+    dets = {}
+    for c in sa.probe_cases():
+        xyz, cam = sa.frame(tmp_path, case=c)
+        trans = ssd.GeometricTransformation(sa.WORLD_POINTS.reshape(3, 3), cam.reshape(3, 3))
+        det = ssd.Detector(ssd.default_config(c["width"], c["height"], max_frames_per_batch=1), trans, gpu_device)
+        fr = det.process_host(xyz)[0]
+        det.close()
+        assert fr.status == 0
+        assert ssd.Stairs(fr).serialize() == c["line"], c
+
+
 def test_device_quadrilateral_test_against_the_reference_goldens(ssd, gpu_device):
     """PINNED: the kernels' QuadrilateralTest (cell map, constant cell, throw codes) against vectors produced by the
     reference's own quadrilateralTest.cpp (tests/golden/ref_quadtest.json, generator make_ref_goldens.py)."""

@@ -29,6 +29,26 @@ def test_oracle_reproduces_the_surveys_observed_run(oracle, tmp_path):
     assert oracle.serialize(steps) == sa.OBSERVED_LINE
 
 
+def test_oracle_reproduces_39_further_lines_of_the_surveys_probe(oracle, tmp_path):
+    """VGA / XGA / FHD x 0-8 steps, noise 0-5 mm, up to 20 % outliers, other camera poses and stair geometries: the
+    oracle's serialized line against what the survey's probe binaries printed (anchors, not pins: tests/golden/
+    survey_probe_lines.json says where they come from)."""
+    import survey_anchor as sa
+    cases = sa.probe_cases()
+    assert len(cases) == 39
+    n_with_steps = 0
+    for c in cases:
+        xyz, cam = sa.frame(tmp_path, case=c)
+        rc, cal = oracle.calibration(sa.WORLD_POINTS, cam)
+        assert rc == 0
+        n, steps, status = oracle.process_lean(oracle.config(c["width"], c["height"]), cal, xyz)
+        assert status == 0
+        line = oracle.serialize(steps) if n > 0 else '["stairs",["stairSteps",0]]'
+        assert line == c["line"], (c, line)
+        n_with_steps += 1 if n > 0 else 0
+    assert n_with_steps >= 30
+
+
 # ------------------------------------------------------------------ golden vectors from the real reference
 def test_serialize_matches_reference_goldens(oracle):
     cases = json.load(open(os.path.join(HERE, "golden", "ref_serialize.json")))
