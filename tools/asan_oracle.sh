@@ -1,0 +1,30 @@
+#!/bin/bash
+# tools/asan_oracle.sh — the CPU oracle (the checker) under AddressSanitizer + UBSan on every named scene:
+# full run with images, lean run, riser statement.  CPU only (GPU sanitizers are not available on this pool).
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=${TMPDIR:-/tmp}/ssd_asan
+mkdir -p $OUT
+g++ -std=c++17 -O1 -g -ffp-contract=off -fPIC -shared -fsanitize=address,undefined -fno-sanitize-recover=undefined \
+    -o $OUT/libssd_oracle.so $ROOT/oracle/ssd_oracle.cpp
+cd $ROOT/tests
+LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 SSD_ASAN_LIB=$OUT/libssd_oracle.so python - <<'PY'
+import importlib, os, sys
+sys.path.insert(0, ".."); sys.path.insert(0, ".")
+import oracle_binding as ob
+ob.ORACLE_LIB = os.environ["SSD_ASAN_LIB"]
+o = ob.load_oracle()
+ssd = importlib.import_module("stair-step-detector_amd")
+import scenes
+names = sorted(scenes.scene_params().keys())
+for name in names:
+    sc = scenes.make(ssd, name)
+    xyz = ssd.synth_host([sc])[0]
+    trans = ssd.transformation_for_scene(sc)
+    cfg = ssd.default_config(sc.width, sc.height)
+    ocfg, ocal = ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants)
+    o.process(ocfg, ocal, xyz, images=4, ground_images=True)
+    o.process_lean(ocfg, ocal, xyz)
+    o.risers(ocfg, ocal, xyz)
+print("oracle under ASan+UBSan: %d scenes clean" % len(names))
+PY
