@@ -20,7 +20,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libssd_hip.so")
+LIB_PATH = os.environ.get("SSD_HIP_LIB") or os.path.join(_HERE, "lib", "libssd_hip.so")   # override: sanitizer builds (tools/)
 
 MAX_BINS = 128
 MAX_PLATEAUS = 32
