@@ -25,6 +25,26 @@ def test_library_exports_every_declared_symbol(ssd):
     assert set(ssd.EXPORTS) <= declared
 
 
+def test_header_is_plain_c_and_links(ssd, tmp_path):
+    """include/ssd_hip.h must be consumable from C (cgo / JNI / ctypes-style bindings): a C99 translation unit that
+    includes it, takes the address of every declared entry point and links against libssd_hip.so."""
+    import subprocess
+    header = open(os.path.join(ROOT, "include", "ssd_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(ssd_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", header, flags=re.S))))
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "ssd_hip.h"\n#include <stdio.h>\ntypedef void (*fn)(void);\nint main(void)\n{\n  const fn f[] = { %s };\n'
+                   '  ssd_config cfg; ssd_frame_result r; ssd_frame_risers rr; (void)r; (void)rr;\n'
+                   '  if(ssd_default_config(&cfg, 640, 480) != SSD_OK) return 1;\n'
+                   '  printf("%%d %%d\\n", (int)(sizeof f / sizeof f[0]), cfg.width);\n  return 0;\n}\n'
+                   % ", ".join("(fn)%s" % n for n in names))
+    exe = tmp_path / "use_header"
+    libdir = os.path.dirname(ssd.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-lssd_hip", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) == len(names) and out[1] == "640"
+
+
 def test_struct_layouts_match_the_header(ssd):
     """ctypes mirrors must have the C sizes (computed from the header's constants)."""
     assert C.sizeof(ssd.Step) == 72
