@@ -806,15 +806,28 @@ __device__ __forceinline__ void closed_column(const BitImg &im, int c, int yA, i
 #pragma unroll
   for(int r = 1; r < 5; r++)
     h[r] = hdilated_row(im, yA - 3 + r, c);
-  for(int y = yA; y < yB; y++)
+  /* four rows per step: their twelve word loads are issued together (one memory round trip instead of four — the
+   * walk is a chain of dependent latencies, and with outliers the box is the whole image) */
+  for(int y0 = yA; y0 < yB; y0 += 4)
   {
+    HRow next[4];
 #pragma unroll
-    for(int r = 0; r < 4; r++)
-      h[r] = h[r + 1];
-    h[4] = hdilated_row(im, y + 2, c);
-    if(!all && (h[0].c | h[1].c | h[2].c | h[3].c | h[4].c) == 0ull)
-      continue;                                   /* nothing lit within two rows: the closing has nothing either */
-    visit(y, closed_from_rows(im, y, c, h));
+    for(int k = 0; k < 4; k++)
+      next[k] = hdilated_row(im, y0 + k + 2, c);          /* rows beyond the image read as zero */
+#pragma unroll
+    for(int k = 0; k < 4; k++)
+    {
+      const int y = y0 + k;
+#pragma unroll
+      for(int r = 0; r < 4; r++)
+        h[r] = h[r + 1];
+      h[4] = next[k];
+      if(y >= yB)
+        continue;
+      if(!all && (h[0].c | h[1].c | h[2].c | h[3].c | h[4].c) == 0ull)
+        continue;                                 /* nothing lit within two rows: the closing has nothing either */
+      visit(y, closed_from_rows(im, y, c, h));
+    }
   }
 }
 
