@@ -2015,6 +2015,8 @@ struct FinalShared
   int px[kMaxCols], py[kMaxCols];
   int n;
   LineI line;
+  double stepsWorld[SSD_MAX_STEPS][9];       /* z, 4 x (x,y) in camera-dependent world coordinates; thread 0 only:
+                                                in LDS because a private array would live in scratch memory */
 };
 
 __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__restrict__ st,
@@ -2129,7 +2131,7 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
   if(tid == 0)
   {
     int n = 0;
-    double stepsWorld[SSD_MAX_STEPS][9];       /* z, 4 x (x,y) in camera-dependent world coordinates */
+    double (&stepsWorld)[SSD_MAX_STEPS][9] = S.stepsWorld;
     if(!threw && fs.firstValidInd >= 0)
     {
       if(fs.groundInd >= 0)
