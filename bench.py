@@ -102,15 +102,23 @@ def main():
     else:
         ssd.synth_device(sc_list, frames.data_ptr(), device=local_rank, stream=stream)
 
-    def step():
+    def enqueue():
         if depth_in:
             det.enqueue_depth(frames.data_ptr(), F, stream=stream)
         else:
             det.enqueue(frames.data_ptr(), F, stream=stream)
-        return det.fetch(F, stream=stream)
 
-    for _ in range(args.warmup):
-        res = step()
+    def run(n_steps):
+        """n_steps passes over the batch, every pass's results fetched to the host: pass i+1 is enqueued before the
+        results of pass i are read (they travel with their own enqueue), so the GPU never waits for the host."""
+        res = None
+        for i in range(n_steps):
+            enqueue()
+            if i > 0:
+                res = det.fetch(F, back=1)
+        return det.fetch(F) if n_steps > 0 else res
+
+    res = run(args.warmup)
 
     def fence():
         torch.cuda.synchronize()
@@ -120,8 +128,7 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    res = run(args.steps)
     fence()
     dt = time.perf_counter() - t0
 

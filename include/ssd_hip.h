@@ -118,11 +118,16 @@ size_t ssd_workspace_bytes(const ssd_handle *h);
  * ssd_enqueue:        frames already in device memory (frame i at d_xyz + i*frame_stride_bytes); enqueues the
  *                     whole pipeline on `stream` (a hipStream_t, NULL = default stream) and returns without
  *                     synchronising. nframes <= max_frames_per_batch.
- * ssd_fetch:          waits for the last ssd_enqueue on that stream and copies its results to the host.
+ * ssd_fetch:          waits for the last ssd_enqueue (whose last step is the copy of its results into pinned host
+ *                     memory) and hands its results over.
  */
 int ssd_process_host(ssd_handle *h, const float *xyz, int nframes, ssd_frame_result *results);
 int ssd_enqueue(ssd_handle *h, const void *d_xyz, size_t frame_stride_bytes, int nframes, void *stream);
 int ssd_fetch(ssd_handle *h, ssd_frame_result *results, int nframes, void *stream);
+/* The results of a batch travel to the host as part of its ssd_enqueue (two slots, used alternately), so a caller may
+ * keep the GPU busy: ssd_enqueue(batch i+1) first, then ssd_fetch_back(.., back = 1) for batch i.  back = 0 is
+ * ssd_fetch.  Waits only for that batch. */
+int ssd_fetch_back(ssd_handle *h, ssd_frame_result *results, int nframes, int back);
 
 /* ---- 16-bit depth input ---------------------------------------------
  * The step before the path in the reference is rs2::pointcloud::calculate (pointcloud.cpp:138): depth image ->

@@ -126,7 +126,7 @@ EXPORTS = [
     "ssd_process_host", "ssd_enqueue", "ssd_fetch", "ssd_enqueue_stages",
     "ssd_set_intrinsics", "ssd_process_depth_host", "ssd_enqueue_depth", "ssd_deproject_host",
     "ssd_synth_depth_host", "ssd_synth_depth_device",
-    "ssd_set_risers", "ssd_fetch_risers", "ssd_set_timing", "ssd_get_stage_times", "ssd_get_stage_times_back", "ssd_serialize",
+    "ssd_fetch_back", "ssd_set_risers", "ssd_fetch_risers", "ssd_set_timing", "ssd_get_stage_times", "ssd_get_stage_times_back", "ssd_serialize",
     "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
     "ssd_synth_generate_host", "ssd_synth_generate_device", "ssd_synth_scene_to_camera",
     "ssd_device_count", "ssd_device_alloc", "ssd_device_free", "ssd_device_upload", "ssd_device_download",
@@ -167,6 +167,7 @@ def lib():
     L.ssd_synth_depth_host.argtypes = [C.POINTER(Scene), i32, C.c_float, vp]
     L.ssd_synth_depth_device.argtypes = [C.POINTER(Scene), i32, C.c_float, vp, sz, i32, vp]
     L.ssd_set_timing.argtypes = [vp, i32]
+    L.ssd_fetch_back.argtypes = [vp, C.POINTER(FrameResult), i32, i32]
     L.ssd_set_risers.argtypes = [vp, i32, C.c_double, i32]
     L.ssd_fetch_risers.argtypes = [vp, C.POINTER(FrameRisers), i32, vp]
     L.ssd_get_stage_times.argtypes = [vp, C.POINTER(C.c_float)]
@@ -319,12 +320,13 @@ class Detector:
         _check(lib().ssd_enqueue_stages(self._h, C.c_void_p(d_ptr), stride_bytes or self.frame_bytes, nframes,
                                         C.c_void_p(stream or 0), stages))
 
-    def fetch(self, nframes, stream=None):
-        """Waits for the last enqueue and returns its results (an indexable ctypes array of FrameResult; the
-        buffer is reused by the next fetch of the same size)."""
+    def fetch(self, nframes, stream=None, back=0):
+        """Waits for the last enqueue (back = 1: the one before it, so that the next batch can already be running) and
+        returns its results (an indexable ctypes array of FrameResult; the buffer is reused by the next fetch of the
+        same size)."""
         if getattr(self, "_res_n", 0) != nframes:
             self._res, self._res_n = (FrameResult * nframes)(), nframes
-        _check(lib().ssd_fetch(self._h, self._res, nframes, C.c_void_p(stream or 0)))
+        _check(lib().ssd_fetch_back(self._h, self._res, nframes, back))
         return self._res
 
     def fetch_list(self, nframes, stream=None):

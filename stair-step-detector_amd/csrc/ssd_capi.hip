@@ -61,8 +61,13 @@ struct ssd_handle
   float *dDepthMaps = nullptr;              /* xmap[W] then ymap[H] (ssd_set_intrinsics) */
   ssd_intrinsics intr{};
   bool haveIntr = false;
-  ssd_frame_result *dResults = nullptr;
-  ssd_frame_result *hResults = nullptr;     /* pinned */
+  /* two result slots, used alternately by the enqueues that run the last stage: the device -> pinned-host copy of
+   * a batch's results is part of its enqueue, so that the next batch can be enqueued before the results are read */
+  ssd_frame_result *dResults = nullptr;     /* 2 x F */
+  ssd_frame_result *hResults = nullptr;     /* 2 x F, pinned */
+  hipEvent_t resultsReady[2] = { nullptr, nullptr };
+  int resultsFrames[2] = { 0, 0 };
+  unsigned long long finalCount = 0;        /* enqueues that produced results */
   ssd_frame_risers *dRisers = nullptr;      /* vertical faces (extension), allocated by ssd_set_risers */
   ssd_frame_risers *hRisers = nullptr;      /* pinned */
   float *dFrames = nullptr;                 /* staging for ssd_process_host */
@@ -406,12 +411,14 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   HIP_TRY_H(hipMalloc(&h->dGroundImg, groundBytes));
   h->tileMaskStride = (static_cast<size_t>(P.nPoints) + kTileHost - 1) / kTileHost * 4;
   HIP_TRY_H(hipMalloc(&h->dTileMasks, h->tileMaskStride * 4 * h->F));
-  HIP_TRY_H(hipMalloc(&h->dResults, sizeof(ssd_frame_result) * h->F));
-  HIP_TRY_H(hipHostMalloc(&h->hResults, sizeof(ssd_frame_result) * h->F, hipHostMallocDefault));
+  HIP_TRY_H(hipMalloc(&h->dResults, sizeof(ssd_frame_result) * h->F * 2));
+  HIP_TRY_H(hipHostMalloc(&h->hResults, sizeof(ssd_frame_result) * h->F * 2, hipHostMallocDefault));
+  HIP_TRY_H(hipEventCreateWithFlags(&h->resultsReady[0], hipEventDisableTiming));
+  HIP_TRY_H(hipEventCreateWithFlags(&h->resultsReady[1], hipEventDisableTiming));
   HIP_TRY_H(hipMemset(h->dState, 0, sizeof(FrameState) * h->F));
   HIP_TRY_H(hipMemset(h->dStepImg, 0, stepBytes));
   HIP_TRY_H(hipMemset(h->dGroundImg, 0, groundBytes));
-  HIP_TRY_H(hipMemset(h->dResults, 0, sizeof(ssd_frame_result) * h->F));
+  HIP_TRY_H(hipMemset(h->dResults, 0, sizeof(ssd_frame_result) * h->F * 2));
   HIP_TRY_H(hipDeviceSynchronize());
 #undef HIP_TRY_H
   h->bytes = sizeof(FrameState) * h->F + stepBytes + groundBytes + h->tileMaskStride * 4 * h->F + sizeof(ssd_frame_result) * h->F;
@@ -431,6 +438,8 @@ int ssd_destroy(ssd_handle *h)
   if(h->dDepthMaps) (void)hipFree(h->dDepthMaps);
   if(h->dResults) (void)hipFree(h->dResults);
   if(h->hResults) (void)hipHostFree(h->hResults);
+  for(hipEvent_t e : h->resultsReady)
+    if(e) (void)hipEventDestroy(e);
   if(h->dFrames) (void)hipFree(h->dFrames);
   if(h->dRisers) (void)hipFree(h->dRisers);
   if(h->hRisers) (void)hipHostFree(h->hRisers);
@@ -628,11 +637,21 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   mark();
   if(stages & SSD_STAGE_FINAL)
   {
-    launch_final(P, h->dState, h->dGroundImg, h->dResults, nframes, dbg, dbgImg, s);
+    launch_final(P, h->dState, h->dGroundImg, h->dResults + static_cast<size_t>(h->finalCount & 1ull) * h->F, nframes, dbg, dbgImg, s);
     if(P.risers)
       launch_risers(xyz, strideFloats, P, h->dState, h->dTileMasks, h->tileMaskStride, h->dRisers, nframes, chunk, depth, s);
   }
   mark();
+  if(stages & SSD_STAGE_FINAL)
+  {
+    /* the results leave with the batch: copy into this enqueue's pinned slot, event for ssd_fetch / ssd_fetch_back */
+    const int slot = static_cast<int>(h->finalCount & 1ull);
+    HIP_TRY(hipMemcpyAsync(h->hResults + static_cast<size_t>(slot) * h->F, h->dResults + static_cast<size_t>(slot) * h->F,
+                           sizeof(ssd_frame_result) * nframes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(h->resultsReady[slot], s));
+    h->resultsFrames[slot] = nframes;
+    h->finalCount++;
+  }
   HIP_TRY(hipGetLastError());
   /* a raster without its consumer leaves bits behind */
   if(((stages & SSD_STAGE_RASTER) && !(stages & SSD_STAGE_OUTLINE)) || ((stages & SSD_STAGE_INQUAD) && !(stages & SSD_STAGE_FINAL)))
@@ -753,18 +772,25 @@ int ssd_get_stage_times(ssd_handle *h, float ms[7])
   return ssd_get_stage_times_back(h, 0, ms);
 }
 
-int ssd_fetch(ssd_handle *h, ssd_frame_result *results, int nframes, void *stream)
+int ssd_fetch_back(ssd_handle *h, ssd_frame_result *results, int nframes, int back)
 {
   if(!h || !results)
     return fail(SSD_E_ARG, "ssd_fetch: null argument");
-  if(nframes < 1 || nframes > h->F)
-    return fail(SSD_E_ARG, "ssd_fetch: nframes out of range");
+  if(back < 0 || back > 1 || h->finalCount < static_cast<unsigned long long>(back) + 1)
+    return fail(SSD_E_ARG, "ssd_fetch: no enqueue at that position (back = 0: the last one, 1: the one before)");
+  const int slot = static_cast<int>((h->finalCount - 1 - back) & 1ull);
+  if(nframes < 1 || nframes > h->resultsFrames[slot])
+    return fail(SSD_E_ARG, "ssd_fetch: nframes exceeds what that enqueue processed");
   HIP_TRY(hipSetDevice(h->device));
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  HIP_TRY(hipMemcpyAsync(h->hResults, h->dResults, sizeof(ssd_frame_result) * nframes, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  std::memcpy(results, h->hResults, sizeof(ssd_frame_result) * nframes);
+  HIP_TRY(hipEventSynchronize(h->resultsReady[slot]));
+  std::memcpy(results, h->hResults + static_cast<size_t>(slot) * h->F, sizeof(ssd_frame_result) * nframes);
   return SSD_OK;
+}
+
+int ssd_fetch(ssd_handle *h, ssd_frame_result *results, int nframes, void *stream)
+{
+  (void)stream;                  /* the copy was enqueued with the batch; its event is what is waited for */
+  return ssd_fetch_back(h, results, nframes, 0);
 }
 
 int ssd_process_host(ssd_handle *h, const float *xyz, int nframes, ssd_frame_result *results)

@@ -312,6 +312,34 @@ def test_risers_in_a_batch_and_with_depth_input(ssd, oracle, gpu_device):
     det.close()
 
 
+def test_results_travel_with_their_enqueue(ssd, oracle, gpu_device):
+    """Two batches in flight: the second is enqueued before the first one's results are read (ssd_fetch_back)."""
+    a = scenes.batch_scenes(ssd, 640, 480, 3, base_seed=31)
+    b = scenes.batch_scenes(ssd, 640, 480, 2, base_seed=77)
+    trans = ssd.transformation_for_scene(a[0])
+    det = ssd.Detector(ssd.default_config(640, 480, max_frames_per_batch=3), trans, gpu_device)
+    want_a = [bytes(r) for r in det.process_host(ssd.synth_host(a))]
+    want_b = [bytes(r) for r in det.process_host(ssd.synth_host(b))]
+    assert want_a[:2] != want_b
+    fb = 640 * 480 * 12
+    buf_a, buf_b = ssd.DeviceBuffer(3 * fb, gpu_device), ssd.DeviceBuffer(2 * fb, gpu_device)
+    ssd.synth_device(a, buf_a.ptr, device=gpu_device)
+    ssd.synth_device(b, buf_b.ptr, device=gpu_device)
+    for _ in range(3):                                     # both slot parities
+        det.enqueue(buf_a.ptr, 3)
+        det.enqueue(buf_b.ptr, 2)
+        assert [bytes(r) for r in det.fetch(3, back=1)] == want_a
+        assert [bytes(r) for r in det.fetch(2, back=0)] == want_b
+        det.enqueue(buf_a.ptr, 3)
+        assert [bytes(r) for r in det.fetch(2, back=1)] == want_b
+        assert [bytes(r) for r in det.fetch(3)] == want_a
+    with pytest.raises(ssd.SsdError):
+        det.fetch(3, back=2)
+    with pytest.raises(ssd.SsdError):
+        det.fetch(3, back=1)                               # that enqueue held 2 frames
+    det.close(); buf_a.free(); buf_b.free()
+
+
 def test_host_batches_larger_than_the_workspace_are_processed_in_chunks(ssd, oracle, gpu_device):
     """ssd_process_host with more frames than max_frames_per_batch loops over chunks (also the 16-bit depth entry)."""
     sc_list = scenes.batch_scenes(ssd, 640, 480, 5, base_seed=909)
