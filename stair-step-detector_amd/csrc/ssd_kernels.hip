@@ -477,30 +477,27 @@ struct WaveWindow
   int slot = -1, row0 = 0, col0 = 0;     /* wave-uniform */
 };
 
-/* bounding box of the bits a lane sent straight to memory (window misses), kept in registers */
-struct MissBox
+/* Bits that miss the window go straight to memory; their bounding box is kept per WAVE in LDS (wm[2..5] = row min /
+ * max, word column min / max; wm[6] = the image slots touched), next to the miss bookkeeping wm[0..1] below: four LDS
+ * min/max per miss, no per-lane state.  One box for all slots of the wave: a wave that misses in several images
+ * (outliers) widens each of them to the union — boxes only bound the region K3 / K5 visit and clear. */
+constexpr int kWaveMissWords = 8;
+__device__ __forceinline__ void wavemiss_init(unsigned int *wm)
 {
-  int slot = -1, y0 = 0, y1 = 0, x0 = 0, x1 = 0;
-};
-__device__ __forceinline__ void missbox_flush(const MissBox &m, ImageBox *boxes)
-{
-  if(m.slot >= 0)
-  {
-    atomicMin(&boxes[m.slot].yMin, m.y0); atomicMax(&boxes[m.slot].yMax, m.y1);
-    atomicMin(&boxes[m.slot].xMin, m.x0); atomicMax(&boxes[m.slot].xMax, m.x1);
-  }
+  wm[0] = 0xffffffffu; wm[1] = 0u;
+  wm[2] = 0x7fffffffu; wm[3] = 0xffffffffu;              /* as int: INT_MAX, -1 */
+  wm[4] = 0x7fffffffu; wm[5] = 0xffffffffu;
+  wm[6] = 0u; wm[7] = 0u;
 }
-__device__ __forceinline__ void missbox_note(MissBox &m, ImageBox *boxes, int slot, int iy, int xw)
+/* end of the kernel, whole wave: the wave's miss box into the block's per-slot boxes */
+__device__ __forceinline__ void wavemiss_flush(unsigned int *wm, ImageBox *boxes, int lane)
 {
-  if(slot != m.slot)
+  const unsigned int slots = wm[6];
+  if(lane < 32 && ((slots >> lane) & 1u))
   {
-    missbox_flush(m, boxes);
-    m.slot = slot; m.y0 = m.y1 = iy; m.x0 = m.x1 = xw;
-  }
-  else
-  {
-    m.y0 = min(m.y0, iy); m.y1 = max(m.y1, iy);
-    m.x0 = min(m.x0, xw); m.x1 = max(m.x1, xw);
+    const int *b = reinterpret_cast<const int *>(wm);
+    atomicMin(&boxes[lane].yMin, b[2]); atomicMax(&boxes[lane].yMax, b[3]);
+    atomicMin(&boxes[lane].xMin, b[4]); atomicMax(&boxes[lane].xMax, b[5]);
   }
 }
 
@@ -560,7 +557,7 @@ constexpr unsigned int kNoMiss = 0xffffffffu;
 
 /* one word's worth of bits of image `slot`: into the window when it is inside, straight to memory otherwise */
 __device__ __forceinline__ void wavewin_or(unsigned long long *ww, unsigned int *wm, const WaveWindow &w, unsigned long long *__restrict__ images,
-                                           unsigned int imgWords, int W64, int winShift, ImageBox *boxes, MissBox &mb,
+                                           unsigned int imgWords, int W64, int winShift,
                                            int slot, int iy, int xw, unsigned long long mask)
 {
   const unsigned int r = static_cast<unsigned int>(iy - w.row0), c = static_cast<unsigned int>(xw - w.col0);
@@ -568,10 +565,13 @@ __device__ __forceinline__ void wavewin_or(unsigned long long *ww, unsigned int 
     atomicOr(&ww[(r << winShift) + c], mask);
   else
   {
-    atomicOr(images + static_cast<size_t>(slot) * imgWords + static_cast<size_t>(iy) * W64 + xw, mask);
-    missbox_note(mb, boxes, slot, iy, xw);
+    atomicOr(images + (static_cast<unsigned int>(slot) * imgWords + static_cast<unsigned int>(iy) * static_cast<unsigned int>(W64) + static_cast<unsigned int>(xw)), mask);
     atomicMin(&wm[0], (((static_cast<unsigned int>(slot) << 16) | static_cast<unsigned int>(iy)) << 6) | static_cast<unsigned int>(xw));
     atomicAdd(&wm[1], 1u);
+    int *b = reinterpret_cast<int *>(wm);
+    atomicMin(&b[2], iy); atomicMax(&b[3], iy);
+    atomicMin(&b[4], xw); atomicMax(&b[5], xw);
+    atomicOr(&wm[6], 1u << slot);
   }
 }
 
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
                                                         const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
   __shared__ unsigned long long wins[kThreads / 64][kWinWords];
-  __shared__ unsigned int wmiss[kThreads / 64][2];
+  __shared__ unsigned int wmiss[kThreads / 64][kWaveMissWords];
   __shared__ ImageBox boxes[kMaxStepImages];
   __shared__ unsigned char lut[kMaxBins];
   __shared__ unsigned int lOob;
@@ -637,10 +637,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
   for(int i = tid; i < (kThreads / 64) * kWinWords; i += kThreads)
     (&wins[0][0])[i] = 0ull;
   if(tid < kThreads / 64)
-  {
-    wmiss[tid][0] = kNoMiss;
-    wmiss[tid][1] = 0u;
-  }
+    wavemiss_init(wmiss[tid]);
   __syncthreads();
 
   /* strideFloats counts floats, or 16-bit depth values for kSrcDepth16 */
@@ -656,7 +653,6 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
   unsigned long long *ww = wins[tid >> 6];
   unsigned int *wm = wmiss[tid >> 6];
   WaveWindow win;
-  MissBox mb;
   unsigned int oob = 0;
 
   for(int i0 = begin; i0 < end; i0 += kTile)
@@ -690,18 +686,18 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
       const int xw = ix >> 6;
       const bool same = slot == pSlot && iy == pY && xw == pXw;
       if(inside && !same && pSlot >= 0)
-        wavewin_or(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, boxes, mb, pSlot, pY, pXw, pMask);
+        wavewin_or(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, pSlot, pY, pXw, pMask);
       pMask = inside ? (same ? (pMask | bit) : bit) : pMask;
       pSlot = inside ? slot : pSlot;
       pY = inside ? iy : pY;
       pXw = inside ? xw : pXw;
     }
     if(pSlot >= 0)
-      wavewin_or(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, boxes, mb, pSlot, pY, pXw, pMask);
+      wavewin_or(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, pSlot, pY, pXw, pMask);
     wavewin_end_of_tile(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, boxes, pSlot >= 0, lane);
   }
   wavewin_flush(ww, win, frameImg, imgWords, X.W64, X.winShift, boxes, lane);
-  missbox_flush(mb, boxes);
+  wavemiss_flush(wm, boxes, lane);
   if(oob)
     atomicAdd(&lOob, oob);
   __syncthreads();
@@ -1832,7 +1828,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
                                                         const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
   __shared__ unsigned long long wins[kThreads / 64][kWinWords];
-  __shared__ unsigned int wmiss[kThreads / 64][2];
+  __shared__ unsigned int wmiss[kThreads / 64][kWaveMissWords];
   __shared__ ImageBox box[1];
   __shared__ QuadTest qts[kMaxPlateaus + 1];
   __shared__ unsigned char lut[kMaxBins];
@@ -1869,10 +1865,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
   for(int i = tid; i < (kThreads / 64) * kWinWords; i += kThreads)
     (&wins[0][0])[i] = 0ull;
   if(tid < kThreads / 64)
-  {
-    wmiss[tid][0] = kNoMiss;
-    wmiss[tid][1] = 0u;
-  }
+    wavemiss_init(wmiss[tid]);
   {
     /* copy the live quadrilateral tests as 32-bit words */
     const unsigned int *src = reinterpret_cast<const unsigned int *>(fs.qt);
@@ -1898,7 +1891,6 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
   unsigned long long *ww = wins[tid >> 6];
   unsigned int *wm = wmiss[tid >> 6];
   WaveWindow win;
-  MissBox mb;
 
   /* calcAverageZ (pointcloud.cpp:574-581) as an order-independent fixed-point sum: a thread walks down a
    * camera column, so consecutive hits nearly always belong to the same quadrilateral — the running sum
@@ -1960,18 +1952,18 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
         const int xw = ix >> 6;
         const bool same = iy == pY && xw == pXw;
         if(inside && !same && pY >= 0)
-          wavewin_or(ww, wm, win, gimg, imgWords, X.W64, X.winShift, box, mb, 0, pY, pXw, pMask);
+          wavewin_or(ww, wm, win, gimg, imgWords, X.W64, X.winShift, 0, pY, pXw, pMask);
         pMask = inside ? (same ? (pMask | bit) : bit) : pMask;
         pY = inside ? iy : pY;
         pXw = inside ? xw : pXw;
       }
     }
     if(pY >= 0)
-      wavewin_or(ww, wm, win, gimg, imgWords, X.W64, X.winShift, box, mb, 0, pY, pXw, pMask);
+      wavewin_or(ww, wm, win, gimg, imgWords, X.W64, X.winShift, 0, pY, pXw, pMask);
     wavewin_end_of_tile(ww, wm, win, gimg, imgWords, X.W64, X.winShift, box, pY >= 0, lane);
   }
   wavewin_flush(ww, win, gimg, imgWords, X.W64, X.winShift, box, lane);
-  missbox_flush(mb, box);
+  wavemiss_flush(wm, box, lane);
   flushAcc();
   if(oob)
     atomicAdd(&lOob, oob);
