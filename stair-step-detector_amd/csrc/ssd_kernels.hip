@@ -655,13 +655,28 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
   WaveWindow win;
   unsigned int oob = 0;
 
-  for(int i0 = begin; i0 < end; i0 += kTile)
+  /* Wave-uniform gate: the tiles none of whose 256 points (of this wave) can belong to a step plateau are never
+   * loaded.  The gate is evaluated for 64 tiles at once (one ballot), and the loop walks the set bits with the loads
+   * of the NEXT wanted tile issued before the current one is processed: a wave that waits for its own loads each
+   * tile leaves the SIMD to seven others, which no longer cover the memory latency once the body is this short. */
+  const int nTiles = (end - begin + kTile - 1) / kTile;
+  const int tile0 = begin / kTile;
+  for(int g = 0; g < nTiles; g += 64)
   {
-    /* wave-uniform gate: nothing of this wave's 256 points can belong to a step plateau */
-    if(!(masks[static_cast<size_t>(i0 / kTile) * kWavesPerBlock] & wanted))
+    const int tl = g + lane;
+    unsigned long long bits = __ballot(tl < nTiles && (masks[static_cast<size_t>(tile0 + tl) * kWavesPerBlock] & wanted) != 0u);
+    if(bits == 0ull)
       continue;
-    F3 v[kPts];
-    load_points<SRC>(base, i0 + kPts * tid, end, v, D);
+    F3 v[kPts], vn[kPts];
+    int cur = __ffsll(static_cast<long long>(bits)) - 1;
+    bits &= bits - 1ull;
+    load_points<SRC>(base, begin + (g + cur) * kTile + kPts * tid, end, v, D);
+   while(true)
+   {
+    const int nxt = bits ? __ffsll(static_cast<long long>(bits)) - 1 : -1;
+    bits &= bits - 1ull;
+    if(nxt >= 0)
+      load_points<SRC>(base, begin + (g + nxt) * kTile + kPts * tid, end, vn, D);
     /* the lane's four neighbouring pixels usually share one 64-bit word: merge them before touching LDS */
     int pSlot = -1;
     int pY = 0;
@@ -695,6 +710,12 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
     if(pSlot >= 0)
       wavewin_or(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, pSlot, pY, pXw, pMask);
     wavewin_end_of_tile(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, boxes, pSlot >= 0, lane);
+    if(nxt < 0)
+      break;
+#pragma unroll
+    for(int j = 0; j < kPts; j++)
+      v[j] = vn[j];
+   }
   }
   wavewin_flush(ww, win, frameImg, imgWords, X.W64, X.winShift, boxes, lane);
   wavemiss_flush(wm, boxes, lane);
