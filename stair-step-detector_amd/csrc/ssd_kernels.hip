@@ -1928,13 +1928,20 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
     }
   };
 
-  for(int i0 = begin; i0 < end; i0 += kTile)
+  /* wave-uniform gate, 64 tiles per ballot, as in k_raster: tiles none of whose points (of this wave) can belong to a
+   * live quadrilateral are never loaded */
+  const int nTiles = (end - begin + kTile - 1) / kTile;
+  const int tile0 = begin / kTile;
+  for(int g = 0; g < nTiles; g += 64)
   {
-    /* wave-uniform gate: nothing of this wave's 256 points can belong to a live quadrilateral */
-    if(!(masks[static_cast<size_t>(i0 / kTile) * kWavesPerBlock] & wanted))
-      continue;
+    const int tl = g + lane;
+    unsigned long long bits = __ballot(tl < nTiles && (masks[static_cast<size_t>(tile0 + tl) * kWavesPerBlock] & wanted) != 0u);
+   while(bits)
+   {
+    const int cur = __ffsll(static_cast<long long>(bits)) - 1;
+    bits &= bits - 1ull;
     F3 v[kPts];
-    load_points<SRC>(base, i0 + kPts * tid, end, v, D);
+    load_points<SRC>(base, begin + (g + cur) * kTile + kPts * tid, end, v, D);
     int pY = -1;
     int pXw = 0;
     unsigned long long pMask = 0;
@@ -1982,6 +1989,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
     if(pY >= 0)
       wavewin_or(ww, wm, win, gimg, imgWords, X.W64, X.winShift, 0, pY, pXw, pMask);
     wavewin_end_of_tile(ww, wm, win, gimg, imgWords, X.W64, X.winShift, box, pY >= 0, lane);
+   }
   }
   wavewin_flush(ww, win, gimg, imgWords, X.W64, X.winShift, box, lane);
   wavemiss_flush(wm, box, lane);
