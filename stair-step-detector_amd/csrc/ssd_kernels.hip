@@ -1892,9 +1892,11 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
     const unsigned int *src = reinterpret_cast<const unsigned int *>(fs.qt);
     unsigned int *dst = reinterpret_cast<unsigned int *>(qts);
     constexpr int wordsPer = sizeof(QuadTest) / 4;
+    /* all of them, unconditionally: independent loads the compiler can issue together — asking "is it live?" first made
+     * every element two dependent round trips, a large part of a block's life */
+#pragma unroll 8
     for(int i = tid; i < (kMaxPlateaus + 1) * wordsPer; i += kThreads)
-      if(fs.accActive[i / wordsPer])
-        dst[i] = src[i];
+      dst[i] = src[i];
   }
   __syncthreads();
 
