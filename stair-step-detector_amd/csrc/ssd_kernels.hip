@@ -2369,12 +2369,19 @@ __global__ __launch_bounds__(kThreads, 8) void k_risers(const float *__restrict_
     }
   };
 
-  for(int i0 = begin; i0 < end; i0 += kTile)
+  /* wave-uniform gate, 64 tiles per ballot (as k_raster / k_inquad) */
+  const int nTiles = (end - begin + kTile - 1) / kTile;
+  const int tile0 = begin / kTile;
+  for(int g = 0; g < nTiles; g += 64)
   {
-    if(!(masks[static_cast<size_t>(i0 / kTile) * kWavesPerBlock] & wanted))
-      continue;
+    const int tl = g + lane;
+    unsigned long long bits = __ballot(tl < nTiles && (masks[static_cast<size_t>(tile0 + tl) * kWavesPerBlock] & wanted) != 0u);
+   while(bits)
+   {
+    const int cur = __ffsll(static_cast<long long>(bits)) - 1;
+    bits &= bits - 1ull;
     F3 v[kPts];
-    load_points<SRC>(base, i0 + kPts * tid, end, v, D);
+    load_points<SRC>(base, begin + (g + cur) * kTile + kPts * tid, end, v, D);
     #pragma unroll
     for(int j = 0; j < kPts; j++)
     {
@@ -2402,6 +2409,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_risers(const float *__restrict_
       accS += z_to_fixed(sd);
       accN++;
     }
+   }
   }
   flushAcc();
   __syncthreads();
