@@ -305,6 +305,10 @@ int ssd_device_sync(int device);
 /* test hooks: std::hypot as the kernels compute it (glibc 2.35 algorithm restated), host and device */
 double ssd_test_hypot_host(double a, double b);
 int ssd_test_hypot_device(int device, const double *a, const double *b, double *out, int n);
+/* test hooks: std::sort as libstdc++ performs it, restated (csrc/ssd_sort.h) for the tie order of segmentation.cpp:724;
+ * perm[k] = original index of the key at sorted position k */
+int ssd_test_sort_host(const double *dist, int n, int32_t *perm);
+int ssd_test_sort_device(int device, const double *dist, int n, int32_t *perm);
 /* test hook: QuadrilateralTest (quadrilateralTest.cpp:275-451) exactly as the kernels build and evaluate it, for one
  * quadrilateral (front-left, front-right, back-left, back-right as x,y) and n points; *err = 0 or the code of the
  * reference's throw (-1..-6), in which case `inside` is left zero */

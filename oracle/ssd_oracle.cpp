@@ -1589,6 +1589,18 @@ double ssdo_hypot(double a, double b)
   return std::hypot(a, b);
 }
 
+void ssdo_sort_perm(const double *dist, int n, int32_t *perm)
+{
+  struct PD { size_t i; double dist; };
+  std::vector<PD> v;
+  v.reserve(size_t(n));
+  for(int i = 0; i < n; i++)
+    v.push_back({ size_t(i), dist[i] });
+  std::sort(v.begin(), v.end(), [](const PD &a, const PD &b) { return a.dist < b.dist; });
+  for(int i = 0; i < n; i++)
+    perm[i] = int32_t(v[size_t(i)].i);
+}
+
 int ssdo_best_line(const int32_t *pts_xy, int n, int32_t line_out[3])
 {
   if(n < 2)

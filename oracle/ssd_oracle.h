@@ -165,6 +165,9 @@ int ssdo_serialize(int n_steps, const double *steps_ext /* n x 9 */, char *buf, 
 int ssdo_quad_test(const double quad[8], const double *pts_xy, int n, uint8_t *inside);
 double ssdo_hypot(double a, double b);
 int ssdo_best_line(const int32_t *pts_xy, int n, int32_t line_out[3]);
+/* the permutation std::sort leaves (keys compared by distance only, as segmentation.cpp:724): perm[k] = original index
+ * of the element at sorted position k */
+void ssdo_sort_perm(const double *dist, int n, int32_t *perm);
 
 #ifdef __cplusplus
 }

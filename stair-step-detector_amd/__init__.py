@@ -130,7 +130,7 @@ EXPORTS = [
     "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
     "ssd_synth_generate_host", "ssd_synth_generate_device", "ssd_synth_scene_to_camera",
     "ssd_device_count", "ssd_device_alloc", "ssd_device_free", "ssd_device_upload", "ssd_device_download",
-    "ssd_device_sync", "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_quad_device",
+    "ssd_device_sync", "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_quad_device", "ssd_test_sort_host", "ssd_test_sort_device",
 ]
 
 _lib = None
@@ -188,6 +188,8 @@ def lib():
     L.ssd_test_hypot_host.argtypes = [C.c_double, C.c_double]
     L.ssd_test_hypot_device.argtypes = [i32, vp, vp, vp, i32]
     L.ssd_test_frame_state.argtypes = [vp, i32, vp, C.c_size_t, vp]
+    L.ssd_test_sort_host.argtypes = [vp, i32, vp]
+    L.ssd_test_sort_device.argtypes = [i32, vp, i32, vp]
     L.ssd_test_quad_device.argtypes = [i32, vp, vp, i32, vp, C.POINTER(C.c_int)]
     L.ssd_test_frame_state.restype = C.c_longlong
     _lib = L
@@ -398,6 +400,17 @@ class Pointcloud:
 
 
 # --------------------------------------------------------------------------- synthetic frame source
+def sort_perm(dist, device=None):
+    """test hook: libstdc++'s std::sort restated (csrc/ssd_sort.h), on the host (device=None) or on a GPU"""
+    d = np.ascontiguousarray(dist, dtype=np.float64)
+    perm = np.zeros(len(d), dtype=np.int32)
+    if device is None:
+        _check(lib().ssd_test_sort_host(d.ctypes.data_as(C.c_void_p), len(d), perm.ctypes.data_as(C.c_void_p)))
+    else:
+        _check(lib().ssd_test_sort_device(device, d.ctypes.data_as(C.c_void_p), len(d), perm.ctypes.data_as(C.c_void_p)))
+    return perm
+
+
 def quad_test_device(quad, pts, device=0):
     """test hook: the kernels' QuadrilateralTest on one quadrilateral -> (err code, uint8 inside[n])"""
     q = np.ascontiguousarray(quad, dtype=np.float64).reshape(8)

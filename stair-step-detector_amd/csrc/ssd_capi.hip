@@ -7,6 +7,7 @@
  */
 #include "ssd_launch.h"
 #include "ssd_synth.h"
+#include "ssd_sort.h"
 
 #include <cmath>
 #include <cstddef>
@@ -1081,6 +1082,39 @@ long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, 
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out, h->dState + frame, n, hipMemcpyDeviceToHost));
   return static_cast<long long>(n);
+}
+
+int ssd_test_sort_host(const double *dist, int n, int32_t *perm)
+{
+  if(!dist || !perm || n < 0 || n > 32768)
+    return fail(SSD_E_ARG, "ssd_test_sort_host: bad argument");
+  std::vector<double> d(dist, dist + n);
+  std::vector<int> idx(static_cast<size_t>(n));
+  for(int i = 0; i < n; i++)
+    idx[static_cast<size_t>(i)] = i;
+  gnu_sort(SortKeys{ d.data(), idx.data() }, n);
+  for(int i = 0; i < n; i++)
+    perm[i] = idx[static_cast<size_t>(i)];
+  return SSD_OK;
+}
+
+int ssd_test_sort_device(int device, const double *dist, int n, int32_t *perm)
+{
+  if(!dist || !perm || n < 1 || n > 32768)
+    return fail(SSD_E_ARG, "ssd_test_sort_device: bad argument");
+  if(ssd_device_count() <= 0)
+    return fail(SSD_E_NODEVICE, "ssd_test_sort_device: no HIP device");
+  HIP_TRY(hipSetDevice(device));
+  double *dd = nullptr;
+  int *di = nullptr;
+  HIP_TRY(hipMalloc(&dd, static_cast<size_t>(n) * sizeof(double)));
+  HIP_TRY(hipMalloc(&di, static_cast<size_t>(n) * sizeof(int)));
+  HIP_TRY(hipMemcpy(dd, dist, static_cast<size_t>(n) * sizeof(double), hipMemcpyHostToDevice));
+  launch_sorttest(dd, di, n, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(perm, di, static_cast<size_t>(n) * sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(dd); (void)hipFree(di);
+  return SSD_OK;
 }
 
 int ssd_test_quad_device(int device, const double quad[8], const double *pts_xy, int n, uint8_t *inside, int *err)

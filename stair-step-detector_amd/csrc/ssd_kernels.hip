@@ -18,6 +18,8 @@
 #include "ssd_device.h"
 #include "ssd_synth.h"
 
+#include "ssd_sort.h"
+
 namespace ssd
 {
 
@@ -1379,7 +1381,7 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
     }
     __syncthreads();
 
-    /* findBestPoint: the element of rank 2n/3 by distance (ties broken by scan order) */
+    /* findBestPoint (segmentation.cpp:708-728): the element of rank 2n/3 by distance, by counting; ties see below */
     for(int t = tid; t < S.vn[0] + S.vn[1]; t += kThreads)
     {
       const int side = t < S.vn[0] ? 0 : 1;
@@ -1394,6 +1396,29 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
       }
       if(rank == 2 * n / 3)
         S.vBest[side] = i;
+    }
+    __syncthreads();
+
+    /* The reference sorts with std::ranges::sort (segmentation.cpp:724), which is not stable: among points at exactly
+     * the same distance, the one on rank 2n/3 is whatever libstdc++'s introsort leaves there.  Only when that can
+     * matter — the selected distance is duplicated AND a duplicate would give another line — the keys are sorted the
+     * way the library does it (ssd_sort.h; vdist in place, vx as the payload: neither is needed afterwards). */
+    if(tid < 2 && S.vn[tid] > 0 && S.vBest[tid] >= 0)
+    {
+      const int side = tid, n = S.vn[side], best = S.vBest[side];
+      const double D = S.vdist[side][best];
+      const double cBest = -S.baseLine.a * S.vpx[side][best] - S.baseLine.b * S.vpy[side][best];
+      bool ambiguous = false;
+      for(int k = 0; k < n; k++)
+        if(k != best && S.vdist[side][k] == D && (-S.baseLine.a * S.vpx[side][k] - S.baseLine.b * S.vpy[side][k]) != cBest)
+          ambiguous = true;
+      if(ambiguous)
+      {
+        for(int k = 0; k < n; k++)
+          S.vx[side][k] = k;
+        gnu_sort(SortKeys{ S.vdist[side], S.vx[side] }, n);
+        S.vBest[side] = S.vx[side][2 * n / 3];
+      }
     }
     __syncthreads();
   }
@@ -2464,6 +2489,17 @@ __global__ void k_riser_results(Params P, const FrameState *__restrict__ st, ssd
   }
 }
 
+/* test hook: gnu_sort on the device */
+__global__ void k_sorttest(double *dist, int *idx, int n)
+{
+  if(blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    for(int i = 0; i < n; i++)
+      idx[i] = i;
+    gnu_sort(SortKeys{ dist, idx }, n);
+  }
+}
+
 /* test hook: QuadrilateralTest as the kernels build and evaluate it (build_quad_test + the constant cell + quad_test),
  * one quadrilateral, n points; err = the negative code of the reference's throw or 0 */
 __global__ void k_quadtest(const double *__restrict__ quad, const double *__restrict__ pts, int n, unsigned char *__restrict__ inside,
@@ -2635,6 +2671,10 @@ void launch_synth_depth(const ssd_scene *dScenes, unsigned short *depth, size_t 
   if(bx > 2048) bx = 2048;
   if(bx < 1) bx = 1;
   hipLaunchKernelGGL(k_synth_depth, dim3(bx, nframes), dim3(kThreads), 0, s, dScenes, depth, strideElems, depthUnits);
+}
+void launch_sorttest(double *dist, int *idx, int n, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_sorttest, dim3(1), dim3(64), 0, s, dist, idx, n);
 }
 void launch_quadtest(const double *quad, const double *pts, int n, unsigned char *inside, int *err, hipStream_t s)
 {

@@ -87,6 +87,7 @@ class Oracle:
         lib.ssdo_best_line.argtypes = [vp, i32, vp]
         lib.ssdo_calibration_load.argtypes = [C.c_char_p, C.c_char_p, vp, vp]
         lib.ssdo_deproject.argtypes = [C.c_float] * 5 + [i32, i32, vp, vp]
+        lib.ssdo_sort_perm.argtypes = [vp, i32, vp]
         lib.ssdo_risers.argtypes = [C.POINTER(Config), C.POINTER(Calibration), vp, C.c_double, i32, C.POINTER(Riser)]
 
     def config(self, width, height):
@@ -109,6 +110,12 @@ class Oracle:
         if n < 0:
             raise RuntimeError("ssdo_risers failed: %d" % n)
         return [out[i] for i in range(n)]
+
+    def sort_perm(self, dist):
+        d = np.ascontiguousarray(dist, dtype=np.float64)
+        perm = np.zeros(len(d), dtype=np.int32)
+        self.lib.ssdo_sort_perm(d.ctypes.data_as(C.c_void_p), len(d), perm.ctypes.data_as(C.c_void_p))
+        return perm
 
     def deproject(self, intr, depth):
         a = np.ascontiguousarray(depth, dtype=np.uint16)

@@ -205,6 +205,37 @@ def test_best_line_against_bruteforce(oracle):
 
 
 # ------------------------------------------------------------------ hypot: oracle = libm, product = restated glibc algorithm
+def test_sort_restatement_leaves_the_permutation_std_sort_leaves(ssd, oracle, tmp_path):
+    """csrc/ssd_sort.h (libstdc++'s introsort restated, for the tie order of segmentation.cpp:724) against std::sort
+    itself: random, tie-heavy, sorted, reversed and organ-pipe keys, and McIlroy's adversary (tests/golden/antiqsort.cpp)
+    that drives std::sort into its heapsort fallback."""
+    import subprocess
+    rng = np.random.default_rng(0)
+    for trial in range(1200):
+        n = int(rng.integers(1, 400))
+        kind = trial % 6
+        if kind == 0:
+            d = rng.uniform(0, 10, n)
+        elif kind == 1:
+            d = rng.integers(0, 4, n).astype(float)
+        elif kind == 2:
+            d = np.sort(rng.integers(0, 30, n)).astype(float)
+        elif kind == 3:
+            d = np.sort(rng.uniform(0, 1, n))[::-1].copy()
+        elif kind == 4:
+            d = np.round(rng.normal(5, 2, n), 1)
+        else:
+            d = np.abs(np.arange(n) - n // 2).astype(float)
+        assert np.array_equal(oracle.sort_perm(d), ssd.sort_perm(d)), (trial, n)
+    exe = str(tmp_path / "antiqsort")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(HERE, "golden", "antiqsort.cpp"), "-o", exe], check=True)
+    for n in (40, 120, 300, 1000):
+        killer = np.array(subprocess.run([exe, str(n)], check=True, capture_output=True, text=True).stdout.split(), dtype=np.float64)
+        for q in (1, 2, 7, 50):
+            d = np.floor(killer / q)
+            assert np.array_equal(oracle.sort_perm(d), ssd.sort_perm(d)), (n, q)
+
+
 def test_product_hypot_equals_libm_on_this_image(ssd, oracle):
     """The oracle calls the host's std::hypot as the reference does; the kernels restate the glibc 2.35
     algorithm (the same function, ssd_test_hypot_host, compiled for the host).  They must agree here."""
