@@ -11,9 +11,16 @@ pass of the whole path (K1 hist .. K5 final + results to the host) over the batc
 its own F frames on its own GPU (frames are independent: no collective on the data path; weak scaling) and
 value = N * F * K / max-over-ranks time.
 
-PyTorch is plumbing here: device memory, the stream, the barrier and the max-reduce.  The hot path is
+PyTorch is plumbing here: device memory, the stream, the barrier and the max-reduce (torch.distributed over
+`gloo` on CPU tensors: the data path has no exchange step, so RCCL is never loaded).  The hot path is
 libssd_hip.so through its C ABI.  The CPU oracle is used only for the cpu_baseline leg and the parity
 spot check, both outside the timed region.
+
+`python bench.py --gpus N` with N > 1 and no RANK in the environment launches the N ranks itself (a child
+`python -m torch.distributed.run ... bench.py --gpus N ...`, started before this process touches the GPU) and
+exits with the child's code.  A world size that differs from --gpus, or fewer visible GPUs than ranks, is an
+error, never a silent 1-GPU run.  BASELINE configs[3] (16384 frames over 8 GPUs): `--gpus 8 --frames 2048`.
+SSD_BENCH_DEVICE=<index> puts every rank on that one device (tests: 2 ranks on a 1-GPU box).
 """
 import argparse
 import importlib
@@ -38,6 +45,79 @@ def shard(total, world, rank):
     return lo, hi
 
 
+def launch_command(n_gpus, argv, port=None):
+    """The command that runs this script as n_gpus ranks on this node (what the driver uses for N > 1)."""
+    if port is None:
+        port = 29500 + os.getpid() % 2000
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def world_from_env(n_gpus, environ=None):
+    """(world, rank, local_rank) from the launcher's environment; --gpus must agree with it."""
+    env = os.environ if environ is None else environ
+    world = int(env.get("WORLD_SIZE", "1"))
+    rank = int(env.get("RANK", "0"))
+    local_rank = int(env.get("LOCAL_RANK", str(rank)))
+    if world != max(n_gpus, 1):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a line for another configuration" % (n_gpus, world))
+    if not 0 <= rank < world:
+        raise SystemExit("bench.py: RANK=%d outside WORLD_SIZE=%d" % (rank, world))
+    return world, rank, local_rank
+
+
+def device_for_rank(local_rank, n_devices, environ=None):
+    """One GPU per rank; SSD_BENCH_DEVICE forces all ranks onto one device (2-rank test on a 1-GPU box)."""
+    env = os.environ if environ is None else environ
+    forced = env.get("SSD_BENCH_DEVICE")
+    dev = int(forced) if forced not in (None, "") else local_rank
+    if not 0 <= dev < n_devices:
+        raise SystemExit("bench.py: rank needs device %d but %d GPU(s) are visible (one GPU per rank; no oversubscription "
+                         "unless SSD_BENCH_DEVICE is set)" % (dev, n_devices))
+    return dev
+
+
+class Ranks:
+    """The only communication of the bench: a barrier and a max over ranks, on CPU tensors over gloo."""
+
+    def __init__(self, world, rank):
+        self.world, self.rank = world, rank
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def max(self, value):
+        if self.world == 1:
+            return float(value)
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, obj):
+        """-> list of every rank's obj on rank 0 (small, outside the timed region), None elsewhere"""
+        if self.world == 1:
+            return [obj]
+        import torch.distributed as dist
+        out = [None] * self.world if self.rank == 0 else None
+        dist.gather_object(obj, out, dst=0)
+        return out
+
+    def close(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,22 +133,23 @@ def main():
     ap.add_argument("--risers", action="store_true",
                     help="also gather the evidence of the vertical faces (extension beyond the reference, SURVEY 8f rank 4); off for the metric")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # not under a launcher: start the ranks as a child BEFORE anything here touches the GPU, exit with its code
+        import subprocess
+        raise SystemExit(subprocess.call(launch_command(args.gpus, sys.argv[1:])))
 
     import numpy as np
     import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(args.gpus, 1) and world > 1:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    world, rank, local_rank = world_from_env(args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the HIP path is mandatory (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    device = device_for_rank(local_rank, torch.cuda.device_count())
+    torch.cuda.set_device(device)
+    ranks = Ranks(world, rank)
 
     ssd = importlib.import_module("stair-step-detector_amd")
     import scenes
@@ -91,16 +172,16 @@ def main():
         frame_bytes = W * H * 2
     frames = torch.empty(F * frame_bytes, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    det = ssd.Detector(cfg, trans, local_rank)
+    det = ssd.Detector(cfg, trans, device)
     det.set_timing(True)
     if args.risers:
         det.set_risers(True, tolerance=0.03, min_support=200)
     intr = ssd.intrinsics_for_scene(sc_list[0])
     if depth_in:
-        ssd.synth_depth_device(sc_list, frames.data_ptr(), device=local_rank, stream=stream)
+        ssd.synth_depth_device(sc_list, frames.data_ptr(), device=device, stream=stream)
         det.set_intrinsics(intr)
     else:
-        ssd.synth_device(sc_list, frames.data_ptr(), device=local_rank, stream=stream)
+        ssd.synth_device(sc_list, frames.data_ptr(), device=device, stream=stream)
 
     def enqueue():
         if depth_in:
@@ -122,8 +203,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        ranks.barrier()
         torch.cuda.synchronize()
 
     fence()
@@ -139,10 +219,22 @@ def main():
         for k, v in det.stage_times_ms(b).items():
             stage[k] += v / n_timed
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max = float(t.item())
+    dt_max = ranks.max(dt)
+    # which frames of the global index space each rank processed, and on which device (rank 0 reports it); with more
+    # than one rank every rank also checks a few frames of ITS shard against the CPU oracle (outside the timed region)
+    mine = {"rank": rank, "device": device, "frames": [lo, hi], "seconds": dt, "steps_found": int(sum(r.n_steps for r in res))}
+    if world > 1 and not args.no_cpu:
+        import oracle_binding as ob
+        import parity
+        oracle = ob.load_oracle()
+        rep = {}
+        for i in sorted(set(int(i) for i in np.linspace(0, F - 1, min(5, F)))):
+            x = frames[i * frame_bytes:(i + 1) * frame_bytes].cpu().numpy()
+            x = oracle.deproject(intr, x.view(np.uint16).reshape(H, W)) if depth_in else x.view(np.float32)
+            parity.check_results_only(ssd, oracle, cfg, trans.constants, x, res[i], rep)
+        mine["parity"] = {"frames_checked_against_oracle": min(5, F), "max_abs_height_err_m": rep.get("max_height_err", 0.0),
+                          "max_abs_corner_err_m": rep.get("max_corner_err", 0.0)}
+    shards = ranks.gather(mine)
 
     if rank == 0:
         value = world * F * args.steps / dt_max
@@ -167,15 +259,21 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[4]: %d synthetic %dx%d frames (8 noisy steps, 5 %% outliers) resident in HBM; per GPU"
                                     if fhd else
-                                    "BASELINE configs[2]: batch of %d synthetic %dx%d frames (3-step staircases, randomised rise/"
+                                    ("BASELINE configs[3]: %d-frame batch frame-sharded over %d GPUs; " % (F * world, world) if world > 1 else
+                                     "BASELINE configs[2]: ") +
+                                    "batch of %d synthetic %dx%d frames (3-step staircases, randomised rise/"
                                     "tread/yaw/noise) resident in HBM, streamed through the whole per-frame path; per GPU") % (F, W, H),
                        "frames_per_gpu_per_step": F, "width": W, "height": H, "input": args.input, "risers": bool(args.risers), "parallelism": "frame-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "kernel": "k_hist (K1: transform+crop+bin+histogram)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": None if traffic is None else "profiles/pmc_k_hist.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                           "of this command, committed; not re-measured in this run)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms},
             "stage_ms": stage,
             "pipeline_bytes_algorithmic_frac_of_peak": (alg_bytes * args.steps / dt_max / 1e9) / HBM_PEAK_GBS,
         }
+        if world > 1:
+            out["ranks"] = shards
         steps_hist = [r.n_steps for r in res]
         out["steps_histogram"] = {str(k): int(sum(1 for n in steps_hist if n == k)) for k in sorted(set(steps_hist))}
 
@@ -184,7 +282,8 @@ def main():
             import parity
             oracle = ob.load_oracle()
             ocfg, ocal = ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants)
-            n_cpu = max(1, min(args.cpu_frames or (256 if fhd else 1280), F))
+            # cpu_baseline is reported at N = 1 only; with more ranks rank 0 still spot-checks its shard against the oracle
+            n_cpu = max(1, min(args.cpu_frames or (17 if world > 1 else 256 if fhd else 1280), F))
             idx = [int(i) for i in np.linspace(0, F - 1, n_cpu)]
             rep = {}
             cdt = 0.0
@@ -201,13 +300,14 @@ def main():
                 if i % 64 == 0 or i == idx[-1]:
                     parity.check_results_only(ssd, oracle, cfg, trans.constants, x, res[i], rep)
                     checked += 1
-            out["cpu_baseline"] = {"value": n_cpu / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
-                                   "sample": "%d of the %d frames of rank 0's batch (evenly spaced), the whole per-frame path in "
-                                             "oracle/ssd_oracle.cpp (CPU restatement of the reference, one thread as the reference runs), "
-                                             "%.1f s of CPU time" % (n_cpu, F, cdt)}
+            if world == 1:
+                out["cpu_baseline"] = {"value": n_cpu / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
+                                       "sample": "%d of the %d frames of rank 0's batch (evenly spaced), the whole per-frame path in "
+                                                 "oracle/ssd_oracle.cpp (CPU restatement of the reference, one thread as the reference runs), "
+                                                 "%.1f s of CPU time" % (n_cpu, F, cdt)}
             # the same port on all host cores, one frame per thread (ctypes drops the GIL)
             cores = len(os.sched_getaffinity(0))
-            if cores > 1 and len(keep) > 1:
+            if world == 1 and cores > 1 and len(keep) > 1:
                 from concurrent.futures import ThreadPoolExecutor
                 reps = max(1, (4 * cores + len(keep) - 1) // len(keep))
                 work = keep * reps
@@ -222,9 +322,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     det.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

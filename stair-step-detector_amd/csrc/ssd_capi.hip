@@ -57,7 +57,7 @@ struct ssd_handle
   FrameState *dState = nullptr;
   unsigned long long *dStepImg = nullptr;
   unsigned long long *dGroundImg = nullptr;
-  unsigned int *dTileMasks = nullptr;       /* per wave tile (256 points): which groups of 4 height bins occur; K1 -> K2, K4 */
+  unsigned int *dTileMasks = nullptr;       /* per cell (64 points): which groups of 4 height bins occur; K1 -> K2, K4, K6 */
   size_t tileMaskStride = 0;
   float *dDepthMaps = nullptr;              /* xmap[W] then ymap[H] (ssd_set_intrinsics) */
   ssd_intrinsics intr{};
@@ -349,21 +349,34 @@ static int make_params(const ssd_config &c, const ssd_calibration &k, Params &P)
   P.px.xToImage = P.xToImage; P.px.yToImage = P.yToImage;
   P.px.W = P.W; P.px.H = P.H; P.px.W64 = P.W64;
   P.px.maxStepImages = P.maxStepImages;
+  P.px.cellCols = (c.width + kCellHost / 2) / kCellHost > 0 ? (c.width + kCellHost / 2) / kCellHost : 1;
   P.risers = 0; P.riserMinSupport = 1; P.riserTol = 0.0;
   P.heightInterval = c.height_interval;
-  /* Shape of the waves' write-combining windows (ssd_kernels.hip, WaveWindow).  A wave takes the same 256 pixels of
-   * every block tile of 1024: when a camera row is a whole number of block tiles (XGA) it walks down one 256-pixel
-   * column strip and a tall narrow window (32 rows x 8 words) follows it; otherwise (VGA, FHD) its strip jumps along
-   * the row from tile to tile and only a window as wide as the image row keeps the hits in LDS. */
-  P.px.winShift = 3;
-  if(c.width % 1024 != 0 && P.W64 <= 32)
+  /* Shape of the waves' write-combining windows (ssd_kernels.hip, WaveWindow).  A wave walks down one cell column —
+   * 64 camera pixels wide, which is 60 .. 110 pixels of the top-down image depending on the range — so the window is
+   * tall and narrow: 64 rows x 4 words up to XGA, 32 rows x 8 words above (measured, tools/exp.sh: XGA raster 1.52 ms
+   * with 32 x 8, 1.00 ms with 64 x 4, 2.23 ms with 16 x 16; FHD stress 1.04 ms with 32 x 8, 1.24 ms with 64 x 4).  The
+   * ground image of k_inquad is denser (the camera looks steeply down on it): 32 x 8.  When a camera row is not a
+   * whole number of cells the columns drift sideways from row to row: a window as wide as the image row then. */
+  P.px.winShift = P.W64 <= 16 ? 2 : 3;
+  P.px.winShiftGround = 3;
+  if(c.width % kCellHost != 0 && P.W64 <= 32)
+  {
     while((1 << P.px.winShift) < P.W64)
       P.px.winShift++;
+    P.px.winShiftGround = P.px.winShift;
+  }
   if(const char *e = getenv("SSD_WIN_SHIFT"))
   {
     const int v = atoi(e);
-    if(v >= 2 && v <= 6)
+    if(v >= 1 && v <= 6)
       P.px.winShift = v;
+  }
+  if(const char *e = getenv("SSD_WIN_SHIFT_G"))
+  {
+    const int v = atoi(e);
+    if(v >= 1 && v <= 6)
+      P.px.winShiftGround = v;
   }
   if((c.width - 1) / 25 + 2 > SSD_MAX_SCANS)
     return fail(SSD_E_ARG, "config: width needs more scan columns than SSD_MAX_SCANS");
@@ -410,7 +423,7 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   HIP_TRY_H(hipMalloc(&h->dState, sizeof(FrameState) * h->F));
   HIP_TRY_H(hipMalloc(&h->dStepImg, stepBytes));
   HIP_TRY_H(hipMalloc(&h->dGroundImg, groundBytes));
-  h->tileMaskStride = (static_cast<size_t>(P.nPoints) + kTileHost - 1) / kTileHost * 4;
+  h->tileMaskStride = (static_cast<size_t>(P.nPoints) + kTileHost - 1) / kTileHost * (kTileHost / kCellHost);   /* masks (u32) per frame */
   HIP_TRY_H(hipMalloc(&h->dTileMasks, h->tileMaskStride * 4 * h->F));
   HIP_TRY_H(hipMalloc(&h->dResults, sizeof(ssd_frame_result) * h->F * 2));
   HIP_TRY_H(hipHostMalloc(&h->hResults, sizeof(ssd_frame_result) * h->F * 2, hipHostMallocDefault));
@@ -596,7 +609,7 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   const Params &P = h->P;
   const float *xyz = static_cast<const float *>(d_xyz);
   const size_t strideFloats = depthInput ? frame_stride_bytes / 2 : frame_stride_bytes / 4;    /* elements of the source type */
-  const DepthSrc depthSrc{ h->dDepthMaps, h->dDepthMaps ? h->dDepthMaps + P.W : nullptr, h->intr.depth_units, P.W };
+  const DepthSrc depthSrc{ h->dDepthMaps, h->dDepthMaps ? h->dDepthMaps + P.W : nullptr, h->intr.depth_units, P.W, P.H };
   const DepthSrc *depth = depthInput ? &depthSrc : nullptr;
   const int chunk = choose_chunk(P.nPoints, nframes);
   DebugFrame *dbg = h->debug ? h->dDebug : nullptr;

@@ -45,6 +45,9 @@ struct PixelParams
   int W, H, W64;                              /* W64 = 64-bit words per image row */
   int maxStepImages;
   int winShift;                               /* the waves' LDS image windows are (256 >> winShift) rows x (1 << winShift) words */
+  int winShiftGround;                         /* the same for the ground image of k_inquad */
+  int cellCols;                               /* cells (64 consecutive points) per camera row, rounded: cells this far apart are
+                                                 vertical neighbours in the camera image (order of the kernels' cell lists) */
 };
 
 /* what the 16-bit depth source needs beside the depth image: rs2::pointcloud's pre-computed maps
@@ -53,7 +56,7 @@ struct DepthSrc
 {
   const float *xmap, *ymap;
   float depthUnits;
-  int W;
+  int W, H;
 };
 
 /* all constants of one handle */

@@ -118,7 +118,7 @@ __device__ __forceinline__ void load_points(const float *__restrict__ base, int 
           raw[j] = depth[idx0 + j];
     }
     const int row = idx0 / D.W, col = idx0 - row * D.W;      /* W % 4 == 0: the four points share the row */
-    const float ym = D.ymap[min(row, 0x7fffffff)];
+    const float ym = D.ymap[min(row, D.H - 1)];               /* lanes past the end of the frame (raw = 0) stay inside the map */
 #pragma unroll
     for(int j = 0; j < kPts; j++)
     {
@@ -165,20 +165,82 @@ __device__ __forceinline__ void load_points(const float *__restrict__ base, int 
   }
 
 /* K2 and K4 run after frame-wide decisions (plateau table, outlines) and need only the points of a few
- * height bins.  Camera rows sweep one plateau at a time, so whole wave tiles (256 consecutive points) are
- * irrelevant to them.  K1 therefore leaves one 32-bit mask per wave tile — which groups of 4 height bins
- * occur in it (4 B per 256 points: no measurable traffic, unlike a byte per point which costs K1 a third of
- * its bandwidth, tools/storebench.hip) — and the later passes skip, without loading anything, every tile
- * whose mask has no group in common with the bins they care about. */
-constexpr int kBinsPerGroup = 4;      /* 128 bins -> 32 groups: one 32-bit mask per wave tile */
+ * height bins.  Camera rows sweep one plateau at a time, so whole runs of consecutive points are irrelevant
+ * to them.  K1 therefore leaves one 32-bit mask per CELL — 64 consecutive points = the 4 points of each of
+ * the 16 lanes of one DPP row — saying which groups of 4 height bins occur in it (4 B per 768 B of input:
+ * no measurable traffic, unlike a byte per point which costs K1 a third of its bandwidth,
+ * tools/storebench.hip).  The later passes gather the cells that hold a bin they care about into a compact
+ * list per block and walk only those (cell_list_build / SSD_CELL_LOOP below): nothing else is loaded, and
+ * every wave iteration works on four wanted cells instead of on 256 consecutive points of which half are
+ * somebody else's (wave-tile gating: 52 % of the tiles at 57 % lane use in K2; cells: 34 % at 88 %). */
+constexpr int kBinsPerGroup = 4;      /* 128 bins -> 32 groups: one 32-bit mask per cell */
 constexpr int kWavesPerBlock = kThreads / 64;
+constexpr int kCell = 64;                         /* points per cell */
+constexpr int kCellsPerTile = kTile / kCell;      /* 16 */
+constexpr int kMaxTilesPerBlock = 32;             /* chunkPoints <= 32 * 1024 (choose_chunk, kMaxTilesPerBlockHost) */
+constexpr int kMaxCellsPerBlock = kMaxTilesPerBlock * kCellsPerTile;
 
-__device__ __forceinline__ unsigned int wave_or_u32(unsigned int v)
+/* OR over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1): every lane of the row gets the row's result */
+__device__ __forceinline__ unsigned int row_or_u32(unsigned int v)
 {
-#pragma unroll
-  for(int o = 32; o > 0; o >>= 1)
-    v |= static_cast<unsigned int>(__shfl_xor(static_cast<int>(v), o));
+  v |= static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x128, 0xf, 0xf, false));
+  v |= static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x124, 0xf, 0xf, false));
+  v |= static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x122, 0xf, 0xf, false));
+  v |= static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x121, 0xf, 0xf, false));
   return v;
+}
+
+/* The list of the cells of a block's chunk whose mask meets `wanted`, in LDS, COLUMN-major: the cells of one
+ * cell column (`cols` cells apart: vertically adjacent in the camera image) follow each other, so a wave that walks
+ * the list stays on one patch of the top-down image that creeps down row by row — what its LDS write-combining
+ * window needs — and jumps only at a column change.  Entries are cell indices relative to the chunk's first cell.
+ * All threads of the block call it; returns the number of entries (block-uniform).  scratch: kWavesPerBlock words. */
+__device__ __forceinline__ int cell_list_build(const unsigned int *__restrict__ cellMasks, int nCells, int cols, unsigned int wanted,
+                                               unsigned short *list, unsigned int *scratch)
+{
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rows = (nCells + cols - 1) / cols;
+  int total = 0;
+  for(int i0 = 0; i0 < rows * cols; i0 += kThreads)
+  {
+    const int i = i0 + tid;
+    const int cx = i / rows, r = i - cx * rows;
+    const int c = r * cols + cx;
+    const bool want = cx < cols && c < nCells && (cellMasks[c] & wanted) != 0u;
+    const unsigned long long b = __ballot(want);
+    if(lane == 0)
+      scratch[wave] = static_cast<unsigned int>(__popcll(b));
+    __syncthreads();
+    int before = total;
+#pragma unroll
+    for(int w = 0; w < kWavesPerBlock; w++)
+    {
+      const int n = static_cast<int>(scratch[w]);
+      before += w < wave ? n : 0;
+      total += n;
+    }
+    if(want)
+      list[before + __popcll(b & ((1ull << lane) - 1ull))] = static_cast<unsigned short>(c);
+    __syncthreads();
+  }
+  return total;
+}
+
+/* A wave takes a contiguous run of GROUPS of four list entries; DPP row q (lanes 16q .. 16q+15) takes entry 4g + q:
+ * its 16 lanes read the cell's 768 bytes contiguously, four consecutive points per lane.  Rows beyond the end of the
+ * list get invalid points (z = 0), which every consumer drops first. */
+template<int SRC>
+__device__ __forceinline__ void load_cell(const float *__restrict__ base, int cell0, const unsigned short *list, int entry, int count,
+                                          int lane, int nPoints, F3 (&v)[kPts], const DepthSrc &D)
+{
+  if(entry < count)
+    load_points<SRC>(base, (cell0 + static_cast<int>(list[entry])) * kCell + kPts * (lane & 15), nPoints, v, D);
+  else
+  {
+#pragma unroll
+    for(int j = 0; j < kPts; j++)
+      v[j] = F3{ 0.0f, 0.0f, 0.0f };
+  }
 }
 
 template<int SRC>
@@ -186,8 +248,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ 
                                                    FrameState *__restrict__ st, unsigned int *__restrict__ tileMasks,
                                                    size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
-  constexpr int kMaxTilesPerBlock = 256;            /* chunkPoints <= 256 * 1024 (choose_chunk) */
-  __shared__ unsigned int lMasks[kMaxTilesPerBlock * kWavesPerBlock];
+  __shared__ unsigned int lMasks[kMaxCellsPerBlock];
   /* [bin][copy]: a vote goes to copy = lane & 31, i.e. LDS bank = copy: the 32 lanes the LDS serves per
    * cycle never collide, whatever their bins (a camera row sweeping one plateau puts all 64 lanes in one bin) */
   __shared__ unsigned int lh[kMaxBins * kHistCopies];
@@ -224,9 +285,9 @@ __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ 
         groups |= 1u << (b / kBinsPerGroup);
       }
     }
-    groups = wave_or_u32(groups);
-    if(lane == 0)
-      lMasks[it * kWavesPerBlock + (tid >> 6)] = groups;
+    groups = row_or_u32(groups);
+    if((lane & 15) == 0)
+      lMasks[it * kCellsPerTile + (tid >> 4)] = groups;          /* cell = 64 consecutive points = lanes 16q .. 16q+15 */
     it++;
   )
 
@@ -250,10 +311,10 @@ __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ 
   }
   if(tid == 0 && lNonZero)
     atomicAdd(&fs.nNonZero, lNonZero);
-  /* the block's tile masks, in one burst */
+  /* the block's cell masks, in one burst */
   {
-    unsigned int *dst = tileMasks + static_cast<size_t>(frame) * tileMaskStride + static_cast<size_t>(begin / kTile) * kWavesPerBlock;
-    for(int i = tid; i < it * kWavesPerBlock; i += kThreads)
+    unsigned int *dst = tileMasks + static_cast<size_t>(frame) * tileMaskStride + static_cast<size_t>(begin / kCell);
+    for(int i = tid; i < it * kCellsPerTile; i += kThreads)
       dst[i] = lMasks[i];
   }
 }
@@ -618,6 +679,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
   __shared__ ImageBox boxes[kMaxStepImages];
   __shared__ unsigned char lut[kMaxBins];
   __shared__ unsigned int lOob;
+  __shared__ unsigned short cellList[kMaxCellsPerBlock];
+  __shared__ unsigned int listScratch[kWavesPerBlock];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int frame = blockIdx.x;                /* frame on the fast grid axis: see launch note on XCD balance */
@@ -648,8 +711,6 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
     : xyz + static_cast<size_t>(frame) * strideFloats;
   const int begin = blockIdx.y * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
-  const unsigned int *masks = tileMasks + static_cast<size_t>(frame) * tileMaskStride + (tid >> 6);
-  const unsigned int wanted = fs.wantedSteps;
   const unsigned int imgWords = static_cast<unsigned int>(X.H) * X.W64;
   unsigned long long *frameImg = stepImg + static_cast<size_t>(frame) * X.maxStepImages * imgWords;
   unsigned long long *ww = wins[tid >> 6];
@@ -657,28 +718,25 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
   WaveWindow win;
   unsigned int oob = 0;
 
-  /* Wave-uniform gate: the tiles none of whose 256 points (of this wave) can belong to a step plateau are never
-   * loaded.  The gate is evaluated for 64 tiles at once (one ballot), and the loop walks the set bits with the loads
-   * of the NEXT wanted tile issued before the current one is processed: a wave that waits for its own loads each
-   * tile leaves the SIMD to seven others, which no longer cover the memory latency once the body is this short. */
-  const int nTiles = (end - begin + kTile - 1) / kTile;
-  const int tile0 = begin / kTile;
-  for(int g = 0; g < nTiles; g += 64)
+  /* Only the cells that hold a bin of a step plateau are walked (cell_list_build), four per wave iteration, with the
+   * loads of the NEXT group issued before the current one is processed: a wave that waits for its own loads each
+   * iteration leaves the SIMD to seven others, which no longer cover the memory latency once the body is this short. */
+  const int cell0 = begin / kCell;
+  const int nCells = (end - begin + kCell - 1) / kCell;
+  const int count = cell_list_build(tileMasks + static_cast<size_t>(frame) * tileMaskStride + cell0, nCells, X.cellCols, fs.wantedSteps,
+                                    cellList, listScratch);
+  const int nGroups = (count + 3) >> 2;
+  int g = (tid >> 6) * nGroups / kWavesPerBlock;
+  const int gEnd = ((tid >> 6) + 1) * nGroups / kWavesPerBlock;
+  if(g < gEnd)
   {
-    const int tl = g + lane;
-    unsigned long long bits = __ballot(tl < nTiles && (masks[static_cast<size_t>(tile0 + tl) * kWavesPerBlock] & wanted) != 0u);
-    if(bits == 0ull)
-      continue;
     F3 v[kPts], vn[kPts];
-    int cur = __ffsll(static_cast<long long>(bits)) - 1;
-    bits &= bits - 1ull;
-    load_points<SRC>(base, begin + (g + cur) * kTile + kPts * tid, end, v, D);
-   while(true)
-   {
-    const int nxt = bits ? __ffsll(static_cast<long long>(bits)) - 1 : -1;
-    bits &= bits - 1ull;
-    if(nxt >= 0)
-      load_points<SRC>(base, begin + (g + nxt) * kTile + kPts * tid, end, vn, D);
+    load_cell<SRC>(base, cell0, cellList, 4 * g + (lane >> 4), count, lane, P.nPoints, v, D);
+    while(true)
+    {
+    const bool more = g + 1 < gEnd;
+    if(more)
+      load_cell<SRC>(base, cell0, cellList, 4 * (g + 1) + (lane >> 4), count, lane, P.nPoints, vn, D);
     /* the lane's four neighbouring pixels usually share one 64-bit word: merge them before touching LDS */
     int pSlot = -1;
     int pY = 0;
@@ -712,12 +770,13 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
     if(pSlot >= 0)
       wavewin_or(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, pSlot, pY, pXw, pMask);
     wavewin_end_of_tile(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, boxes, pSlot >= 0, lane);
-    if(nxt < 0)
+    if(!more)
       break;
+    g++;
 #pragma unroll
     for(int j = 0; j < kPts; j++)
       v[j] = vn[j];
-   }
+    }
   }
   wavewin_flush(ww, win, frameImg, imgWords, X.W64, X.winShift, boxes, lane);
   wavemiss_flush(wm, boxes, lane);
@@ -1882,6 +1941,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
   __shared__ unsigned long long lsum[kMaxPlateaus + 1][8];
   __shared__ unsigned int lcnt[kMaxPlateaus + 1][8];
   __shared__ unsigned int lOob;
+  __shared__ unsigned short cellList[kMaxCellsPerBlock];
+  __shared__ unsigned int listScratch[kWavesPerBlock];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int frame = blockIdx.x;                /* frame on the fast grid axis: see launch note on XCD balance */
@@ -1932,8 +1993,6 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
   const int begin = blockIdx.y * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
   unsigned long long *gimg = groundImg + static_cast<size_t>(frame) * X.H * X.W64;
-  const unsigned int *masks = tileMasks + static_cast<size_t>(frame) * tileMaskStride + (tid >> 6);
-  const unsigned int wanted = fs.wantedQuads;
   const int copy = lane & 7;
   const unsigned int imgWords = static_cast<unsigned int>(X.H) * X.W64;
   unsigned long long *ww = wins[tid >> 6];
@@ -1955,20 +2014,17 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
     }
   };
 
-  /* wave-uniform gate, 64 tiles per ballot, as in k_raster: tiles none of whose points (of this wave) can belong to a
-   * live quadrilateral are never loaded */
-  const int nTiles = (end - begin + kTile - 1) / kTile;
-  const int tile0 = begin / kTile;
-  for(int g = 0; g < nTiles; g += 64)
+  /* only the cells that hold a bin of a live quadrilateral are walked, four per wave iteration (cell_list_build) */
+  const int cell0 = begin / kCell;
+  const int nCells = (end - begin + kCell - 1) / kCell;
+  const int count = cell_list_build(tileMasks + static_cast<size_t>(frame) * tileMaskStride + cell0, nCells, X.cellCols, fs.wantedQuads,
+                                    cellList, listScratch);
+  const int nGroups = (count + 3) >> 2;
+  const int gEnd = ((tid >> 6) + 1) * nGroups / kWavesPerBlock;
+  for(int g = (tid >> 6) * nGroups / kWavesPerBlock; g < gEnd; g++)
   {
-    const int tl = g + lane;
-    unsigned long long bits = __ballot(tl < nTiles && (masks[static_cast<size_t>(tile0 + tl) * kWavesPerBlock] & wanted) != 0u);
-   while(bits)
-   {
-    const int cur = __ffsll(static_cast<long long>(bits)) - 1;
-    bits &= bits - 1ull;
     F3 v[kPts];
-    load_points<SRC>(base, begin + (g + cur) * kTile + kPts * tid, end, v, D);
+    load_cell<SRC>(base, cell0, cellList, 4 * g + (lane >> 4), count, lane, P.nPoints, v, D);
     int pY = -1;
     int pXw = 0;
     unsigned long long pMask = 0;
@@ -2007,18 +2063,17 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
         const int xw = ix >> 6;
         const bool same = iy == pY && xw == pXw;
         if(inside && !same && pY >= 0)
-          wavewin_or(ww, wm, win, gimg, imgWords, X.W64, X.winShift, 0, pY, pXw, pMask);
+          wavewin_or(ww, wm, win, gimg, imgWords, X.W64, X.winShiftGround, 0, pY, pXw, pMask);
         pMask = inside ? (same ? (pMask | bit) : bit) : pMask;
         pY = inside ? iy : pY;
         pXw = inside ? xw : pXw;
       }
     }
     if(pY >= 0)
-      wavewin_or(ww, wm, win, gimg, imgWords, X.W64, X.winShift, 0, pY, pXw, pMask);
-    wavewin_end_of_tile(ww, wm, win, gimg, imgWords, X.W64, X.winShift, box, pY >= 0, lane);
-   }
+      wavewin_or(ww, wm, win, gimg, imgWords, X.W64, X.winShiftGround, 0, pY, pXw, pMask);
+    wavewin_end_of_tile(ww, wm, win, gimg, imgWords, X.W64, X.winShiftGround, box, pY >= 0, lane);
   }
-  wavewin_flush(ww, win, gimg, imgWords, X.W64, X.winShift, box, lane);
+  wavewin_flush(ww, win, gimg, imgWords, X.W64, X.winShiftGround, box, lane);
   wavemiss_flush(wm, box, lane);
   flushAcc();
   if(oob)
@@ -2349,8 +2404,10 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
 template<int SRC>
 __global__ __launch_bounds__(kThreads, 8) void k_risers(const float *__restrict__ xyz, size_t strideFloats, PointParams P, double tol,
                                                         FrameState *__restrict__ st, const unsigned int *__restrict__ tileMasks,
-                                                        size_t tileMaskStride, int chunkPoints, DepthSrc D)
+                                                        size_t tileMaskStride, int chunkPoints, int cellCols, DepthSrc D)
 {
+  __shared__ unsigned short cellList[kMaxCellsPerBlock];
+  __shared__ unsigned int listScratch[kWavesPerBlock];
   __shared__ RiserState rs[kMaxRisers];
   __shared__ signed char riserOfBin[kMaxBins];
   __shared__ unsigned long long lsum[kMaxRisers][8];
@@ -2379,7 +2436,6 @@ __global__ __launch_bounds__(kThreads, 8) void k_risers(const float *__restrict_
     : xyz + static_cast<size_t>(frame) * strideFloats;
   const int begin = blockIdx.y * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
-  const unsigned int *masks = tileMasks + static_cast<size_t>(frame) * tileMaskStride + (tid >> 6);
   const int copy = lane & 7;
 
   int curR = -1;
@@ -2394,19 +2450,16 @@ __global__ __launch_bounds__(kThreads, 8) void k_risers(const float *__restrict_
     }
   };
 
-  /* wave-uniform gate, 64 tiles per ballot (as k_raster / k_inquad) */
-  const int nTiles = (end - begin + kTile - 1) / kTile;
-  const int tile0 = begin / kTile;
-  for(int g = 0; g < nTiles; g += 64)
+  /* only the cells that hold a bin of a riser are walked (as k_raster / k_inquad) */
+  const int cell0 = begin / kCell;
+  const int nCells = (end - begin + kCell - 1) / kCell;
+  const int count = cell_list_build(tileMasks + static_cast<size_t>(frame) * tileMaskStride + cell0, nCells, cellCols, wanted, cellList, listScratch);
+  const int nGroups = (count + 3) >> 2;
+  const int gEnd = ((tid >> 6) + 1) * nGroups / kWavesPerBlock;
+  for(int g = (tid >> 6) * nGroups / kWavesPerBlock; g < gEnd; g++)
   {
-    const int tl = g + lane;
-    unsigned long long bits = __ballot(tl < nTiles && (masks[static_cast<size_t>(tile0 + tl) * kWavesPerBlock] & wanted) != 0u);
-   while(bits)
-   {
-    const int cur = __ffsll(static_cast<long long>(bits)) - 1;
-    bits &= bits - 1ull;
     F3 v[kPts];
-    load_points<SRC>(base, begin + (g + cur) * kTile + kPts * tid, end, v, D);
+    load_cell<SRC>(base, cell0, cellList, 4 * g + (lane >> 4), count, lane, P.nPoints, v, D);
     #pragma unroll
     for(int j = 0; j < kPts; j++)
     {
@@ -2434,7 +2487,6 @@ __global__ __launch_bounds__(kThreads, 8) void k_risers(const float *__restrict_
       accS += z_to_fixed(sd);
       accN++;
     }
-   }
   }
   flushAcc();
   __syncthreads();
@@ -2600,6 +2652,12 @@ void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameSt
                  int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
+  static const int dynLds = getenv("SSD_K1_DYN_LDS") ? atoi(getenv("SSD_K1_DYN_LDS")) : 0;     /* experiment knob: limits residency */
+  if(dynLds > 0)
+  {
+    hipLaunchKernelGGL(k_hist<kSrcF3Aligned>, grid, dim3(kThreads), dynLds, s, xyz, strideFloats, P.pt, st, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
+    return;
+  }
   if(depth)
     hipLaunchKernelGGL(k_hist<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, tileMasks, tileMaskStride, chunkPoints, *depth);
   else if(aligned16(xyz, strideFloats, P.nPoints))
@@ -2651,11 +2709,11 @@ void launch_risers(const float *xyz, size_t strideFloats, const Params &P, Frame
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
   if(depth)
-    hipLaunchKernelGGL(k_risers<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.riserTol, st, tileMasks, tileMaskStride, chunkPoints, *depth);
+    hipLaunchKernelGGL(k_risers<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.riserTol, st, tileMasks, tileMaskStride, chunkPoints, P.px.cellCols, *depth);
   else if(aligned16(xyz, strideFloats, P.nPoints))
-    hipLaunchKernelGGL(k_risers<kSrcF3Aligned>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.riserTol, st, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
+    hipLaunchKernelGGL(k_risers<kSrcF3Aligned>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.riserTol, st, tileMasks, tileMaskStride, chunkPoints, P.px.cellCols, DepthSrc{});
   else
-    hipLaunchKernelGGL(k_risers<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.riserTol, st, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
+    hipLaunchKernelGGL(k_risers<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.riserTol, st, tileMasks, tileMaskStride, chunkPoints, P.px.cellCols, DepthSrc{});
   hipLaunchKernelGGL(k_riser_results, dim3((nframes + 63) / 64), dim3(64), 0, s, P, st, out, nframes);
 }
 void launch_synth(const ssd_scene *dScenes, float *xyz, size_t strideFloats, int nframes, int nPoints, hipStream_t s)

@@ -7,7 +7,10 @@
 namespace ssd
 {
 constexpr int kTileHost = 1024;
-constexpr int kMaxTilesPerBlockHost = 256;  /* K1 keeps one mask per wave tile of its chunk in LDS */   /* = kThreads * kPts of ssd_kernels.hip: chunk sizes are multiples of it */
+/* kTileHost = kThreads * kPts of ssd_kernels.hip: chunk sizes are multiples of it; a block's chunk is at most
+ * kMaxTilesPerBlockHost tiles (K1 keeps the chunk's cell masks, K2/K4/K6 the list of its wanted cells, in LDS) */
+constexpr int kMaxTilesPerBlockHost = 32;
+constexpr int kCellHost = 64;               /* points per cell (one gating mask each) */
 
 void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned int *tileMasks, size_t tileMaskStride,
                  int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s);

@@ -1,7 +1,19 @@
 #!/bin/bash
-# quick A/B on the GPU box: tests, then the XGA and FHD benches (extra bench.py arguments may be given)
-cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q -x 2>&1 | tail -3
-show='import json,sys; d=json.load(sys.stdin); print(round(d["value"]), round(d["ms_per_step"],3), round(sum(d["stage_ms"].values()),3), {k: round(v,3) for k,v in d["stage_ms"].items()})'
-python bench.py --steps 10 --warmup 2 --no-cpu "$@" 2>/dev/null | python -c "$show"
-python bench.py --workload fhd_stress --steps 10 --warmup 2 --no-cpu "$@" 2>/dev/null | python -c "$show"
+# tools/exp.sh TAG "ENV=VAL ENV=VAL" ... — one short bench per environment setting (GPU box, via gpurun); prints the stage
+# times.  A setting that contains the word FHD runs the fhd_stress workload.
+TAG=$1; shift
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+i=0
+for envs in "$@"; do
+  i=$((i+1))
+  wl="xga_batch"; case "$envs" in *FHD*) wl="fhd_stress";; esac
+  env $(echo $envs | sed 's/FHD//') timeout 200 python bench.py --workload $wl --steps 8 --warmup 2 --no-cpu > $OUT/b$i.json 2> $OUT/b$i.err
+  python - "$OUT/b$i.json" "$envs" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    print("%-40s %8.0f f/s  %s" % (sys.argv[2], d["value"], {k: round(v, 3) for k, v in d["stage_ms"].items()}))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+done
