@@ -14,12 +14,19 @@
  *   ssd_enqueue / ssd_fetch      the same, for frames already resident in device memory, asynchronous
  *   ssd_serialize                Stairs::serialize()                     stairs.cpp:55-70 (byte-exact text line)
  *   ssd_get_debug                integer intermediates for parity tests (hist, peaks, images, scans, lines)
- *   ssd_synth_*                  frame source replacing Camera::waitForFrames (camera.cpp:46-49): synthetic
- *                                L515-shaped clouds, bit-identical on host and device
+ *
+ * Not in this library: the synthetic frame source that stands in for the camera (include/ssd_source.h,
+ * libssd_source.so) and the hooks that let tests run pieces of the kernels in isolation (include/ssd_testhooks.h,
+ * libssd_testhooks.so).
  *
  * Plain pointers and sizes only; no C++ or torch types.  All functions return
  * 0 on success or a negative SSD_E_* code; nothing throws across the boundary.
  * A handle is bound to one device and is not thread-safe (one host thread per GPU).
+ * Streams: a handle's workspace is single-buffered, so its calls execute in the order they were made.  Use one stream
+ * per handle; if a call names another stream than the previous one (ssd_process_*_host use the default stream), the
+ * library orders it behind the previous call with an event — correct, but the two do not overlap.
+ * Configuration limits: max(|z_min|, |z_max|) < 2048 m and max|z| * width * height < 2^23 (the mean height of a step
+ * is accumulated in 2^-40 m fixed point), 3..SSD_MAX_BINS histogram bins, width and height <= 8192.
  */
 #ifndef SSD_HIP_H_
 #define SSD_HIP_H_
@@ -262,38 +269,6 @@ int ssd_get_debug(ssd_handle *h, int frame, ssd_debug_frame *out);
  * Only valid when debug capture was enabled for the batch. */
 int ssd_get_debug_image(ssd_handle *h, int frame, int step_slot, int closed, uint8_t *out);
 
-/* ---- synthetic frame source ------------------------------------------------- */
-typedef struct
-{
-  int32_t width, height;
-  double fx, fy, cx, cy;            /* pinhole intrinsics, pixels */
-  double cam_height;                /* camera centre above the ground plane, metres */
-  double axis_right[3];             /* camera x axis in scene coordinates (x right, y forward, z up) */
-  double axis_down[3];              /* camera y axis */
-  double axis_fwd[3];               /* camera z axis (optical axis) */
-  int32_t n_steps;
-  double first_riser_y;             /* pivot (0, first_riser_y): the first riser passes through it */
-  double tread, rise, stair_width, landing;
-  double yaw_cos, yaw_sin;          /* stairs rotated about the vertical through the pivot */
-  double sigma;                     /* depth noise standard deviation, metres */
-  double outlier_frac, outlier_min, outlier_max;  /* fraction of pixels replaced by uniform random depth */
-  double invalid_frac;              /* fraction of pixels reported invalid (0,0,0) */
-  double max_range;                 /* hits beyond this camera depth are invalid */
-  uint64_t seed;
-} ssd_scene;
-
-/* One frame per scene. Host version writes nframes*W*H*3 floats to xyz; device version writes to
- * device memory (frame i at d_xyz + i*frame_stride_bytes) on `stream`. Bit-identical outputs. */
-int ssd_synth_generate_host(const ssd_scene *scenes, int nframes, float *xyz);
-int ssd_synth_generate_device(const ssd_scene *scenes, int nframes, void *d_xyz, size_t frame_stride_bytes,
-                              int device, void *stream);
-/* synthetic depth frames of the same scenes (depth quantised to depth_units), host and device, bit-identical */
-int ssd_synth_depth_host(const ssd_scene *scenes, int nframes, float depth_units, uint16_t *depth);
-int ssd_synth_depth_device(const ssd_scene *scenes, int nframes, float depth_units, void *d_depth, size_t frame_stride_bytes,
-                           int device, void *stream);
-/* camera coordinates of a scene point (x right, y forward, z up) */
-int ssd_synth_scene_to_camera(const ssd_scene *scene, const double scene_xyz[3], double camera_xyz[3]);
-
 /* plain device-memory helpers so that hosts without a HIP binding can stage frames */
 int ssd_device_count(void);
 int ssd_device_alloc(int device, size_t bytes, void **d_ptr);
@@ -301,22 +276,6 @@ int ssd_device_free(int device, void *d_ptr);
 int ssd_device_upload(int device, void *d_dst, const void *src, size_t bytes);
 int ssd_device_download(int device, void *dst, const void *d_src, size_t bytes);
 int ssd_device_sync(int device);
-
-/* test hooks: std::hypot as the kernels compute it (glibc 2.35 algorithm restated), host and device */
-double ssd_test_hypot_host(double a, double b);
-int ssd_test_hypot_device(int device, const double *a, const double *b, double *out, int n);
-/* test hooks: std::sort as libstdc++ performs it, restated (csrc/ssd_sort.h) for the tie order of segmentation.cpp:724;
- * perm[k] = original index of the key at sorted position k */
-int ssd_test_sort_host(const double *dist, int n, int32_t *perm);
-int ssd_test_sort_device(int device, const double *dist, int n, int32_t *perm);
-/* test hook: QuadrilateralTest (quadrilateralTest.cpp:275-451) exactly as the kernels build and evaluate it, for one
- * quadrilateral (front-left, front-right, back-left, back-right as x,y) and n points; *err = 0 or the code of the
- * reference's throw (-1..-6), in which case `inside` is left zero */
-int ssd_test_quad_device(int device, const double quad[8], const double *pts_xy, int n, uint8_t *inside, int *err);
-/* test hook: the raw per-frame device state after the last enqueue (layout private to the library; layout[0..7] =
- * sizeof state, offsets of hist, lut, image boxes, plateau table, quadrilateral tests, sums, counts); returns the
- * number of bytes copied or a negative error */
-long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, long long layout[8]);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,37 @@
+/*
+ * ssd_testhooks.h — C ABI of libssd_testhooks.so: TEST INFRASTRUCTURE, not part of the product ABI.
+ * Lets tests run pieces of the kernels in isolation: std::hypot and std::sort as restated for the device, the
+ * kernels' QuadrilateralTest on one quadrilateral, a frame's raw device state.
+ */
+#ifndef SSD_TESTHOOKS_H_
+#define SSD_TESTHOOKS_H_
+
+#include "ssd_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* test hooks: std::hypot as the kernels compute it (glibc 2.35 algorithm restated), host and device */
+double ssd_test_hypot_host(double a, double b);
+int ssd_test_hypot_device(int device, const double *a, const double *b, double *out, int n);
+/* test hooks: std::sort as libstdc++ performs it, restated (csrc/ssd_sort.h) for the tie order of segmentation.cpp:724;
+ * perm[k] = original index of the key at sorted position k */
+int ssd_test_sort_host(const double *dist, int n, int32_t *perm);
+int ssd_test_sort_device(int device, const double *dist, int n, int32_t *perm);
+/* test hook: QuadrilateralTest (quadrilateralTest.cpp:275-451) exactly as the kernels build and evaluate it, for one
+ * quadrilateral (front-left, front-right, back-left, back-right as x,y) and n points; *err = 0 or the code of the
+ * reference's throw (-1..-6), in which case `inside` is left zero */
+int ssd_test_quad_device(int device, const double quad[8], const double *pts_xy, int n, uint8_t *inside, int *err);
+/* test hook: the raw per-frame device state after the last enqueue (layout private to the library; layout[0..7] =
+ * sizeof state, offsets of hist, lut, image boxes, plateau table, quadrilateral tests, sums, counts); returns the
+ * number of bytes copied or a negative error */
+long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, long long layout[8]);
+
+const char *ssd_testhooks_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SSD_TESTHOOKS_H_ */

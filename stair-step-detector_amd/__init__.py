@@ -120,20 +120,33 @@ class Scene(C.Structure):
                 ("seed", C.c_uint64)]
 
 
+# libssd_hip.so — the product ABI (include/ssd_hip.h)
 EXPORTS = [
     "ssd_default_config", "ssd_calibration_from_points", "ssd_calibration_identity", "ssd_calibration_load",
     "ssd_create", "ssd_destroy", "ssd_last_error", "ssd_workspace_bytes",
     "ssd_process_host", "ssd_enqueue", "ssd_fetch", "ssd_enqueue_stages",
     "ssd_set_intrinsics", "ssd_process_depth_host", "ssd_enqueue_depth", "ssd_deproject_host",
-    "ssd_synth_depth_host", "ssd_synth_depth_device",
     "ssd_fetch_back", "ssd_set_risers", "ssd_fetch_risers", "ssd_set_timing", "ssd_get_stage_times", "ssd_get_stage_times_back", "ssd_serialize",
     "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
-    "ssd_synth_generate_host", "ssd_synth_generate_device", "ssd_synth_scene_to_camera",
     "ssd_device_count", "ssd_device_alloc", "ssd_device_free", "ssd_device_upload", "ssd_device_download",
-    "ssd_device_sync", "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_quad_device", "ssd_test_sort_host", "ssd_test_sort_device",
+    "ssd_device_sync",
 ]
+# libssd_source.so — the frame source standing in for the camera (include/ssd_source.h)
+SOURCE_EXPORTS = [
+    "ssd_synth_generate_host", "ssd_synth_generate_device", "ssd_synth_depth_host", "ssd_synth_depth_device",
+    "ssd_synth_scene_to_camera", "ssd_source_default_scene", "ssd_source_write_calibration", "ssd_source_last_error",
+]
+# libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
+HOOK_EXPORTS = [
+    "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_quad_device", "ssd_test_sort_host",
+    "ssd_test_sort_device", "ssd_testhooks_last_error",
+]
+SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
+HOOKS_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_testhooks.so")
 
 _lib = None
+_source_lib = None
+_hooks_lib = None
 
 
 def lib():
@@ -164,8 +177,6 @@ def lib():
     L.ssd_process_depth_host.argtypes = [vp, vp, i32, C.POINTER(FrameResult)]
     L.ssd_enqueue_depth.argtypes = [vp, vp, sz, i32, vp]
     L.ssd_deproject_host.argtypes = [C.POINTER(Intrinsics), i32, i32, vp, vp]
-    L.ssd_synth_depth_host.argtypes = [C.POINTER(Scene), i32, C.c_float, vp]
-    L.ssd_synth_depth_device.argtypes = [C.POINTER(Scene), i32, C.c_float, vp, sz, i32, vp]
     L.ssd_set_timing.argtypes = [vp, i32]
     L.ssd_fetch_back.argtypes = [vp, C.POINTER(FrameResult), i32, i32]
     L.ssd_set_risers.argtypes = [vp, i32, C.c_double, i32]
@@ -176,29 +187,64 @@ def lib():
     L.ssd_set_debug.argtypes = [vp, i32]
     L.ssd_get_debug.argtypes = [vp, i32, C.POINTER(DebugFrame)]
     L.ssd_get_debug_image.argtypes = [vp, i32, i32, i32, vp]
-    L.ssd_synth_generate_host.argtypes = [C.POINTER(Scene), i32, vp]
-    L.ssd_synth_generate_device.argtypes = [C.POINTER(Scene), i32, vp, sz, i32, vp]
-    L.ssd_synth_scene_to_camera.argtypes = [C.POINTER(Scene), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ssd_device_alloc.argtypes = [i32, sz, C.POINTER(vp)]
     L.ssd_device_free.argtypes = [i32, vp]
     L.ssd_device_upload.argtypes = [i32, vp, vp, sz]
     L.ssd_device_download.argtypes = [i32, vp, vp, sz]
     L.ssd_device_sync.argtypes = [i32]
-    L.ssd_test_hypot_host.restype = C.c_double
-    L.ssd_test_hypot_host.argtypes = [C.c_double, C.c_double]
-    L.ssd_test_hypot_device.argtypes = [i32, vp, vp, vp, i32]
-    L.ssd_test_frame_state.argtypes = [vp, i32, vp, C.c_size_t, vp]
-    L.ssd_test_sort_host.argtypes = [vp, i32, vp]
-    L.ssd_test_sort_device.argtypes = [i32, vp, i32, vp]
-    L.ssd_test_quad_device.argtypes = [i32, vp, vp, i32, vp, C.POINTER(C.c_int)]
-    L.ssd_test_frame_state.restype = C.c_longlong
     _lib = L
     return L
 
 
-def _check(rc):
+def source_lib():
+    """Loads libssd_source.so (the synthetic frame source: tests, bench, driver); raises if it has not been built."""
+    global _source_lib
+    if _source_lib is not None:
+        return _source_lib
+    if not os.path.exists(SOURCE_LIB_PATH):
+        raise SsdError("%s is missing: build it with make -C stair-step-detector_amd/csrc" % SOURCE_LIB_PATH)
+    L = C.CDLL(SOURCE_LIB_PATH)
+    vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    L.ssd_source_last_error.restype = C.c_char_p
+    L.ssd_synth_depth_host.argtypes = [C.POINTER(Scene), i32, C.c_float, vp]
+    L.ssd_synth_depth_device.argtypes = [C.POINTER(Scene), i32, C.c_float, vp, sz, i32, vp]
+    L.ssd_synth_generate_host.argtypes = [C.POINTER(Scene), i32, vp]
+    L.ssd_synth_generate_device.argtypes = [C.POINTER(Scene), i32, vp, sz, i32, vp]
+    L.ssd_synth_scene_to_camera.argtypes = [C.POINTER(Scene), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ssd_source_default_scene.argtypes = [C.POINTER(Scene), i32, i32, i32, C.c_uint64]
+    L.ssd_source_write_calibration.argtypes = [C.POINTER(Scene), C.POINTER(C.c_double), C.c_char_p]
+    _source_lib = L
+    return L
+
+
+def hooks_lib():
+    """Loads libssd_testhooks.so (test infrastructure, not part of the product ABI)."""
+    global _hooks_lib
+    if _hooks_lib is not None:
+        return _hooks_lib
+    if not os.path.exists(HOOKS_LIB_PATH):
+        raise SsdError("%s is missing: build it with make -C stair-step-detector_amd/csrc" % HOOKS_LIB_PATH)
+    lib()                                           # the hooks take handles of the product library
+    L = C.CDLL(HOOKS_LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int
+    L.ssd_testhooks_last_error.restype = C.c_char_p
+    L.ssd_test_hypot_host.restype = C.c_double
+    L.ssd_test_hypot_host.argtypes = [C.c_double, C.c_double]
+    L.ssd_test_hypot_device.argtypes = [i32, vp, vp, vp, i32]
+    L.ssd_test_frame_state.argtypes = [vp, i32, vp, C.c_size_t, vp]
+    L.ssd_test_frame_state.restype = C.c_longlong
+    L.ssd_test_sort_host.argtypes = [vp, i32, vp]
+    L.ssd_test_sort_device.argtypes = [i32, vp, i32, vp]
+    L.ssd_test_quad_device.argtypes = [i32, vp, vp, i32, vp, C.POINTER(C.c_int)]
+    _hooks_lib = L
+    return L
+
+
+def _check(rc, which="hip"):
     if rc < 0:
-        raise SsdError("libssd_hip error %d: %s" % (rc, lib().ssd_last_error().decode()))
+        msg = {"hip": lambda: lib().ssd_last_error(), "source": lambda: source_lib().ssd_source_last_error(),
+               "hooks": lambda: hooks_lib().ssd_testhooks_last_error()}[which]().decode()
+        raise SsdError("libssd_%s error %d: %s" % (which, rc, msg))
     return rc
 
 
@@ -366,9 +412,7 @@ class Detector:
         """test hook: raw device state of one frame after the last enqueue -> (bytes, layout dict)"""
         lay = (C.c_longlong * 8)()
         buf = C.create_string_buffer(1 << 16)
-        n = lib().ssd_test_frame_state(self._h, frame, buf, len(buf), lay)
-        if n < 0:
-            raise RuntimeError(last_error())
+        n = _check(hooks_lib().ssd_test_frame_state(self._h, frame, buf, len(buf), lay), "hooks")
         names = ("size", "hist", "lut", "boxes", "plateaus", "quad_tests", "sum_z", "cnt")
         return buf.raw[:n], dict(zip(names, [int(x) for x in lay]))
 
@@ -405,9 +449,9 @@ def sort_perm(dist, device=None):
     d = np.ascontiguousarray(dist, dtype=np.float64)
     perm = np.zeros(len(d), dtype=np.int32)
     if device is None:
-        _check(lib().ssd_test_sort_host(d.ctypes.data_as(C.c_void_p), len(d), perm.ctypes.data_as(C.c_void_p)))
+        _check(hooks_lib().ssd_test_sort_host(d.ctypes.data_as(C.c_void_p), len(d), perm.ctypes.data_as(C.c_void_p)), "hooks")
     else:
-        _check(lib().ssd_test_sort_device(device, d.ctypes.data_as(C.c_void_p), len(d), perm.ctypes.data_as(C.c_void_p)))
+        _check(hooks_lib().ssd_test_sort_device(device, d.ctypes.data_as(C.c_void_p), len(d), perm.ctypes.data_as(C.c_void_p)), "hooks")
     return perm
 
 
@@ -417,8 +461,8 @@ def quad_test_device(quad, pts, device=0):
     p = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 2)
     out = np.zeros(len(p), dtype=np.uint8)
     err = C.c_int(0)
-    _check(lib().ssd_test_quad_device(device, q.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), len(p),
-                                      out.ctypes.data_as(C.c_void_p), C.byref(err)))
+    _check(hooks_lib().ssd_test_quad_device(device, q.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), len(p),
+                                            out.ctypes.data_as(C.c_void_p), C.byref(err)), "hooks")
     return err.value, out
 
 
@@ -464,7 +508,7 @@ def synth_host(scenes):
     arr = scene_array(scenes)
     h, w = scenes[0].height, scenes[0].width
     out = np.empty((len(scenes), h, w, 3), dtype=np.float32)
-    _check(lib().ssd_synth_generate_host(arr, len(scenes), out.ctypes.data_as(C.c_void_p)))
+    _check(source_lib().ssd_synth_generate_host(arr, len(scenes), out.ctypes.data_as(C.c_void_p)), "source")
     return out
 
 
@@ -479,14 +523,14 @@ def synth_depth_host(scenes, depth_units=0.00025):
     """-> uint16 [n, H, W]: the scenes as 16-bit depth frames; host, bit-identical to the device generator."""
     arr = scene_array(scenes)
     out = np.empty((len(scenes), scenes[0].height, scenes[0].width), dtype=np.uint16)
-    _check(lib().ssd_synth_depth_host(arr, len(scenes), depth_units, out.ctypes.data_as(C.c_void_p)))
+    _check(source_lib().ssd_synth_depth_host(arr, len(scenes), depth_units, out.ctypes.data_as(C.c_void_p)), "source")
     return out
 
 
 def synth_depth_device(scenes, d_ptr, depth_units=0.00025, stride_bytes=None, device=0, stream=None):
     arr = scene_array(scenes)
     stride = stride_bytes or scenes[0].width * scenes[0].height * 2
-    _check(lib().ssd_synth_depth_device(arr, len(scenes), depth_units, C.c_void_p(d_ptr), stride, device, C.c_void_p(stream or 0)))
+    _check(source_lib().ssd_synth_depth_device(arr, len(scenes), depth_units, C.c_void_p(d_ptr), stride, device, C.c_void_p(stream or 0)), "source")
 
 
 def deproject_host(intr, depth):
@@ -500,7 +544,7 @@ def deproject_host(intr, depth):
 def synth_device(scenes, d_ptr, stride_bytes=None, device=0, stream=None):
     arr = scene_array(scenes)
     stride = stride_bytes or scenes[0].width * scenes[0].height * 12
-    _check(lib().ssd_synth_generate_device(arr, len(scenes), C.c_void_p(d_ptr), stride, device, C.c_void_p(stream or 0)))
+    _check(source_lib().ssd_synth_generate_device(arr, len(scenes), C.c_void_p(d_ptr), stride, device, C.c_void_p(stream or 0)), "source")
 
 
 CALIBRATION_MARKS = ((-0.35, 0.9, 0.0), (0.35, 0.9, 0.0), (0.2, 0.35, 0.0))
@@ -512,7 +556,7 @@ def calibration_points(scene, marks=CALIBRATION_MARKS, world_offset=(0.0, 0.0, 0
     for m in marks:
         p = (C.c_double * 3)(*m)
         o = (C.c_double * 3)()
-        _check(lib().ssd_synth_scene_to_camera(C.byref(scene), p, o))
+        _check(source_lib().ssd_synth_scene_to_camera(C.byref(scene), p, o), "source")
         cam.append([o[0], o[1], o[2]])
         world.append([m[0] + world_offset[0], m[1] + world_offset[1], m[2] + world_offset[2]])
     return np.array(world), np.array(cam)

@@ -7,7 +7,8 @@
  *   detect-stairs-amd [--width W] [--height H] [--frames N] [--steps K] [--seed S] [--file frames.f32]
  *                     [--calibration files]   (GeometricCalibration::load() from the working directory, as detect-stairs.cpp:30)
  */
-#include "stairs_api.h"
+#include "../../include/stairs/stairs_api.h"
+#include "../../include/ssd_source.h"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,24 +19,8 @@ using namespace stairs;
 
 static ssd_scene makeScene(int W, int H, int K, uint64_t seed)
 {
-  ssd_scene s{};
-  const double pi = 3.14159265358979323846;
-  s.width = W; s.height = H;
-  s.fx = (W / 2.0) / std::tan(35.0 * pi / 180.0);
-  s.fy = (H / 2.0) / std::tan(27.5 * pi / 180.0);
-  s.cx = (W - 1) / 2.0; s.cy = (H - 1) / 2.0;
-  s.cam_height = 1.0;
-  const double pitch = 50.0 * pi / 180.0;
-  s.axis_right[0] = 1; s.axis_right[1] = 0; s.axis_right[2] = 0;
-  s.axis_down[0] = 0; s.axis_down[1] = -std::sin(pitch); s.axis_down[2] = -std::cos(pitch);
-  s.axis_fwd[0] = 0; s.axis_fwd[1] = std::cos(pitch); s.axis_fwd[2] = -std::sin(pitch);
-  s.n_steps = K;
-  s.first_riser_y = 0.45; s.tread = 0.28; s.rise = 0.17; s.stair_width = 0.8; s.landing = 1.0;
-  s.yaw_cos = 1.0; s.yaw_sin = 0.0;
-  s.sigma = 0.001;
-  s.outlier_frac = 0; s.outlier_min = 0.3; s.outlier_max = 3.0;
-  s.invalid_frac = 0; s.max_range = 9.0;
-  s.seed = seed;
+  ssd_scene s;
+  ssd_source_default_scene(&s, W, H, K, seed);
   return s;
 }
 

@@ -6,9 +6,9 @@
  * SSD_E_NODEVICE.
  */
 #include "ssd_launch.h"
-#include "ssd_synth.h"
-#include "ssd_sort.h"
+#include "ssd_handle.h"
 
+#include <charconv>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -47,44 +47,6 @@ int env_int(const char *name, int dflt)
 
 } // namespace
 
-struct ssd_handle
-{
-  int device = 0;
-  ssd_config cfg{};
-  Params P{};
-  int F = 0;                      /* max frames per batch */
-  size_t imgWords = 0;            /* 64-bit words per bit image */
-  FrameState *dState = nullptr;
-  unsigned long long *dStepImg = nullptr;
-  unsigned long long *dGroundImg = nullptr;
-  unsigned int *dTileMasks = nullptr;       /* per cell (64 points): which groups of 4 height bins occur; K1 -> K2, K4, K6 */
-  size_t tileMaskStride = 0;
-  float *dDepthMaps = nullptr;              /* xmap[W] then ymap[H] (ssd_set_intrinsics) */
-  ssd_intrinsics intr{};
-  bool haveIntr = false;
-  /* two result slots, used alternately by the enqueues that run the last stage: the device -> pinned-host copy of
-   * a batch's results is part of its enqueue, so that the next batch can be enqueued before the results are read */
-  ssd_frame_result *dResults = nullptr;     /* 2 x F */
-  ssd_frame_result *hResults = nullptr;     /* 2 x F, pinned */
-  hipEvent_t resultsReady[2] = { nullptr, nullptr };
-  int resultsFrames[2] = { 0, 0 };
-  unsigned long long finalCount = 0;        /* enqueues that produced results */
-  ssd_frame_risers *dRisers = nullptr;      /* vertical faces (extension), allocated by ssd_set_risers */
-  ssd_frame_risers *hRisers = nullptr;      /* pinned */
-  float *dFrames = nullptr;                 /* staging for ssd_process_host */
-  size_t dFramesCap = 0;                    /* frames */
-  DebugFrame *dDebug = nullptr;
-  unsigned long long *dDebugImg = nullptr;
-  bool debug = false;
-  bool imagesDirty = false;
-  int lastFrames = 0;
-  size_t bytes = 0;
-  /* per-stage timing: a ring of event sets, one per enqueue, so that a timed loop never has to synchronise */
-  bool timing = false;
-  std::vector<hipEvent_t> ev;     /* kTimingSlots x 8 */
-  unsigned long long enqueueCount = 0;
-  unsigned long long timedFrom = 0;
-};
 
 extern "C"
 {
@@ -340,6 +302,13 @@ static int make_params(const ssd_config &c, const ssd_calibration &k, Params &P)
   if(nBins < 3 || nBins > SSD_MAX_BINS)
     return fail(SSD_E_ARG, "config: histogram needs 3.." + std::to_string(SSD_MAX_BINS) + " bins");
   P.nBins = static_cast<int>(nBins);
+  /* mean z is accumulated as a sum of round(z * 2^40) in int64 through a magic-constant add that is exact only for
+   * |z| < 2048 (ssd_kernels.hip, z_plus_magic_bits), and the sum over a frame's points must stay below 2^63 */
+  {
+    const double zAbs = std::fmax(std::fabs(c.z_min), std::fabs(c.z_max));
+    if(!(zAbs < 2048.0) || !(zAbs * static_cast<double>(c.width) * static_cast<double>(c.height) < 8388608.0))
+      return fail(SSD_E_ARG, "config: max(|z_min|, |z_max|) must be < 2048 m and max|z| * width * height < 2^23 (fixed-point mean z)");
+  }
   if(c.max_step_plateaus < 1 || c.max_step_plateaus > SSD_MAX_STEP_IMAGES)
     return fail(SSD_E_ARG, "config: max_step_plateaus out of range");
   P.maxStepImages = c.max_step_plateaus;
@@ -429,6 +398,7 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   HIP_TRY_H(hipHostMalloc(&h->hResults, sizeof(ssd_frame_result) * h->F * 2, hipHostMallocDefault));
   HIP_TRY_H(hipEventCreateWithFlags(&h->resultsReady[0], hipEventDisableTiming));
   HIP_TRY_H(hipEventCreateWithFlags(&h->resultsReady[1], hipEventDisableTiming));
+  HIP_TRY_H(hipEventCreateWithFlags(&h->lastDone, hipEventDisableTiming));
   HIP_TRY_H(hipMemset(h->dState, 0, sizeof(FrameState) * h->F));
   HIP_TRY_H(hipMemset(h->dStepImg, 0, stepBytes));
   HIP_TRY_H(hipMemset(h->dGroundImg, 0, groundBytes));
@@ -454,6 +424,7 @@ int ssd_destroy(ssd_handle *h)
   if(h->hResults) (void)hipHostFree(h->hResults);
   for(hipEvent_t e : h->resultsReady)
     if(e) (void)hipEventDestroy(e);
+  if(h->lastDone) (void)hipEventDestroy(h->lastDone);
   if(h->dFrames) (void)hipFree(h->dFrames);
   if(h->dRisers) (void)hipFree(h->dRisers);
   if(h->hRisers) (void)hipHostFree(h->hRisers);
@@ -520,6 +491,8 @@ int ssd_fetch_risers(ssd_handle *h, ssd_frame_risers *out, int nframes, void *st
     return fail(SSD_E_ARG, "ssd_fetch_risers: nframes out of range");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if(h->haveLast && s != h->lastStream)
+    HIP_TRY(hipStreamWaitEvent(s, h->lastDone, 0));
   HIP_TRY(hipMemcpyAsync(h->hRisers, h->dRisers, sizeof(ssd_frame_risers) * nframes, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   std::memcpy(out, h->hRisers, sizeof(ssd_frame_risers) * nframes);
@@ -606,6 +579,9 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   }
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
+  /* the workspace is single-buffered: work enqueued on another stream than the previous call's waits for it */
+  if(h->haveLast && s != h->lastStream)
+    HIP_TRY(hipStreamWaitEvent(s, h->lastDone, 0));
   const Params &P = h->P;
   const float *xyz = static_cast<const float *>(d_xyz);
   const size_t strideFloats = depthInput ? frame_stride_bytes / 2 : frame_stride_bytes / 4;    /* elements of the source type */
@@ -667,6 +643,9 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
     h->finalCount++;
   }
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->lastDone, s));
+  h->lastStream = s;
+  h->haveLast = true;
   /* a raster without its consumer leaves bits behind */
   if(((stages & SSD_STAGE_RASTER) && !(stages & SSD_STAGE_OUTLINE)) || ((stages & SSD_STAGE_INQUAD) && !(stages & SSD_STAGE_FINAL)))
     h->imagesDirty = true;
@@ -849,11 +828,14 @@ int ssd_serialize(const ssd_frame_result *r, char *buf, size_t cap)
   }
   std::string s;
   s.reserve(128 + 160 * static_cast<size_t>(r->n_steps > 0 ? r->n_steps : 0));
-  char tmp[64];
+  /* fixed notation, 3 decimals, as `os << fixed << setprecision(3)` prints in the classic locale: std::to_chars is
+   * locale-independent (a host that called setlocale(LC_NUMERIC, "de_DE") must not get "0,170") and writes every
+   * digit of any magnitude (DBL_MAX has 309 integral digits) */
+  char tmp[384];
   auto num = [&](double v)
   {
-    std::snprintf(tmp, sizeof(tmp), "%.3f", v);
-    s += tmp;
+    const std::to_chars_result r = std::to_chars(tmp, tmp + sizeof(tmp), v, std::chars_format::fixed, 3);
+    s.append(tmp, r.ptr);
   };
   s += "[\"stairs\",[\"stairSteps\",";
   s += std::to_string(r->n_steps);
@@ -920,117 +902,6 @@ int ssd_get_debug_image(ssd_handle *h, int frame, int step_slot, int closed, uin
   return SSD_OK;
 }
 
-/* ---- synthetic frame source ------------------------------------------------ */
-
-int ssd_synth_generate_host(const ssd_scene *scenes, int nframes, float *xyz)
-{
-  if(!scenes || !xyz || nframes < 1)
-    return fail(SSD_E_ARG, "ssd_synth_generate_host: bad argument");
-  size_t off = 0;
-  for(int f = 0; f < nframes; f++)
-  {
-    const ssd_scene &s = scenes[f];
-    if(s.width <= 0 || s.height <= 0)
-      return fail(SSD_E_ARG, "ssd_synth_generate_host: bad scene size");
-    const uint64_t key = synth_frame_key(s);
-    for(int v = 0; v < s.height; v++)
-      for(int u = 0; u < s.width; u++)
-      {
-        synth_pixel(s, key, u, v, xyz + off);
-        off += 3;
-      }
-  }
-  return SSD_OK;
-}
-
-int ssd_synth_generate_device(const ssd_scene *scenes, int nframes, void *d_xyz, size_t frame_stride_bytes, int device, void *stream)
-{
-  if(!scenes || !d_xyz || nframes < 1 || nframes > 65535)
-    return fail(SSD_E_ARG, "ssd_synth_generate_device: bad argument");
-  const int nPoints = scenes[0].width * scenes[0].height;
-  for(int f = 0; f < nframes; f++)
-    if(scenes[f].width != scenes[0].width || scenes[f].height != scenes[0].height)
-      return fail(SSD_E_ARG, "ssd_synth_generate_device: all scenes of a batch must share one resolution");
-  if(frame_stride_bytes < static_cast<size_t>(nPoints) * 12 || frame_stride_bytes % 4)
-    return fail(SSD_E_ARG, "ssd_synth_generate_device: bad stride");
-  if(ssd_device_count() <= 0)
-    return fail(SSD_E_NODEVICE, "ssd_synth_generate_device: no HIP device");
-  HIP_TRY(hipSetDevice(device));
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  ssd_scene *dScenes = nullptr;
-  HIP_TRY(hipMalloc(&dScenes, sizeof(ssd_scene) * nframes));
-  hipError_t e = hipMemcpyAsync(dScenes, scenes, sizeof(ssd_scene) * nframes, hipMemcpyHostToDevice, s);
-  if(e == hipSuccess)
-  {
-    launch_synth(dScenes, static_cast<float *>(d_xyz), frame_stride_bytes / 4, nframes, nPoints, s);
-    e = hipGetLastError();
-  }
-  if(e == hipSuccess)
-    e = hipStreamSynchronize(s);
-  (void)hipFree(dScenes);
-  if(e != hipSuccess)
-    return fail(SSD_E_HIP, std::string("ssd_synth_generate_device: ") + hipGetErrorString(e));
-  return SSD_OK;
-}
-
-int ssd_synth_depth_host(const ssd_scene *scenes, int nframes, float depth_units, uint16_t *depth)
-{
-  if(!scenes || !depth || nframes < 1 || !(depth_units > 0.0f))
-    return fail(SSD_E_ARG, "ssd_synth_depth_host: bad argument");
-  size_t off = 0;
-  for(int f = 0; f < nframes; f++)
-  {
-    const ssd_scene &s = scenes[f];
-    const uint64_t key = synth_frame_key(s);
-    for(int v = 0; v < s.height; v++)
-      for(int u = 0; u < s.width; u++)
-        depth[off++] = synth_depth_raw(s, key, u, v, depth_units);
-  }
-  return SSD_OK;
-}
-
-int ssd_synth_depth_device(const ssd_scene *scenes, int nframes, float depth_units, void *d_depth, size_t frame_stride_bytes,
-                           int device, void *stream)
-{
-  if(!scenes || !d_depth || nframes < 1 || nframes > 65535 || !(depth_units > 0.0f))
-    return fail(SSD_E_ARG, "ssd_synth_depth_device: bad argument");
-  const int nPoints = scenes[0].width * scenes[0].height;
-  for(int f = 0; f < nframes; f++)
-    if(scenes[f].width != scenes[0].width || scenes[f].height != scenes[0].height)
-      return fail(SSD_E_ARG, "ssd_synth_depth_device: all scenes of a batch must share one resolution");
-  if(frame_stride_bytes < static_cast<size_t>(nPoints) * 2 || frame_stride_bytes % 2)
-    return fail(SSD_E_ARG, "ssd_synth_depth_device: bad stride");
-  if(ssd_device_count() <= 0)
-    return fail(SSD_E_NODEVICE, "ssd_synth_depth_device: no HIP device");
-  HIP_TRY(hipSetDevice(device));
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  ssd_scene *dScenes = nullptr;
-  HIP_TRY(hipMalloc(&dScenes, sizeof(ssd_scene) * nframes));
-  hipError_t e = hipMemcpyAsync(dScenes, scenes, sizeof(ssd_scene) * nframes, hipMemcpyHostToDevice, s);
-  if(e == hipSuccess)
-  {
-    launch_synth_depth(dScenes, static_cast<unsigned short *>(d_depth), frame_stride_bytes / 2, depth_units, nframes, nPoints, s);
-    e = hipGetLastError();
-  }
-  if(e == hipSuccess)
-    e = hipStreamSynchronize(s);
-  (void)hipFree(dScenes);
-  if(e != hipSuccess)
-    return fail(SSD_E_HIP, std::string("ssd_synth_depth_device: ") + hipGetErrorString(e));
-  return SSD_OK;
-}
-
-int ssd_synth_scene_to_camera(const ssd_scene *s, const double p[3], double out[3])
-{
-  if(!s || !p || !out)
-    return fail(SSD_E_ARG, "ssd_synth_scene_to_camera: null");
-  const double v[3] = { p[0], p[1], p[2] - s->cam_height };
-  out[0] = v[0] * s->axis_right[0] + v[1] * s->axis_right[1] + v[2] * s->axis_right[2];
-  out[1] = v[0] * s->axis_down[0] + v[1] * s->axis_down[1] + v[2] * s->axis_down[2];
-  out[2] = v[0] * s->axis_fwd[0] + v[1] * s->axis_fwd[1] + v[2] * s->axis_fwd[2];
-  return SSD_OK;
-}
-
 /* ---- plain device-memory helpers --------------------------------------------- */
 
 int ssd_device_alloc(int device, size_t bytes, void **d_ptr)
@@ -1065,110 +936,6 @@ int ssd_device_sync(int device)
 {
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipDeviceSynchronize());
-  return SSD_OK;
-}
-
-/* ---- test hooks ---------------------------------------------------------------- */
-
-/* hypot as the kernels compute it: on the host (no GPU needed) and on the device */
-double ssd_test_hypot_host(double a, double b)
-{
-  return hypot_ref_host(a, b);
-}
-long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, long long layout[8])
-{
-  if(!h || !out || frame < 0 || frame >= h->F)
-    return fail(SSD_E_ARG, "ssd_test_frame_state: bad argument");
-  if(layout)
-  {
-    layout[0] = sizeof(FrameState);
-    layout[1] = offsetof(FrameState, hist);
-    layout[2] = offsetof(FrameState, lut);
-    layout[3] = offsetof(FrameState, imgYMin);
-    layout[4] = offsetof(FrameState, pl);
-    layout[5] = offsetof(FrameState, qt);
-    layout[6] = offsetof(FrameState, sumZ);
-    layout[7] = offsetof(FrameState, cnt);
-  }
-  const size_t n = cap < sizeof(FrameState) ? cap : sizeof(FrameState);
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, h->dState + frame, n, hipMemcpyDeviceToHost));
-  return static_cast<long long>(n);
-}
-
-int ssd_test_sort_host(const double *dist, int n, int32_t *perm)
-{
-  if(!dist || !perm || n < 0 || n > 32768)
-    return fail(SSD_E_ARG, "ssd_test_sort_host: bad argument");
-  std::vector<double> d(dist, dist + n);
-  std::vector<int> idx(static_cast<size_t>(n));
-  for(int i = 0; i < n; i++)
-    idx[static_cast<size_t>(i)] = i;
-  gnu_sort(SortKeys{ d.data(), idx.data() }, n);
-  for(int i = 0; i < n; i++)
-    perm[i] = idx[static_cast<size_t>(i)];
-  return SSD_OK;
-}
-
-int ssd_test_sort_device(int device, const double *dist, int n, int32_t *perm)
-{
-  if(!dist || !perm || n < 1 || n > 32768)
-    return fail(SSD_E_ARG, "ssd_test_sort_device: bad argument");
-  if(ssd_device_count() <= 0)
-    return fail(SSD_E_NODEVICE, "ssd_test_sort_device: no HIP device");
-  HIP_TRY(hipSetDevice(device));
-  double *dd = nullptr;
-  int *di = nullptr;
-  HIP_TRY(hipMalloc(&dd, static_cast<size_t>(n) * sizeof(double)));
-  HIP_TRY(hipMalloc(&di, static_cast<size_t>(n) * sizeof(int)));
-  HIP_TRY(hipMemcpy(dd, dist, static_cast<size_t>(n) * sizeof(double), hipMemcpyHostToDevice));
-  launch_sorttest(dd, di, n, nullptr);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(perm, di, static_cast<size_t>(n) * sizeof(int), hipMemcpyDeviceToHost));
-  (void)hipFree(dd); (void)hipFree(di);
-  return SSD_OK;
-}
-
-int ssd_test_quad_device(int device, const double quad[8], const double *pts_xy, int n, uint8_t *inside, int *err)
-{
-  if(!quad || !pts_xy || !inside || !err || n < 1)
-    return fail(SSD_E_ARG, "ssd_test_quad_device: bad argument");
-  if(ssd_device_count() <= 0)
-    return fail(SSD_E_NODEVICE, "ssd_test_quad_device: no HIP device");
-  HIP_TRY(hipSetDevice(device));
-  double *dq = nullptr, *dp = nullptr;
-  unsigned char *di = nullptr;
-  int *de = nullptr;
-  HIP_TRY(hipMalloc(&dq, 8 * sizeof(double)));
-  HIP_TRY(hipMalloc(&dp, static_cast<size_t>(n) * 2 * sizeof(double)));
-  HIP_TRY(hipMalloc(&di, static_cast<size_t>(n)));
-  HIP_TRY(hipMalloc(&de, sizeof(int)));
-  HIP_TRY(hipMemcpy(dq, quad, 8 * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dp, pts_xy, static_cast<size_t>(n) * 2 * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(di, 0, static_cast<size_t>(n)));
-  launch_quadtest(dq, dp, n, di, de, nullptr);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(inside, di, static_cast<size_t>(n), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(err, de, sizeof(int), hipMemcpyDeviceToHost));
-  (void)hipFree(dq); (void)hipFree(dp); (void)hipFree(di); (void)hipFree(de);
-  return SSD_OK;
-}
-
-int ssd_test_hypot_device(int device, const double *a, const double *b, double *out, int n)
-{
-  if(ssd_device_count() <= 0)
-    return fail(SSD_E_NODEVICE, "ssd_test_hypot_device: no HIP device");
-  HIP_TRY(hipSetDevice(device));
-  double *da = nullptr, *db = nullptr, *dout = nullptr;
-  HIP_TRY(hipMalloc(&da, 8 * static_cast<size_t>(n)));
-  HIP_TRY(hipMalloc(&db, 8 * static_cast<size_t>(n)));
-  HIP_TRY(hipMalloc(&dout, 8 * static_cast<size_t>(n)));
-  HIP_TRY(hipMemcpy(da, a, 8 * static_cast<size_t>(n), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(db, b, 8 * static_cast<size_t>(n), hipMemcpyHostToDevice));
-  launch_hypot(da, db, dout, n, nullptr);
-  HIP_TRY(hipMemcpy(out, dout, 8 * static_cast<size_t>(n), hipMemcpyDeviceToHost));
-  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
   return SSD_OK;
 }
 

@@ -16,8 +16,8 @@
  * K1/K2/K4 are HBM-read bound (12 B per raw point); no MFMA anywhere.
  */
 #include "ssd_device.h"
-#include "ssd_synth.h"
-
+#include "ssd_math.h"
+#include "ssd_quadtest.h"
 #include "ssd_sort.h"
 
 namespace ssd
@@ -910,89 +910,6 @@ __device__ __forceinline__ void closed_column(const BitImg &im, int c, int yA, i
 }
 
 /* ========================================================================= */
-/* small fp64 helpers that must match the host libm bit for bit                */
-
-/* std::hypot as glibc 2.35 computes it without FMA (sysdeps/ieee754/dbl-64/e_hypot.c): the oracle
- * calls the host's hypot, the device restates the published algorithm; tests/test_oracle.py checks
- * the two agree on this image. */
-__host__ __device__ inline double hypot_kernel(double ax, double ay)
-{
-  double t1, t2;
-  double h = sqrt(ax * ax + ay * ay);
-  if(h <= 2.0 * ay)
-  {
-    const double delta = h - ay;
-    t1 = ax * (2.0 * delta - ax);
-    t2 = (delta - 2.0 * (ax - ay)) * delta;
-  }
-  else
-  {
-    const double delta = h - ax;
-    t1 = 2.0 * delta * (ax - 2.0 * ay);
-    t2 = (4.0 * delta - ay) * ay + delta * delta;
-  }
-  h -= (t1 + t2) / (2.0 * h);
-  return h;
-}
-
-__host__ __device__ inline double hypot_ref(double x, double y)
-{
-  const double kScale = 0x1p-600, kLarge = 0x1p+511, kTiny = 0x1p-459, kEps = 0x1p-54;
-  x = fabs(x);
-  y = fabs(y);
-  double ax = x < y ? y : x;
-  double ay = x < y ? x : y;
-  if(ax > kLarge)
-  {
-    if(ay <= ax * kEps)
-      return ax + ay;
-    return hypot_kernel(ax * kScale, ay * kScale) / kScale;
-  }
-  if(ay < kTiny)
-  {
-    if(ax >= ay / kEps)
-      return ax + ay;
-    return hypot_kernel(ax / kScale, ay / kScale) * kScale;
-  }
-  if(ax * kEps >= ay)
-    return ax + ay;
-  return hypot_kernel(ax, ay);
-}
-
-struct LineD { double a, b, c; };
-struct LineI { int a, b, c; };
-
-/* LineCoordinates(p, q), types.h:140-158 */
-__device__ __forceinline__ LineI line_through_i(int x1, int y1, int x2, int y2)
-{
-  return { y2 - y1, x1 - x2, x2 * y1 - x1 * y2 };
-}
-__device__ __forceinline__ LineD line_through_d(double x1, double y1, double x2, double y2)
-{
-  return { y2 - y1, x1 - x2, x2 * y1 - x1 * y2 };
-}
-/* Line<double>::normalized, segmentation.cpp:383-387 */
-__device__ __forceinline__ LineD normalized_line(double a, double b, double c)
-{
-  const double h = hypot_ref(a, b);
-  return { a / h, b / h, c / h };
-}
-/* Line<double>::intersection, segmentation.cpp:344-362; returns false for angles <= 60 degrees */
-__device__ __forceinline__ bool intersect60(const LineD &l, const LineD &o, double &x, double &y)
-{
-  const double kTan60 = 1.7320508075688772;       /* std::numbers::sqrt3 */
-  const double numerator = l.a * o.b - o.a * l.b;
-  const double denominator = l.a * o.a + l.b * o.b;
-  if(fabs(numerator) > fabs(denominator) * kTan60)
-  {
-    x = (l.b * o.c - o.b * l.c) / numerator;
-    y = (o.a * l.c - l.a * o.c) / numerator;
-    return true;
-  }
-  return false;
-}
-
-/* ========================================================================= */
 /* BestLine (segmentation.cpp:409-487), one wave per point list                */
 
 /* residual of the line through points p and q: sum of the n smallest |a x + b y + c| of the other
@@ -1583,236 +1500,6 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
 
 /* ========================================================================= */
 /* K3b: ground quadrilateral and the prepared quadrilateral tests              */
-
-struct SegTmp { double bxLo, bxUp, byLo, byUp; };
-
-__device__ __forceinline__ void sector_init(double a, double b, double &lo, double &up)
-{
-  lo = a; up = a;                       /* Sector(a, b): quadrilateralTest.cpp:28-40 */
-  if(lo > b) lo = b;
-  else if(up < b) up = b;
-}
-__device__ __forceinline__ void sector_expand(double c, double &lo, double &up)
-{
-  if(lo > c) lo = c;
-  else if(up < c) up = c;
-}
-__device__ __forceinline__ bool sector_overlaps(double lo, double up, double olo, double oup)
-{
-  return lo < oup && up > olo;
-}
-
-/* QuadrilateralTest::QuadrilateralTest (quadrilateralTest.cpp:275-443) flattened into tables */
-__device__ void build_quad_test(const double *q /* 4 x (x,y) */, QuadTest &t)
-{
-  t.err = 0;
-  t.fx0 = 1.0; t.fx1 = 0.0; t.fy0 = 1.0; t.fy1 = 0.0;
-  sector_init(q[0], q[2], t.bxLo, t.bxUp);
-  sector_init(q[1], q[3], t.byLo, t.byUp);
-  sector_expand(q[4], t.bxLo, t.bxUp); sector_expand(q[5], t.byLo, t.byUp);
-  sector_expand(q[6], t.bxLo, t.bxUp); sector_expand(q[7], t.byLo, t.byUp);
-
-  /* segments counterclockwise: 0->1, 1->3, 3->2, 2->0 */
-  const int sp[4] = { 0, 1, 3, 2 }, sq[4] = { 1, 3, 2, 0 };
-  SegTmp box[4];
-  for(int s = 0; s < 4; s++)
-  {
-    const double px = q[2 * sp[s]], py = q[2 * sp[s] + 1], qx = q[2 * sq[s]], qy = q[2 * sq[s] + 1];
-    sector_init(px, qx, box[s].bxLo, box[s].bxUp);
-    sector_init(py, qy, box[s].byLo, box[s].byUp);
-    const double dx = qx - px, dy = qy - py;
-    const LineD l = line_through_d(px, py, qx, qy);
-    if(fabs(dx) < fabs(dy))
-    {
-      t.segSteep[s] = 1;                      /* SteepLine :145-166 */
-      t.segK[s] = l.b / l.a;
-      t.segC[s] = l.c / l.a;
-      t.segLeftIfPositive[s] = dy > 0 ? 0 : 1;
-    }
-    else
-    {
-      t.segSteep[s] = 0;                      /* FlatLine :124-143 */
-      t.segK[s] = l.a / l.b;
-      t.segC[s] = l.c / l.b;
-      t.segLeftIfPositive[s] = dx > 0 ? 1 : 0;
-    }
-  }
-  auto isLeft = [&](int s, double x, double y)
-  {
-    const bool positive = t.segSteep[s] ? (x + y * t.segK[s] + t.segC[s] > 0) : (x * t.segK[s] + y + t.segC[s] > 0);
-    return t.segLeftIfPositive[s] ? positive : !positive;
-  };
-  const bool inside = isLeft(0, q[6], q[7]);
-  t.insideIsLeft = inside ? 1 : 0;
-  if(inside != isLeft(1, q[4], q[5]) || inside != isLeft(2, q[0], q[1]) || inside != isLeft(3, q[2], q[3]))
-  {
-    t.err = -1;
-    return;
-  }
-
-  double xs[4] = { q[0], q[2], q[4], q[6] }, ys[4] = { q[1], q[3], q[5], q[7] };
-  for(int i = 1; i < 4; i++)                 /* insertion sort of 4 */
-  {
-    const double vx = xs[i], vy = ys[i];
-    int k = i - 1;
-    while(k >= 0 && xs[k] > vx) { xs[k + 1] = xs[k]; k--; }
-    xs[k + 1] = vx;
-    k = i - 1;
-    while(k >= 0 && ys[k] > vy) { ys[k + 1] = ys[k]; k--; }
-    ys[k + 1] = vy;
-  }
-
-  int nRows = 0;
-  double rowUpper[3];
-  int nCells[3];
-  double cellUpper[3][3];
-  unsigned char cellMask[3][3], cellCnt[3][3], cellConst[3][3];
-  double lowerY = ys[0];
-  for(int yi = 1; yi < 4; yi++)
-  {
-    if(!(lowerY < ys[yi]))
-      continue;
-    const int r = nRows++;
-    rowUpper[r] = ys[yi];
-    nCells[r] = 0;
-    double lowerX = xs[0];
-    for(int xi = 1; xi < 4; xi++)
-    {
-      if(!(lowerX < xs[xi]))
-        continue;
-      const int c = nCells[r]++;
-      cellUpper[r][c] = xs[xi];
-      double cxLo, cxUp, cyLo, cyUp;
-      sector_init(lowerX, xs[xi], cxLo, cxUp);
-      sector_init(lowerY, ys[yi], cyLo, cyUp);
-      unsigned char mask = 0, cnt = 0;
-      bool nb[5] = { false, false, false, false, false };
-      for(int s = 0; s < 4; s++)
-      {
-        const bool xo = sector_overlaps(cxLo, cxUp, box[s].bxLo, box[s].bxUp);
-        const bool yo = sector_overlaps(cyLo, cyUp, box[s].byLo, box[s].byUp);
-        if(xo && yo)
-        {
-          mask |= static_cast<unsigned char>(1u << s);
-          cnt++;
-        }
-        if(cnt == 0)
-        {
-          /* BBox::getRelativePosition :93-110 */
-          int rel = 0;
-          const double mx = (cxLo + cxUp) / 2, my = (cyLo + cyUp) / 2;
-          if(yo && mx < box[s].bxLo) rel = 1;
-          else if(yo && mx > box[s].bxUp) rel = 2;
-          else if(xo && my < box[s].byLo) rel = 3;
-          else if(xo && my > box[s].byUp) rel = 4;
-          nb[rel] = true;
-        }
-      }
-      cellMask[r][c] = mask;
-      cellCnt[r][c] = cnt;
-      cellConst[r][c] = (nb[1] && nb[2] && nb[3] && nb[4]) ? 1 : 0;
-      lowerX = xs[xi];
-    }
-    lowerY = ys[yi];
-  }
-  if(nRows == 0) { t.err = -2; return; }
-  for(int r = 0; r < nRows; r++)
-  {
-    if(nCells[r] == 0) { t.err = -3; return; }
-    for(int c = 0; c < nCells[r]; c++)
-      if(cellCnt[r][c] > 2) { t.err = -4; return; }
-  }
-  /* merge equal neighbours (:377-394) */
-  for(int r = 0; r < nRows; r++)
-  {
-    int c = 0;
-    while(c + 1 < nCells[r])
-    {
-      const unsigned char cur = cellMask[r][c], nxt = cellMask[r][c + 1];
-      if(cur == 0 && nxt == 0) { t.err = -5; return; }
-      if(cellCnt[r][c] > 1 && cellCnt[r][c + 1] > 1) { t.err = -6; return; }
-      if(cur == nxt)
-      {
-        for(int k = c; k + 1 < nCells[r]; k++)
-        {
-          cellUpper[r][k] = cellUpper[r][k + 1];
-          cellMask[r][k] = cellMask[r][k + 1];
-          cellCnt[r][k] = cellCnt[r][k + 1];
-          cellConst[r][k] = cellConst[r][k + 1];
-        }
-        nCells[r]--;
-      }
-      else
-        c++;
-    }
-  }
-  t.nRows = static_cast<unsigned char>(nRows);
-  for(int r = 0; r < 3; r++)
-  {
-    t.nCells[r] = r < nRows ? static_cast<unsigned char>(nCells[r]) : 0;
-    for(int c = 0; c < 3; c++)
-    {
-      const bool live = r < nRows && c < nCells[r];
-      t.cellMask[r][c] = live ? cellMask[r][c] : 0;
-      t.cellConst[r][c] = live ? cellConst[r][c] : 0;
-    }
-    t.xTrans[r][0] = r < nRows && nCells[r] > 1 ? cellUpper[r][0] : 0.0;
-    t.xTrans[r][1] = r < nRows && nCells[r] > 2 ? cellUpper[r][1] : 0.0;
-  }
-  t.yTrans[0] = nRows > 1 ? rowUpper[0] : 0.0;
-  t.yTrans[1] = nRows > 2 ? rowUpper[1] : 0.0;
-
-  /* fast cell: the selectors put (x, y) into row r / cell c exactly when lower <= coordinate < upper
-   * (quadrilateralTest.cpp:487-571), first and last cells being bounded by the strict bounding box */
-  double bestArea = -1.0;
-  for(int r = 0; r < nRows; r++)
-  {
-    const double y0 = r == 0 ? nextafter(t.byLo, 1e300) : rowUpper[r - 1];
-    const double y1 = r == nRows - 1 ? t.byUp : rowUpper[r];
-    for(int c = 0; c < nCells[r]; c++)
-    {
-      if(cellMask[r][c] != 0 || cellConst[r][c] == 0)
-        continue;
-      const double x0 = c == 0 ? nextafter(t.bxLo, 1e300) : cellUpper[r][c - 1];
-      const double x1 = c == nCells[r] - 1 ? t.bxUp : cellUpper[r][c];
-      const double area = (x1 - x0) * (y1 - y0);
-      if(area > bestArea)
-      {
-        bestArea = area;
-        t.fx0 = x0; t.fx1 = x1; t.fy0 = y0; t.fy1 = y1;
-      }
-    }
-  }
-}
-
-/* QuadrilateralTest::isPointWithin (quadrilateralTest.cpp:445-451 and the selector lambdas :487-571) */
-__device__ __forceinline__ bool quad_test(const QuadTest &t, double x, double y)
-{
-  if(!(t.bxLo < x && x < t.bxUp && t.byLo < y && y < t.byUp))
-    return false;
-  int r = 0;
-  if(t.nRows > 1 && !(y < t.yTrans[0]))
-    r = (t.nRows == 2 || y < t.yTrans[1]) ? 1 : 2;
-  const int nc = t.nCells[r];
-  int c = 0;
-  if(nc > 1 && !(x < t.xTrans[r][0]))
-    c = (nc == 2 || x < t.xTrans[r][1]) ? 1 : 2;
-  unsigned int mask = t.cellMask[r][c];
-  if(mask == 0)
-    return t.cellConst[r][c] != 0;                     /* the large middle cell of a tread: no arithmetic */
-  const bool inside = t.insideIsLeft != 0;
-  bool ok = true;
-  while(mask)                                          /* at most two segments per cell (:370-372) */
-  {
-    const int s = __ffs(static_cast<int>(mask)) - 1;
-    mask &= mask - 1;
-    const double k = t.segK[s], cc = t.segC[s];
-    const bool positive = t.segSteep[s] ? (x + y * k + cc > 0) : (x * k + y + cc > 0);
-    const bool left = t.segLeftIfPositive[s] ? positive : !positive;
-    ok = ok && (left == inside);
-  }
-  return ok;
-}
 
 /* one wave per frame: lane k < kMaxPlateaus builds the test of plateau k, lane kGroundAcc the ground's */
 __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__ st, int nframes, DebugFrame *__restrict__ dbg)
@@ -2541,91 +2228,6 @@ __global__ void k_riser_results(Params P, const FrameState *__restrict__ st, ssd
   }
 }
 
-/* test hook: gnu_sort on the device */
-__global__ void k_sorttest(double *dist, int *idx, int n)
-{
-  if(blockIdx.x == 0 && threadIdx.x == 0)
-  {
-    for(int i = 0; i < n; i++)
-      idx[i] = i;
-    gnu_sort(SortKeys{ dist, idx }, n);
-  }
-}
-
-/* test hook: QuadrilateralTest as the kernels build and evaluate it (build_quad_test + the constant cell + quad_test),
- * one quadrilateral, n points; err = the negative code of the reference's throw or 0 */
-__global__ void k_quadtest(const double *__restrict__ quad, const double *__restrict__ pts, int n, unsigned char *__restrict__ inside,
-                           int *__restrict__ err)
-{
-  __shared__ QuadTest t;
-  if(threadIdx.x == 0)
-  {
-    double q[8];
-    for(int k = 0; k < 8; k++)
-      q[k] = quad[k];
-    QuadTest local;
-    build_quad_test(q, local);
-    t = local;
-    if(blockIdx.x == 0)
-      *err = local.err;
-  }
-  __syncthreads();
-  if(t.err)
-    return;
-  for(int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-  {
-    const double x = pts[2 * i], y = pts[2 * i + 1];
-    const bool fast = x >= t.fx0 && x < t.fx1 && y >= t.fy0 && y < t.fy1;
-    inside[i] = (fast || quad_test(t, x, y)) ? 1 : 0;
-  }
-}
-
-/* ========================================================================= */
-/* synthetic frame source                                                      */
-
-__global__ __launch_bounds__(kThreads) void k_synth(const ssd_scene *__restrict__ scenes, float *__restrict__ xyz,
-                                                    size_t strideFloats)
-{
-  const int frame = blockIdx.y;
-  const ssd_scene s = scenes[frame];
-  const int n = s.width * s.height;
-  const uint64_t key = synth_frame_key(s);
-  float *out = xyz + static_cast<size_t>(frame) * strideFloats;
-  for(int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
-  {
-    const int v = i / s.width, u = i - v * s.width;
-    float p[3];
-    synth_pixel(s, key, u, v, p);
-    out[3 * static_cast<size_t>(i)] = p[0];
-    out[3 * static_cast<size_t>(i) + 1] = p[1];
-    out[3 * static_cast<size_t>(i) + 2] = p[2];
-  }
-}
-
-/* synthetic 16-bit depth frames: the same scenes, depth quantised to depth_units as the sensor reports it */
-__global__ __launch_bounds__(kThreads) void k_synth_depth(const ssd_scene *__restrict__ scenes, unsigned short *__restrict__ depth,
-                                                          size_t strideElems, float depthUnits)
-{
-  const int frame = blockIdx.y;
-  const ssd_scene s = scenes[frame];
-  const int n = s.width * s.height;
-  const uint64_t key = synth_frame_key(s);
-  unsigned short *out = depth + static_cast<size_t>(frame) * strideElems;
-  for(int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
-  {
-    const int v = i / s.width, u = i - v * s.width;
-    out[i] = synth_depth_raw(s, key, u, v, depthUnits);
-  }
-}
-
-/* test hook: hypot_ref on the device */
-__global__ void k_hypot(const double *a, const double *b, double *out, int n)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if(i < n)
-    out[i] = hypot_ref(a[i], b[i]);
-}
-
 } // namespace ssd
 
 /* ========================================================================= */
@@ -2716,32 +2318,5 @@ void launch_risers(const float *xyz, size_t strideFloats, const Params &P, Frame
     hipLaunchKernelGGL(k_risers<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.riserTol, st, tileMasks, tileMaskStride, chunkPoints, P.px.cellCols, DepthSrc{});
   hipLaunchKernelGGL(k_riser_results, dim3((nframes + 63) / 64), dim3(64), 0, s, P, st, out, nframes);
 }
-void launch_synth(const ssd_scene *dScenes, float *xyz, size_t strideFloats, int nframes, int nPoints, hipStream_t s)
-{
-  int bx = (nPoints + kThreads * 4 - 1) / (kThreads * 4);
-  if(bx > 2048) bx = 2048;
-  if(bx < 1) bx = 1;
-  hipLaunchKernelGGL(k_synth, dim3(bx, nframes), dim3(kThreads), 0, s, dScenes, xyz, strideFloats);
-}
-void launch_synth_depth(const ssd_scene *dScenes, unsigned short *depth, size_t strideElems, float depthUnits, int nframes, int nPoints, hipStream_t s)
-{
-  int bx = (nPoints + kThreads * 4 - 1) / (kThreads * 4);
-  if(bx > 2048) bx = 2048;
-  if(bx < 1) bx = 1;
-  hipLaunchKernelGGL(k_synth_depth, dim3(bx, nframes), dim3(kThreads), 0, s, dScenes, depth, strideElems, depthUnits);
-}
-void launch_sorttest(double *dist, int *idx, int n, hipStream_t s)
-{
-  hipLaunchKernelGGL(k_sorttest, dim3(1), dim3(64), 0, s, dist, idx, n);
-}
-void launch_quadtest(const double *quad, const double *pts, int n, unsigned char *inside, int *err, hipStream_t s)
-{
-  hipLaunchKernelGGL(k_quadtest, dim3(n > 4096 ? 16 : 1), dim3(256), 0, s, quad, pts, n, inside, err);
-}
-void launch_hypot(const double *a, const double *b, double *out, int n, hipStream_t s)
-{
-  hipLaunchKernelGGL(k_hypot, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, n);
-}
-double hypot_ref_host(double a, double b) { return hypot_ref(a, b); }
 
 } // namespace ssd

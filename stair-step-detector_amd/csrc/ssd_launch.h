@@ -24,12 +24,6 @@ void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, Frame
 void launch_final(const Params &P, FrameState *st, unsigned long long *groundImg, ssd_frame_result *results, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s);
 void launch_risers(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, const unsigned int *tileMasks, size_t tileMaskStride,
                    ssd_frame_risers *out, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s);
-void launch_synth(const ssd_scene *dScenes, float *xyz, size_t strideFloats, int nframes, int nPoints, hipStream_t s);
-void launch_synth_depth(const ssd_scene *dScenes, unsigned short *depth, size_t strideElems, float depthUnits, int nframes, int nPoints, hipStream_t s);
-void launch_sorttest(double *dist, int *idx, int n, hipStream_t s);
-void launch_quadtest(const double *quad, const double *pts, int n, unsigned char *inside, int *err, hipStream_t s);
-void launch_hypot(const double *a, const double *b, double *out, int n, hipStream_t s);
-double hypot_ref_host(double a, double b);
 }
 
 #endif /* SSD_LAUNCH_H_ */

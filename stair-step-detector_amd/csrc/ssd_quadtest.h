@@ -1,0 +1,247 @@
+/*
+ * ssd_quadtest.h — QuadrilateralTest (quadrilateralTest.cpp:275-451) as the kernels build and evaluate it: the 3x3
+ * cell map flattened into tables (ssd_device.h, QuadTest).  Shared by ssd_kernels.hip (k_quads, k_inquad) and the
+ * test hook that runs it against the reference's golden vectors (ssd_testhooks.hip).
+ */
+#ifndef SSD_QUADTEST_H_
+#define SSD_QUADTEST_H_
+
+#include "ssd_device.h"
+#include "ssd_math.h"
+
+namespace ssd
+{
+
+struct SegTmp { double bxLo, bxUp, byLo, byUp; };
+
+__device__ __forceinline__ void sector_init(double a, double b, double &lo, double &up)
+{
+  lo = a; up = a;                       /* Sector(a, b): quadrilateralTest.cpp:28-40 */
+  if(lo > b) lo = b;
+  else if(up < b) up = b;
+}
+__device__ __forceinline__ void sector_expand(double c, double &lo, double &up)
+{
+  if(lo > c) lo = c;
+  else if(up < c) up = c;
+}
+__device__ __forceinline__ bool sector_overlaps(double lo, double up, double olo, double oup)
+{
+  return lo < oup && up > olo;
+}
+
+/* QuadrilateralTest::QuadrilateralTest (quadrilateralTest.cpp:275-443) flattened into tables */
+__device__ inline void build_quad_test(const double *q /* 4 x (x,y) */, QuadTest &t)
+{
+  t.err = 0;
+  t.fx0 = 1.0; t.fx1 = 0.0; t.fy0 = 1.0; t.fy1 = 0.0;
+  sector_init(q[0], q[2], t.bxLo, t.bxUp);
+  sector_init(q[1], q[3], t.byLo, t.byUp);
+  sector_expand(q[4], t.bxLo, t.bxUp); sector_expand(q[5], t.byLo, t.byUp);
+  sector_expand(q[6], t.bxLo, t.bxUp); sector_expand(q[7], t.byLo, t.byUp);
+
+  /* segments counterclockwise: 0->1, 1->3, 3->2, 2->0 */
+  const int sp[4] = { 0, 1, 3, 2 }, sq[4] = { 1, 3, 2, 0 };
+  SegTmp box[4];
+  for(int s = 0; s < 4; s++)
+  {
+    const double px = q[2 * sp[s]], py = q[2 * sp[s] + 1], qx = q[2 * sq[s]], qy = q[2 * sq[s] + 1];
+    sector_init(px, qx, box[s].bxLo, box[s].bxUp);
+    sector_init(py, qy, box[s].byLo, box[s].byUp);
+    const double dx = qx - px, dy = qy - py;
+    const LineD l = line_through_d(px, py, qx, qy);
+    if(fabs(dx) < fabs(dy))
+    {
+      t.segSteep[s] = 1;                      /* SteepLine :145-166 */
+      t.segK[s] = l.b / l.a;
+      t.segC[s] = l.c / l.a;
+      t.segLeftIfPositive[s] = dy > 0 ? 0 : 1;
+    }
+    else
+    {
+      t.segSteep[s] = 0;                      /* FlatLine :124-143 */
+      t.segK[s] = l.a / l.b;
+      t.segC[s] = l.c / l.b;
+      t.segLeftIfPositive[s] = dx > 0 ? 1 : 0;
+    }
+  }
+  auto isLeft = [&](int s, double x, double y)
+  {
+    const bool positive = t.segSteep[s] ? (x + y * t.segK[s] + t.segC[s] > 0) : (x * t.segK[s] + y + t.segC[s] > 0);
+    return t.segLeftIfPositive[s] ? positive : !positive;
+  };
+  const bool inside = isLeft(0, q[6], q[7]);
+  t.insideIsLeft = inside ? 1 : 0;
+  if(inside != isLeft(1, q[4], q[5]) || inside != isLeft(2, q[0], q[1]) || inside != isLeft(3, q[2], q[3]))
+  {
+    t.err = -1;
+    return;
+  }
+
+  double xs[4] = { q[0], q[2], q[4], q[6] }, ys[4] = { q[1], q[3], q[5], q[7] };
+  for(int i = 1; i < 4; i++)                 /* insertion sort of 4 */
+  {
+    const double vx = xs[i], vy = ys[i];
+    int k = i - 1;
+    while(k >= 0 && xs[k] > vx) { xs[k + 1] = xs[k]; k--; }
+    xs[k + 1] = vx;
+    k = i - 1;
+    while(k >= 0 && ys[k] > vy) { ys[k + 1] = ys[k]; k--; }
+    ys[k + 1] = vy;
+  }
+
+  int nRows = 0;
+  double rowUpper[3];
+  int nCells[3];
+  double cellUpper[3][3];
+  unsigned char cellMask[3][3], cellCnt[3][3], cellConst[3][3];
+  double lowerY = ys[0];
+  for(int yi = 1; yi < 4; yi++)
+  {
+    if(!(lowerY < ys[yi]))
+      continue;
+    const int r = nRows++;
+    rowUpper[r] = ys[yi];
+    nCells[r] = 0;
+    double lowerX = xs[0];
+    for(int xi = 1; xi < 4; xi++)
+    {
+      if(!(lowerX < xs[xi]))
+        continue;
+      const int c = nCells[r]++;
+      cellUpper[r][c] = xs[xi];
+      double cxLo, cxUp, cyLo, cyUp;
+      sector_init(lowerX, xs[xi], cxLo, cxUp);
+      sector_init(lowerY, ys[yi], cyLo, cyUp);
+      unsigned char mask = 0, cnt = 0;
+      bool nb[5] = { false, false, false, false, false };
+      for(int s = 0; s < 4; s++)
+      {
+        const bool xo = sector_overlaps(cxLo, cxUp, box[s].bxLo, box[s].bxUp);
+        const bool yo = sector_overlaps(cyLo, cyUp, box[s].byLo, box[s].byUp);
+        if(xo && yo)
+        {
+          mask |= static_cast<unsigned char>(1u << s);
+          cnt++;
+        }
+        if(cnt == 0)
+        {
+          /* BBox::getRelativePosition :93-110 */
+          int rel = 0;
+          const double mx = (cxLo + cxUp) / 2, my = (cyLo + cyUp) / 2;
+          if(yo && mx < box[s].bxLo) rel = 1;
+          else if(yo && mx > box[s].bxUp) rel = 2;
+          else if(xo && my < box[s].byLo) rel = 3;
+          else if(xo && my > box[s].byUp) rel = 4;
+          nb[rel] = true;
+        }
+      }
+      cellMask[r][c] = mask;
+      cellCnt[r][c] = cnt;
+      cellConst[r][c] = (nb[1] && nb[2] && nb[3] && nb[4]) ? 1 : 0;
+      lowerX = xs[xi];
+    }
+    lowerY = ys[yi];
+  }
+  if(nRows == 0) { t.err = -2; return; }
+  for(int r = 0; r < nRows; r++)
+  {
+    if(nCells[r] == 0) { t.err = -3; return; }
+    for(int c = 0; c < nCells[r]; c++)
+      if(cellCnt[r][c] > 2) { t.err = -4; return; }
+  }
+  /* merge equal neighbours (:377-394) */
+  for(int r = 0; r < nRows; r++)
+  {
+    int c = 0;
+    while(c + 1 < nCells[r])
+    {
+      const unsigned char cur = cellMask[r][c], nxt = cellMask[r][c + 1];
+      if(cur == 0 && nxt == 0) { t.err = -5; return; }
+      if(cellCnt[r][c] > 1 && cellCnt[r][c + 1] > 1) { t.err = -6; return; }
+      if(cur == nxt)
+      {
+        for(int k = c; k + 1 < nCells[r]; k++)
+        {
+          cellUpper[r][k] = cellUpper[r][k + 1];
+          cellMask[r][k] = cellMask[r][k + 1];
+          cellCnt[r][k] = cellCnt[r][k + 1];
+          cellConst[r][k] = cellConst[r][k + 1];
+        }
+        nCells[r]--;
+      }
+      else
+        c++;
+    }
+  }
+  t.nRows = static_cast<unsigned char>(nRows);
+  for(int r = 0; r < 3; r++)
+  {
+    t.nCells[r] = r < nRows ? static_cast<unsigned char>(nCells[r]) : 0;
+    for(int c = 0; c < 3; c++)
+    {
+      const bool live = r < nRows && c < nCells[r];
+      t.cellMask[r][c] = live ? cellMask[r][c] : 0;
+      t.cellConst[r][c] = live ? cellConst[r][c] : 0;
+    }
+    t.xTrans[r][0] = r < nRows && nCells[r] > 1 ? cellUpper[r][0] : 0.0;
+    t.xTrans[r][1] = r < nRows && nCells[r] > 2 ? cellUpper[r][1] : 0.0;
+  }
+  t.yTrans[0] = nRows > 1 ? rowUpper[0] : 0.0;
+  t.yTrans[1] = nRows > 2 ? rowUpper[1] : 0.0;
+
+  /* fast cell: the selectors put (x, y) into row r / cell c exactly when lower <= coordinate < upper
+   * (quadrilateralTest.cpp:487-571), first and last cells being bounded by the strict bounding box */
+  double bestArea = -1.0;
+  for(int r = 0; r < nRows; r++)
+  {
+    const double y0 = r == 0 ? nextafter(t.byLo, 1e300) : rowUpper[r - 1];
+    const double y1 = r == nRows - 1 ? t.byUp : rowUpper[r];
+    for(int c = 0; c < nCells[r]; c++)
+    {
+      if(cellMask[r][c] != 0 || cellConst[r][c] == 0)
+        continue;
+      const double x0 = c == 0 ? nextafter(t.bxLo, 1e300) : cellUpper[r][c - 1];
+      const double x1 = c == nCells[r] - 1 ? t.bxUp : cellUpper[r][c];
+      const double area = (x1 - x0) * (y1 - y0);
+      if(area > bestArea)
+      {
+        bestArea = area;
+        t.fx0 = x0; t.fx1 = x1; t.fy0 = y0; t.fy1 = y1;
+      }
+    }
+  }
+}
+
+/* QuadrilateralTest::isPointWithin (quadrilateralTest.cpp:445-451 and the selector lambdas :487-571) */
+__device__ __forceinline__ bool quad_test(const QuadTest &t, double x, double y)
+{
+  if(!(t.bxLo < x && x < t.bxUp && t.byLo < y && y < t.byUp))
+    return false;
+  int r = 0;
+  if(t.nRows > 1 && !(y < t.yTrans[0]))
+    r = (t.nRows == 2 || y < t.yTrans[1]) ? 1 : 2;
+  const int nc = t.nCells[r];
+  int c = 0;
+  if(nc > 1 && !(x < t.xTrans[r][0]))
+    c = (nc == 2 || x < t.xTrans[r][1]) ? 1 : 2;
+  unsigned int mask = t.cellMask[r][c];
+  if(mask == 0)
+    return t.cellConst[r][c] != 0;                     /* the large middle cell of a tread: no arithmetic */
+  const bool inside = t.insideIsLeft != 0;
+  bool ok = true;
+  while(mask)                                          /* at most two segments per cell (:370-372) */
+  {
+    const int s = __ffs(static_cast<int>(mask)) - 1;
+    mask &= mask - 1;
+    const double k = t.segK[s], cc = t.segC[s];
+    const bool positive = t.segSteep[s] ? (x + y * k + cc > 0) : (x * k + y + cc > 0);
+    const bool left = t.segLeftIfPositive[s] ? positive : !positive;
+    ok = ok && (left == inside);
+  }
+  return ok;
+}
+
+} // namespace ssd
+
+#endif /* SSD_QUADTEST_H_ */

@@ -12,7 +12,7 @@
 #ifndef SSD_SYNTH_H_
 #define SSD_SYNTH_H_
 
-#include "../../include/ssd_hip.h"
+#include "../../include/ssd_source.h"
 #include <hip/hip_runtime.h>
 
 namespace ssd

@@ -1,0 +1,211 @@
+/*
+ * ssd_testhooks.hip — libssd_testhooks.so: entry points that exist only so that tests can run pieces of the
+ * kernels in isolation (std::hypot and std::sort as restated for the device, QuadrilateralTest as the kernels build
+ * and evaluate it, a frame's raw device state).  C ABI in include/ssd_testhooks.h.  Not part of the product ABI.
+ */
+#include "ssd_handle.h"
+#include "ssd_math.h"
+#include "ssd_quadtest.h"
+#include "ssd_sort.h"
+#include "../../include/ssd_testhooks.h"
+
+#include <cstddef>
+#include <string>
+#include <vector>
+
+using namespace ssd;
+
+namespace
+{
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+  do                                                                                                    \
+  {                                                                                                     \
+    const hipError_t e_ = (expr);                                                                       \
+    if(e_ != hipSuccess)                                                                                \
+      return fail(SSD_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+  } while(0)
+
+int device_count()
+{
+  int n = 0;
+  if(hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+} // namespace
+
+namespace ssd
+{
+
+/* test hook: gnu_sort on the device */
+__global__ void k_sorttest(double *dist, int *idx, int n)
+{
+  if(blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    for(int i = 0; i < n; i++)
+      idx[i] = i;
+    gnu_sort(SortKeys{ dist, idx }, n);
+  }
+}
+
+/* test hook: QuadrilateralTest as the kernels build and evaluate it (build_quad_test + the constant cell + quad_test),
+ * one quadrilateral, n points; err = the negative code of the reference's throw or 0 */
+__global__ void k_quadtest(const double *__restrict__ quad, const double *__restrict__ pts, int n, unsigned char *__restrict__ inside,
+                           int *__restrict__ err)
+{
+  __shared__ QuadTest t;
+  if(threadIdx.x == 0)
+  {
+    double q[8];
+    for(int k = 0; k < 8; k++)
+      q[k] = quad[k];
+    QuadTest local;
+    build_quad_test(q, local);
+    t = local;
+    if(blockIdx.x == 0)
+      *err = local.err;
+  }
+  __syncthreads();
+  if(t.err)
+    return;
+  for(int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+  {
+    const double x = pts[2 * i], y = pts[2 * i + 1];
+    const bool fast = x >= t.fx0 && x < t.fx1 && y >= t.fy0 && y < t.fy1;
+    inside[i] = (fast || quad_test(t, x, y)) ? 1 : 0;
+  }
+}
+
+/* test hook: hypot_ref on the device */
+__global__ void k_hypot(const double *a, const double *b, double *out, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    out[i] = hypot_ref(a[i], b[i]);
+}
+
+} // namespace ssd
+
+extern "C"
+{
+
+const char *ssd_testhooks_last_error(void)
+{
+  return g_err.c_str();
+}
+
+
+/* hypot as the kernels compute it: on the host (no GPU needed) and on the device */
+double ssd_test_hypot_host(double a, double b)
+{
+  return hypot_ref(a, b);
+}
+long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, long long layout[8])
+{
+  if(!h || !out || frame < 0 || frame >= h->F)
+    return fail(SSD_E_ARG, "ssd_test_frame_state: bad argument");
+  if(layout)
+  {
+    layout[0] = sizeof(FrameState);
+    layout[1] = offsetof(FrameState, hist);
+    layout[2] = offsetof(FrameState, lut);
+    layout[3] = offsetof(FrameState, imgYMin);
+    layout[4] = offsetof(FrameState, pl);
+    layout[5] = offsetof(FrameState, qt);
+    layout[6] = offsetof(FrameState, sumZ);
+    layout[7] = offsetof(FrameState, cnt);
+  }
+  const size_t n = cap < sizeof(FrameState) ? cap : sizeof(FrameState);
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, h->dState + frame, n, hipMemcpyDeviceToHost));
+  return static_cast<long long>(n);
+}
+
+int ssd_test_sort_host(const double *dist, int n, int32_t *perm)
+{
+  if(!dist || !perm || n < 0 || n > 32768)
+    return fail(SSD_E_ARG, "ssd_test_sort_host: bad argument");
+  std::vector<double> d(dist, dist + n);
+  std::vector<int> idx(static_cast<size_t>(n));
+  for(int i = 0; i < n; i++)
+    idx[static_cast<size_t>(i)] = i;
+  gnu_sort(SortKeys{ d.data(), idx.data() }, n);
+  for(int i = 0; i < n; i++)
+    perm[i] = idx[static_cast<size_t>(i)];
+  return SSD_OK;
+}
+
+int ssd_test_sort_device(int device, const double *dist, int n, int32_t *perm)
+{
+  if(!dist || !perm || n < 1 || n > 32768)
+    return fail(SSD_E_ARG, "ssd_test_sort_device: bad argument");
+  if(device_count() <= 0)
+    return fail(SSD_E_NODEVICE, "ssd_test_sort_device: no HIP device");
+  HIP_TRY(hipSetDevice(device));
+  double *dd = nullptr;
+  int *di = nullptr;
+  HIP_TRY(hipMalloc(&dd, static_cast<size_t>(n) * sizeof(double)));
+  HIP_TRY(hipMalloc(&di, static_cast<size_t>(n) * sizeof(int)));
+  HIP_TRY(hipMemcpy(dd, dist, static_cast<size_t>(n) * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_sorttest, dim3(1), dim3(64), 0, nullptr, dd, di, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(perm, di, static_cast<size_t>(n) * sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(dd); (void)hipFree(di);
+  return SSD_OK;
+}
+
+int ssd_test_quad_device(int device, const double quad[8], const double *pts_xy, int n, uint8_t *inside, int *err)
+{
+  if(!quad || !pts_xy || !inside || !err || n < 1)
+    return fail(SSD_E_ARG, "ssd_test_quad_device: bad argument");
+  if(device_count() <= 0)
+    return fail(SSD_E_NODEVICE, "ssd_test_quad_device: no HIP device");
+  HIP_TRY(hipSetDevice(device));
+  double *dq = nullptr, *dp = nullptr;
+  unsigned char *di = nullptr;
+  int *de = nullptr;
+  HIP_TRY(hipMalloc(&dq, 8 * sizeof(double)));
+  HIP_TRY(hipMalloc(&dp, static_cast<size_t>(n) * 2 * sizeof(double)));
+  HIP_TRY(hipMalloc(&di, static_cast<size_t>(n)));
+  HIP_TRY(hipMalloc(&de, sizeof(int)));
+  HIP_TRY(hipMemcpy(dq, quad, 8 * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dp, pts_xy, static_cast<size_t>(n) * 2 * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(di, 0, static_cast<size_t>(n)));
+  hipLaunchKernelGGL(k_quadtest, dim3(n > 4096 ? 16 : 1), dim3(256), 0, nullptr, dq, dp, n, di, de);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(inside, di, static_cast<size_t>(n), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(err, de, sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(dq); (void)hipFree(dp); (void)hipFree(di); (void)hipFree(de);
+  return SSD_OK;
+}
+
+int ssd_test_hypot_device(int device, const double *a, const double *b, double *out, int n)
+{
+  if(device_count() <= 0)
+    return fail(SSD_E_NODEVICE, "ssd_test_hypot_device: no HIP device");
+  HIP_TRY(hipSetDevice(device));
+  double *da = nullptr, *db = nullptr, *dout = nullptr;
+  HIP_TRY(hipMalloc(&da, 8 * static_cast<size_t>(n)));
+  HIP_TRY(hipMalloc(&db, 8 * static_cast<size_t>(n)));
+  HIP_TRY(hipMalloc(&dout, 8 * static_cast<size_t>(n)));
+  HIP_TRY(hipMemcpy(da, a, 8 * static_cast<size_t>(n), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, b, 8 * static_cast<size_t>(n), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_hypot, dim3((n + 255) / 256), dim3(256), 0, nullptr, da, db, dout, n);
+  HIP_TRY(hipMemcpy(out, dout, 8 * static_cast<size_t>(n), hipMemcpyDeviceToHost));
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+  return SSD_OK;
+}
+
+
+} // extern "C"

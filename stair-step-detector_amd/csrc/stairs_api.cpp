@@ -1,5 +1,5 @@
 /* stairs_api.cpp — see stairs_api.h */
-#include "stairs_api.h"
+#include "../../include/stairs/stairs_api.h"
 #include <iostream>
 #include <stdexcept>
 
@@ -36,6 +36,44 @@ GeometricTransformation::GeometricTransformation(const RefPoints &w, const RefPo
   const double cp[9] = { c[0].x, c[0].y, c[0].z, c[1].x, c[1].y, c[1].z, c[2].x, c[2].y, c[2].z };
   if(ssd_calibration_from_points(wp, cp, &_cal) != SSD_OK)
     throw std::invalid_argument(ssd_last_error());
+}
+
+/* Transformation_<3>::transform (transformation.h:59-64): a * x + b, row sums left to right, then the translation */
+Point3 CameraToWorld::apply(double x, double y, double z) const
+{
+  const double *a = _camera.a, *b = _camera.b;
+  Point3 w;
+  w.x = (a[0] * x + a[1] * y) + a[2] * z;
+  w.y = (a[3] * x + a[4] * y) + a[5] * z;
+  w.z = (a[6] * x + a[7] * y) + a[8] * z;
+  w.x = w.x + b[0];
+  w.y = w.y + b[1];
+  w.z = w.z + b[2];
+  return w;
+}
+
+/* Transformation_<3>::transformInv (transformation.h:66-69): aInv * (x - b); for the camera transformation aInv is
+ * exactly the transpose of a (transformation.cpp:139-142) */
+Point3 WorldToCamera::operator()(const Point3 &p) const
+{
+  const double *a = _camera.a, *b = _camera.b;
+  const double dx = p.x - b[0], dy = p.y - b[1], dz = p.z - b[2];
+  Point3 c;
+  c.x = (a[0] * dx + a[3] * dy) + a[6] * dz;
+  c.y = (a[1] * dx + a[4] * dy) + a[7] * dz;
+  c.z = (a[2] * dx + a[5] * dy) + a[8] * dz;
+  return c;
+}
+
+/* ToExternalWorld::operator() (transformation.cpp:190-194): 2-D rotation + translation of (x, y); z = worldZ + p.z */
+Point3 ToExternalWorld::operator()(const Point3 &p) const
+{
+  const double *r = _world.r2, *t = _world.t2;
+  double ex = r[0] * p.x + r[1] * p.y;
+  double ey = r[2] * p.x + r[3] * p.y;
+  ex = ex + t[0];
+  ey = ey + t[1];
+  return Point3{ ex, ey, _world.world_z + p.z };
 }
 
 GeometricTransformation GeometricCalibration::load()

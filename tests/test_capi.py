@@ -14,25 +14,37 @@ import scenes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_library_exports_every_declared_symbol(ssd):
-    header = open(os.path.join(ROOT, "include", "ssd_hip.h")).read()
+def _declared(header_name):
+    header = open(os.path.join(ROOT, "include", header_name)).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    declared = set(re.findall(r"\b(ssd_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) >= 25
-    L = ssd.lib()
-    missing = [s for s in sorted(declared) if not hasattr(L, s)]
-    assert not missing, missing
-    assert set(ssd.EXPORTS) <= declared
+    return set(re.findall(r"\b(ssd_[a-z0-9_]+)\s*\(", header))
+
+
+def test_library_exports_every_declared_symbol(ssd):
+    """each of the three libraries exports exactly what its header declares — and the product library nothing of the
+    frame source or the test hooks (they are not part of the product ABI)"""
+    import subprocess
+    for header, L, names, path in (("ssd_hip.h", ssd.lib(), ssd.EXPORTS, ssd.LIB_PATH),
+                                   ("ssd_source.h", ssd.source_lib(), ssd.SOURCE_EXPORTS, ssd.SOURCE_LIB_PATH),
+                                   ("ssd_testhooks.h", ssd.hooks_lib(), ssd.HOOK_EXPORTS, ssd.HOOKS_LIB_PATH)):
+        declared = _declared(header)
+        missing = [s for s in sorted(declared) if not hasattr(L, s)]
+        assert not missing, (header, missing)
+        assert set(names) == declared, (header, sorted(set(names) ^ declared))
+        exported = set(re.findall(r" T (ssd_[a-z0-9_]+)", subprocess.run(["nm", "-D", "--defined-only", path], check=True,
+                                                                          capture_output=True, text=True).stdout))
+        assert exported == declared, (header, sorted(exported ^ declared))
+    assert len(_declared("ssd_hip.h")) >= 25
+    assert not [n for n in _declared("ssd_hip.h") if n.startswith("ssd_test_") or n.startswith("ssd_synth_")]
 
 
 def test_header_is_plain_c_and_links(ssd, tmp_path):
     """include/ssd_hip.h must be consumable from C (cgo / JNI / ctypes-style bindings): a C99 translation unit that
     includes it, takes the address of every declared entry point and links against libssd_hip.so."""
     import subprocess
-    header = open(os.path.join(ROOT, "include", "ssd_hip.h")).read()
-    names = sorted(set(re.findall(r"\b(ssd_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", header, flags=re.S))))
+    names = sorted(_declared("ssd_hip.h") | _declared("ssd_source.h") | _declared("ssd_testhooks.h"))
     src = tmp_path / "use_header.c"
-    src.write_text('#include "ssd_hip.h"\n#include <stdio.h>\ntypedef void (*fn)(void);\nint main(void)\n{\n  const fn f[] = { %s };\n'
+    src.write_text('#include "ssd_hip.h"\n#include "ssd_source.h"\n#include "ssd_testhooks.h"\n#include <stdio.h>\ntypedef void (*fn)(void);\nint main(void)\n{\n  const fn f[] = { %s };\n'
                    '  ssd_config cfg; ssd_frame_result r; ssd_frame_risers rr; (void)r; (void)rr;\n'
                    '  if(ssd_default_config(&cfg, 640, 480) != SSD_OK) return 1;\n'
                    '  printf("%%d %%d\\n", (int)(sizeof f / sizeof f[0]), cfg.width);\n  return 0;\n}\n'
@@ -40,7 +52,7 @@ def test_header_is_plain_c_and_links(ssd, tmp_path):
     exe = tmp_path / "use_header"
     libdir = os.path.dirname(ssd.LIB_PATH)
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
-                    "-L", libdir, "-lssd_hip", "-Wl,-rpath," + libdir], check=True)
+                    "-L", libdir, "-lssd_hip", "-lssd_source", "-lssd_testhooks", "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert int(out[0]) == len(names) and out[1] == "640"
 
@@ -146,6 +158,53 @@ def test_serialize_cabi_matches_oracle_and_reference_goldens(ssd, oracle):
     fr = ssd.FrameResult()
     fr.status = ssd.ST_THROW
     assert ssd.Stairs(fr).serialize() == ""
+
+
+def test_serialize_prints_every_digit_and_ignores_the_c_locale(ssd, oracle):
+    """ostream << fixed << setprecision(3) prints all 309 integral digits of DBL_MAX and never a decimal comma; so must
+    ssd_serialize (it used snprintf into 64 bytes).  Against the oracle's ostream; against the real stairs.cpp where
+    oracle/_ref is present."""
+    import locale
+    vals = [0.17, -0.0001, 1e60, -1e300, 1.7976931348623157e308, float("inf"), float("-inf"), float("nan"), 0.0005, 0.0015, -0.0]
+    ref = ob.load_ref()
+    old = locale.setlocale(locale.LC_NUMERIC)
+    for loc in (None, "de_DE.UTF-8", "de_DE", "fr_FR.UTF-8"):
+        if loc is not None:
+            try:
+                locale.setlocale(locale.LC_NUMERIC, loc)
+            except locale.Error:
+                continue
+        for v in vals:
+            r = ssd.FrameResult()
+            r.n_steps = 1
+            r.steps[0].height = v
+            r.steps[0].quad[0] = -v
+            buf = C.create_string_buffer(1 << 13)
+            n = ssd.lib().ssd_serialize(C.byref(r), buf, len(buf))
+            steps = np.zeros((1, 9))
+            steps[0, 0], steps[0, 1] = v, -v
+            assert n == len(buf.value) and buf.value.decode() == oracle.serialize(steps), (loc, v)
+            if ref is not None:
+                assert buf.value.decode() == ref.serialize(steps), (loc, v)
+            assert b"," + b"0" * 3 not in buf.value.split(b"[")[-1][:3]
+    locale.setlocale(locale.LC_NUMERIC, old)
+    small = C.create_string_buffer(64)
+    r = ssd.FrameResult()
+    r.n_steps = 1
+    r.steps[0].height = 1e300
+    assert ssd.lib().ssd_serialize(C.byref(r), small, len(small)) == -5          # SSD_E_CAP, never a truncated line
+
+
+def test_create_rejects_ranges_the_fixed_point_mean_cannot_hold(ssd):
+    """the mean height is a sum of round(z * 2^40) in int64 via a magic-constant add: |z| < 2048 m and
+    max|z| * W * H < 2^23; such a configuration must be refused, not answered wrongly"""
+    cal = ssd.GeometricTransformation().constants
+    for zmin, zmax, w, h in ((-0.1, 2500.0, 640, 480), (-3000.0, 1.0, 640, 480), (-0.1, 10.0, 1920, 1080)):
+        cfg = ssd.default_config(w, h)
+        cfg.z_min, cfg.z_max, cfg.height_interval = zmin, zmax, (zmax - zmin) / 100.0
+        hnd = C.c_void_p()
+        assert ssd.lib().ssd_create(C.byref(cfg), C.byref(cal), 0, C.byref(hnd)) == -1, (zmin, zmax, w, h)
+        assert b"2^23" in ssd.lib().ssd_last_error()
 
 
 def test_wire_format_parses_like_the_ros_node(ssd, oracle):

@@ -1,0 +1,116 @@
+"""BASELINE.json configurations at their full sizes, and the N > 1 launch of bench.py, on the one GPU of the box."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import parity
+import scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _state_counts(ssd, det, frame):
+    raw, lay = det.frame_state(frame)
+    hist = np.frombuffer(raw, dtype=np.uint32, count=ssd.MAX_BINS, offset=lay["hist"])
+    n_nonzero, n_inrange = np.frombuffer(raw, dtype=np.uint32, count=2, offset=lay["hist"] + 4 * ssd.MAX_BINS)
+    return hist, int(n_nonzero), int(n_inrange)
+
+
+def test_config3_full_batch(ssd, oracle, gpu_device):
+    """BASELINE configs[2] (SURVEY.md section 8(d) "config 3") at its full size: 1024 XGA frames resident in HBM (9.66 GB),
+    one batch (grid.x = 1024, ~25 k blocks per streaming kernel).  Every 64th frame against the oracle; the second run
+    bitwise equal (workspace left clean by 1024 frames' worth of consumers); histogram mass = in-range count <= non-zero
+    count <= W H for all 1024 frames."""
+    n, W, H = 1024, 1024, 768
+    sc_list = scenes.batch_scenes(ssd, W, H, n, base_seed=100000, rng_seed=1000)      # the frames bench.py times on rank 0
+    trans = ssd.transformation_for_scene(sc_list[0])
+    cfg = ssd.default_config(W, H, max_frames_per_batch=n)
+    buf = ssd.DeviceBuffer(W * H * 12 * n, gpu_device)
+    ssd.synth_device(sc_list, buf.ptr, device=gpu_device)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    det.enqueue(buf.ptr, n)
+    r1 = det.fetch_list(n)
+    for i in range(n):
+        hist, n_nonzero, n_inrange = _state_counts(ssd, det, i)
+        assert int(hist.sum()) == n_inrange <= n_nonzero <= W * H, "frame %d" % i
+        assert n_inrange > W * H // 4, "frame %d: implausibly few points in range" % i
+    det.enqueue(buf.ptr, n)
+    r2 = det.fetch_list(n)
+    assert [bytes(x) for x in r1] == [bytes(x) for x in r2]
+    rep = {}
+    for i in range(0, n, 64):
+        parity.check_results_only(ssd, oracle, cfg, trans.constants, ssd.synth_host([sc_list[i]])[0], r1[i], rep)
+    assert rep.get("max_corner_err", 0.0) == 0.0 and rep.get("max_height_err", 0.0) <= parity.TOL_HEIGHT
+    assert sum(1 for r in r1 if r.n_steps >= 3) >= n * 9 // 10
+    det.close()
+    buf.free()
+
+
+def test_config5_batch(ssd, oracle, gpu_device):
+    """BASELINE configs[4] (SURVEY.md "config 5"): a batch of 64 FHD stress frames (8 noisy steps, 5 % outliers) in HBM; every
+    16th frame against the oracle, second run bitwise equal, histogram mass = in-range count."""
+    n, W, H = 64, 1920, 1080
+    sc_list = scenes.fhd_stress_scenes(ssd, n, base_seed=9000)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    cfg = ssd.default_config(W, H, max_frames_per_batch=n)
+    buf = ssd.DeviceBuffer(W * H * 12 * n, gpu_device)
+    ssd.synth_device(sc_list, buf.ptr, device=gpu_device)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    det.enqueue(buf.ptr, n)
+    r1 = det.fetch_list(n)
+    for i in range(n):
+        hist, n_nonzero, n_inrange = _state_counts(ssd, det, i)
+        assert int(hist.sum()) == n_inrange <= n_nonzero <= W * H
+    det.enqueue(buf.ptr, n)
+    r2 = det.fetch_list(n)
+    assert [bytes(x) for x in r1] == [bytes(x) for x in r2]
+    rep = {}
+    for i in range(0, n, 16):
+        parity.check_results_only(ssd, oracle, cfg, trans.constants, ssd.synth_host([sc_list[i]])[0], r1[i], rep)
+    assert rep.get("max_corner_err", 0.0) == 0.0 and rep.get("max_height_err", 0.0) <= parity.TOL_HEIGHT
+    assert all(5 <= r.n_steps <= 9 for r in r1)      # the reference reports fewer than the 8 built steps (SURVEY.md 8(a) probe note)
+    det.close()
+    buf.free()
+
+
+def test_bench_runs_two_ranks_on_this_gpu():
+    """`python bench.py --gpus 2` launches its own two ranks (torch.distributed.run, gloo); SSD_BENCH_DEVICE=0 lets both
+    use the one GPU of this box.  The line must say n_gpus 2, the shards must be disjoint contiguous frame ranges, and
+    each rank must have checked frames of ITS shard against the oracle."""
+    env = dict(os.environ, SSD_BENCH_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "64", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_gpu_per_step"] == 64
+    assert "configs[3]" in d["config"]["workload"]
+    ranks = sorted(d["ranks"], key=lambda r: r["rank"])
+    assert [r["rank"] for r in ranks] == [0, 1] and [r["device"] for r in ranks] == [0, 0]
+    assert ranks[0]["frames"] == [0, 64] and ranks[1]["frames"] == [64, 128]
+    for r in ranks:
+        assert r["parity"]["frames_checked_against_oracle"] == 5
+        assert r["parity"]["max_abs_corner_err_m"] == 0.0 and r["parity"]["max_abs_height_err_m"] <= parity.TOL_HEIGHT
+        assert r["steps_found"] > 0
+    assert d["value"] == pytest.approx(2 * 64 * 2 / (d["ms_per_step"] * 2 * 1e-3), rel=1e-6)
+    assert "cpu_baseline" not in d                      # reported at N = 1 only
+
+
+def test_bench_refuses_two_ranks_without_two_gpus():
+    """without the override, 2 ranks on a 1-GPU box must fail loudly instead of printing a line"""
+    import importlib
+    ssd = importlib.import_module("stair-step-detector_amd")
+    if ssd.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SSD_BENCH_DEVICE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "8", "--steps", "1", "--warmup", "0", "--no-cpu"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode != 0 and "n_gpus" not in p.stdout

@@ -240,7 +240,7 @@ def test_product_hypot_equals_libm_on_this_image(ssd, oracle):
     """The oracle calls the host's std::hypot as the reference does; the kernels restate the glibc 2.35
     algorithm (the same function, ssd_test_hypot_host, compiled for the host).  They must agree here."""
     rng = np.random.default_rng(16)
-    L = ssd.lib()
+    L = ssd.hooks_lib()
     vals = []
     for a in range(-60, 61, 7):
         for b in range(-1100, 1101, 13):
