@@ -118,6 +118,41 @@ class Ranks:
             dist.destroy_process_group()
 
 
+def host_fed_leg(ssd, scenes, n_frames=256, reps=3, device=0):
+    """PCIe-inclusive rates of ssd_process_host / ssd_process_depth_host (frames in HOST memory; double-buffered ingest:
+    the copy of a slice overlaps the kernels of the one before) — the deployment a camera implies.  Reported beside the
+    HBM-resident `value`, never as it.  XGA frames; float3 vertices and 16-bit depth; pinned and pageable sources."""
+    import numpy as np
+    W, H = 1024, 768
+    sc = scenes.batch_scenes(ssd, W, H, n_frames, base_seed=4242)
+    trans = ssd.transformation_for_scene(sc[0])
+    det = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=64), trans, device)
+    det.set_intrinsics(ssd.intrinsics_for_scene(sc[0]))
+    out = {"frames": n_frames, "width": W, "height": H}
+    dev = ssd.DeviceBuffer(W * H * 12 * n_frames, device)
+    for kind, item, shape, dtype in (("float3", 12, (n_frames, H, W, 3), np.float32), ("depth16", 2, (n_frames, H, W), np.uint16)):
+        if kind == "float3":
+            ssd.synth_device(sc, dev.ptr, device=device)
+        else:
+            ssd.synth_depth_device(sc, dev.ptr, device=device)
+        pinned = ssd.PinnedArray(shape, dtype)
+        pinned.array[...] = dev.download(W * H * item * n_frames, dtype=dtype).reshape(shape)
+        pageable = np.array(pinned.array)
+        run = det.process_host if kind == "float3" else det.process_depth_host
+        for name, arr in (("pinned", pinned.array), ("pageable", pageable)):
+            run(arr)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                res = run(arr)
+            dt = (time.perf_counter() - t0) / reps
+            out["%s_%s" % (kind, name)] = {"frames_per_s": n_frames / dt, "host_to_device_GBps": n_frames * W * H * item / dt / 1e9,
+                                          "stairs_found": int(sum(1 for r in res if r.n_steps >= 3))}
+        pinned.free()
+    dev.free()
+    det.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +165,7 @@ def main():
     ap.add_argument("--input", choices=["float3", "depth16"], default="float3",
                     help="float3 = xyz vertices (the metric's input); depth16 = 16-bit depth frames deprojected on the fly (SURVEY 8f rank 1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-hostfed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg reported beside `value`")
     ap.add_argument("--risers", action="store_true",
                     help="also gather the evidence of the vertical faces (extension beyond the reference, SURVEY 8f rank 4); off for the metric")
     args = ap.parse_args()
@@ -319,6 +355,13 @@ def main():
                                                  "sample": "%d frames (%d distinct), one frame per thread, %.1f s wall" % (len(work), len(keep), adt)}
             out["parity"] = {"frames_checked_against_oracle": checked, "max_abs_height_err_m": rep.get("max_height_err", 0.0),
                              "max_abs_corner_err_m": rep.get("max_corner_err", 0.0), "bar_m": 1e-4}
+        if world == 1 and not args.no_hostfed and not fhd:
+            det.close()
+            del frames
+            torch.cuda.empty_cache()
+            out["host_fed"] = host_fed_leg(ssd, scenes, device=device)
+            out["host_fed"]["note"] = ("frames in host memory through ssd_process_host / ssd_process_depth_host (PCIe-inclusive, "
+                                       "double-buffered ingest); NOT the metric `value`, which is measured on frames resident in HBM")
         print(json.dumps(out), flush=True)
 
     det.close()

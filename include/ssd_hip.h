@@ -121,7 +121,10 @@ size_t ssd_workspace_bytes(const ssd_handle *h);
 
 /* ---- processing ------------------------------------------------------------
  * A frame is width*height points, AoS float x,y,z (rs2::vertex layout), row-major, invalid = (0,0,0).
- * ssd_process_host:   frames in host memory, contiguous; copies to the device, runs, fills results[n].
+ * ssd_process_host:   frames in host memory, contiguous; fills results[n].  Double-buffered: the batch is cut into slices
+ *                     of up to 32 frames, the host-to-device copy of a slice overlaps the kernels of the one before.
+ *                     Memory from ssd_host_alloc (pinned) is copied by DMA directly; pageable memory goes through the
+ *                     runtime's staging.  PCIe-bound either way (9.4 MB per XGA frame, 1.6 MB as 16-bit depth).
  * ssd_enqueue:        frames already in device memory (frame i at d_xyz + i*frame_stride_bytes); enqueues the
  *                     whole pipeline on `stream` (a hipStream_t, NULL = default stream) and returns without
  *                     synchronising. nframes <= max_frames_per_batch.
@@ -268,6 +271,10 @@ int ssd_get_debug(ssd_handle *h, int frame, ssd_debug_frame *out);
  * reference's cv::Mat.  step_slot = index among the step plateaus, or -1 for the ground image.
  * Only valid when debug capture was enabled for the batch. */
 int ssd_get_debug_image(ssd_handle *h, int frame, int step_slot, int closed, uint8_t *out);
+
+/* pinned (page-locked) host memory for frames handed to ssd_process_host / ssd_process_depth_host */
+int ssd_host_alloc(size_t bytes, void **ptr);
+int ssd_host_free(void *ptr);
 
 /* plain device-memory helpers so that hosts without a HIP binding can stage frames */
 int ssd_device_count(void);

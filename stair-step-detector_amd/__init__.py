@@ -129,7 +129,7 @@ EXPORTS = [
     "ssd_fetch_back", "ssd_set_risers", "ssd_fetch_risers", "ssd_set_timing", "ssd_get_stage_times", "ssd_get_stage_times_back", "ssd_serialize",
     "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
     "ssd_device_count", "ssd_device_alloc", "ssd_device_free", "ssd_device_upload", "ssd_device_download",
-    "ssd_device_sync",
+    "ssd_device_sync", "ssd_host_alloc", "ssd_host_free",
 ]
 # libssd_source.so — the frame source standing in for the camera (include/ssd_source.h)
 SOURCE_EXPORTS = [
@@ -192,6 +192,8 @@ def lib():
     L.ssd_device_upload.argtypes = [i32, vp, vp, sz]
     L.ssd_device_download.argtypes = [i32, vp, vp, sz]
     L.ssd_device_sync.argtypes = [i32]
+    L.ssd_host_alloc.argtypes = [sz, C.POINTER(vp)]
+    L.ssd_host_free.argtypes = [vp]
     _lib = L
     return L
 
@@ -565,6 +567,29 @@ def calibration_points(scene, marks=CALIBRATION_MARKS, world_offset=(0.0, 0.0, 0
 def transformation_for_scene(scene):
     world, cam = calibration_points(scene)
     return GeometricTransformation(world, cam)
+
+
+class PinnedArray:
+    """A numpy array over page-locked host memory (ssd_host_alloc): ssd_process_host copies it by DMA without staging."""
+
+    def __init__(self, shape, dtype):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        _check(lib().ssd_host_alloc(self.nbytes, C.byref(p)))
+        self.ptr = p.value
+        self.array = np.frombuffer((C.c_uint8 * self.nbytes).from_address(self.ptr), dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().ssd_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class DeviceBuffer:

@@ -425,7 +425,14 @@ int ssd_destroy(ssd_handle *h)
   for(hipEvent_t e : h->resultsReady)
     if(e) (void)hipEventDestroy(e);
   if(h->lastDone) (void)hipEventDestroy(h->lastDone);
-  if(h->dFrames) (void)hipFree(h->dFrames);
+  for(int k = 0; k < 2; k++)
+  {
+    if(h->ingestBuf[k]) (void)hipFree(h->ingestBuf[k]);
+    if(h->ingestCopied[k]) (void)hipEventDestroy(h->ingestCopied[k]);
+    if(h->ingestConsumed[k]) (void)hipEventDestroy(h->ingestConsumed[k]);
+  }
+  if(h->ingestCopy) (void)hipStreamDestroy(h->ingestCopy);
+  if(h->ingestCompute) (void)hipStreamDestroy(h->ingestCompute);
   if(h->dRisers) (void)hipFree(h->dRisers);
   if(h->hRisers) (void)hipHostFree(h->hRisers);
   if(h->dDebug) (void)hipFree(h->dDebug);
@@ -588,6 +595,17 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   const DepthSrc depthSrc{ h->dDepthMaps, h->dDepthMaps ? h->dDepthMaps + P.W : nullptr, h->intr.depth_units, P.W, P.H };
   const DepthSrc *depth = depthInput ? &depthSrc : nullptr;
   const int chunk = choose_chunk(P.nPoints, nframes);
+  /* K2 walks cell columns: the taller its chunks the fewer window flushes — as long as the launch keeps >= 4096 blocks */
+  int chunkRaster = chunk;
+  {
+    int tiles = env_int("SSD_K2_CHUNK_TILES", 32);
+    if(tiles > kMaxTilesPerBlockRasterHost) tiles = kMaxTilesPerBlockRasterHost;
+    const long long totalTiles = (static_cast<long long>(P.nPoints) + kTileHost - 1) / kTileHost * nframes;
+    while(tiles > chunk / kTileHost && totalTiles / tiles < 4096)
+      tiles /= 2;
+    if(tiles * kTileHost > chunkRaster)
+      chunkRaster = tiles * kTileHost;
+  }
   DebugFrame *dbg = h->debug ? h->dDebug : nullptr;
   unsigned long long *dbgImg = h->debug ? h->dDebugImg : nullptr;
   const bool timing = h->timing && !h->ev.empty();
@@ -614,7 +632,7 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
     launch_peaks(P, h->dState, nframes, dbg, s);
   mark();
   if(stages & SSD_STAGE_RASTER)
-    launch_raster(xyz, strideFloats, P, h->dState, h->dStepImg, h->dTileMasks, h->tileMaskStride, nframes, chunk, depth, s);
+    launch_raster(xyz, strideFloats, P, h->dState, h->dStepImg, h->dTileMasks, h->tileMaskStride, nframes, chunkRaster, depth, s);
   mark();
   if(stages & SSD_STAGE_OUTLINE)
     launch_outline(P, h->dState, h->dStepImg, nframes, dbg, dbgImg, s);
@@ -712,37 +730,6 @@ int ssd_deproject_host(const ssd_intrinsics *intr, int width, int height, const 
   return SSD_OK;
 }
 
-int ssd_process_depth_host(ssd_handle *h, const uint16_t *depth, int nframes, ssd_frame_result *results)
-{
-  if(!h || !depth || !results || nframes < 1)
-    return fail(SSD_E_ARG, "ssd_process_depth_host: bad argument");
-  HIP_TRY(hipSetDevice(h->device));
-  const size_t frameElems = (static_cast<size_t>(h->P.nPoints) + 3) / 4 * 4;       /* stride kept a multiple of 8 bytes */
-  const size_t needFloats = (static_cast<size_t>(nframes < h->F ? nframes : h->F) * frameElems * 2 + 3) / 4;
-  const size_t frameFloats = static_cast<size_t>(h->P.nPoints) * 3;
-  if(h->dFramesCap * frameFloats < needFloats)
-  {
-    if(h->dFrames) (void)hipFree(h->dFrames);
-    h->dFrames = nullptr;
-    h->dFramesCap = 0;
-    const size_t frames = (needFloats + frameFloats - 1) / frameFloats;
-    HIP_TRY(hipMalloc(&h->dFrames, frames * frameFloats * 4));
-    h->dFramesCap = frames;
-  }
-  for(int done = 0; done < nframes; )
-  {
-    const int n = nframes - done < h->F ? nframes - done : h->F;
-    HIP_TRY(hipMemcpy2DAsync(h->dFrames, frameElems * 2, depth + static_cast<size_t>(done) * h->P.nPoints, static_cast<size_t>(h->P.nPoints) * 2,
-                             static_cast<size_t>(h->P.nPoints) * 2, n, hipMemcpyHostToDevice, nullptr));
-    int rc = ssd_enqueue_depth(h, h->dFrames, frameElems * 2, n, nullptr);
-    if(rc) return rc;
-    rc = ssd_fetch(h, results + done, n, nullptr);
-    if(rc) return rc;
-    done += n;
-  }
-  return SSD_OK;
-}
-
 /* milliseconds of the 7 stages of a timed enqueue; `back` = 0 is the last one, 1 the one before, ...
  * (at most SSD_TIMING_SLOTS - 1 back, and not before timing was switched on); waits for that enqueue */
 int ssd_get_stage_times_back(ssd_handle *h, int back, float ms[7])
@@ -786,32 +773,117 @@ int ssd_fetch(ssd_handle *h, ssd_frame_result *results, int nframes, void *strea
   return ssd_fetch_back(h, results, nframes, 0);
 }
 
+/* ---- frames in host memory: double-buffered ingest ----------------------------------------------------------------
+ * A camera-fed product is host-fed: frames arrive in host memory and cross PCIe once (9.4 MB per XGA vertex frame,
+ * 1.6 MB as 16-bit depth).  The batch is cut into slices of at most kIngestFrames frames; slice c + 1 is copied into the
+ * other of two device staging buffers on a copy stream while the kernels of slice c run on a compute stream, and the
+ * results of slice c - 1 are read (they travelled with their enqueue).  Source memory obtained from ssd_host_alloc is
+ * pinned: its copies are true DMA; pageable memory goes through the runtime's own staging (the call then blocks in
+ * the copy while the GPU computes the previous slice). */
+static const int kIngestFrames = 32;
+
+static int ingest_prepare(ssd_handle *h, size_t sliceBytes)
+{
+  if(!h->ingestCopy)
+  {
+    HIP_TRY(hipStreamCreateWithFlags(&h->ingestCopy, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&h->ingestCompute, hipStreamNonBlocking));
+    for(int k = 0; k < 2; k++)
+    {
+      HIP_TRY(hipEventCreateWithFlags(&h->ingestCopied[k], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&h->ingestConsumed[k], hipEventDisableTiming));
+    }
+  }
+  if(h->ingestCap < sliceBytes)
+  {
+    HIP_TRY(hipDeviceSynchronize());
+    for(int k = 0; k < 2; k++)
+    {
+      if(h->ingestBuf[k]) (void)hipFree(h->ingestBuf[k]);
+      h->ingestBuf[k] = nullptr;
+    }
+    h->ingestCap = 0;
+    HIP_TRY(hipMalloc(&h->ingestBuf[0], sliceBytes));
+    HIP_TRY(hipMalloc(&h->ingestBuf[1], sliceBytes));
+    h->ingestCap = sliceBytes;
+  }
+  return SSD_OK;
+}
+
+static int process_host_impl(ssd_handle *h, const void *src, size_t srcFrameBytes, size_t devFrameBytes, int nframes,
+                             ssd_frame_result *results, bool depthInput)
+{
+  HIP_TRY(hipSetDevice(h->device));
+  const int slice = h->F < kIngestFrames ? h->F : kIngestFrames;
+  int rc = ingest_prepare(h, static_cast<size_t>(slice) * devFrameBytes);
+  if(rc) return rc;
+  const unsigned char *from = static_cast<const unsigned char *>(src);
+  int prevFrames = 0, prevAt = 0, c = 0;
+  for(int done = 0; done < nframes; c++)
+  {
+    const int n = nframes - done < slice ? nframes - done : slice;
+    const int k = c & 1;
+    if(c >= 2)
+      HIP_TRY(hipStreamWaitEvent(h->ingestCopy, h->ingestConsumed[k], 0));        /* the kernels of slice c - 2 read this buffer */
+    if(srcFrameBytes == devFrameBytes)
+      HIP_TRY(hipMemcpyAsync(h->ingestBuf[k], from + static_cast<size_t>(done) * srcFrameBytes, static_cast<size_t>(n) * srcFrameBytes,
+                             hipMemcpyHostToDevice, h->ingestCopy));
+    else
+      HIP_TRY(hipMemcpy2DAsync(h->ingestBuf[k], devFrameBytes, from + static_cast<size_t>(done) * srcFrameBytes, srcFrameBytes, srcFrameBytes, n,
+                               hipMemcpyHostToDevice, h->ingestCopy));
+    HIP_TRY(hipEventRecord(h->ingestCopied[k], h->ingestCopy));
+    HIP_TRY(hipStreamWaitEvent(h->ingestCompute, h->ingestCopied[k], 0));
+    rc = enqueue_impl(h, h->ingestBuf[k], devFrameBytes, n, h->ingestCompute, SSD_STAGE_ALL, depthInput);
+    if(rc) return rc;
+    HIP_TRY(hipEventRecord(h->ingestConsumed[k], h->ingestCompute));
+    if(prevFrames)
+    {
+      rc = ssd_fetch_back(h, results + prevAt, prevFrames, 1);
+      if(rc) return rc;
+    }
+    prevFrames = n;
+    prevAt = done;
+    done += n;
+  }
+  return ssd_fetch_back(h, results + prevAt, prevFrames, 0);
+}
+
 int ssd_process_host(ssd_handle *h, const float *xyz, int nframes, ssd_frame_result *results)
 {
   if(!h || !xyz || !results || nframes < 1)
     return fail(SSD_E_ARG, "ssd_process_host: bad argument");
-  HIP_TRY(hipSetDevice(h->device));
-  const size_t frameFloats = static_cast<size_t>(h->P.nPoints) * 3;
-  const size_t need = static_cast<size_t>(nframes < h->F ? nframes : h->F);
-  if(h->dFramesCap < need)
-  {
-    if(h->dFrames) (void)hipFree(h->dFrames);
-    h->dFrames = nullptr;
-    h->dFramesCap = 0;
-    HIP_TRY(hipMalloc(&h->dFrames, need * frameFloats * 4));
-    h->dFramesCap = need;
-  }
-  for(int done = 0; done < nframes; )
-  {
-    const int n = nframes - done < h->F ? nframes - done : h->F;
-    HIP_TRY(hipMemcpyAsync(h->dFrames, xyz + static_cast<size_t>(done) * frameFloats, static_cast<size_t>(n) * frameFloats * 4,
-                           hipMemcpyHostToDevice, nullptr));
-    int rc = ssd_enqueue(h, h->dFrames, frameFloats * 4, n, nullptr);
-    if(rc) return rc;
-    rc = ssd_fetch(h, results + done, n, nullptr);
-    if(rc) return rc;
-    done += n;
-  }
+  const size_t frameBytes = static_cast<size_t>(h->P.nPoints) * 12;
+  return process_host_impl(h, xyz, frameBytes, frameBytes, nframes, results, false);
+}
+
+int ssd_process_depth_host(ssd_handle *h, const uint16_t *depth, int nframes, ssd_frame_result *results)
+{
+  if(!h || !depth || !results || nframes < 1)
+    return fail(SSD_E_ARG, "ssd_process_depth_host: bad argument");
+  if(!h->haveIntr)
+    return fail(SSD_E_ARG, "ssd_process_depth_host: call ssd_set_intrinsics first");
+  const size_t frameElems = (static_cast<size_t>(h->P.nPoints) + 3) / 4 * 4;       /* device stride kept a multiple of 8 bytes */
+  return process_host_impl(h, depth, static_cast<size_t>(h->P.nPoints) * 2, frameElems * 2, nframes, results, true);
+}
+
+/* pinned host memory for frames (DMA without a staging copy) */
+int ssd_host_alloc(size_t bytes, void **ptr)
+{
+  if(!ptr || bytes == 0)
+    return fail(SSD_E_ARG, "ssd_host_alloc: bad argument");
+  if(ssd_device_count() <= 0)
+    return fail(SSD_E_NODEVICE, "ssd_host_alloc: no HIP device");
+  *ptr = nullptr;
+  const hipError_t e = hipHostMalloc(ptr, bytes, hipHostMallocDefault);
+  if(e != hipSuccess)
+    return fail(e == hipErrorOutOfMemory ? SSD_E_NOMEM : SSD_E_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+  return SSD_OK;
+}
+
+int ssd_host_free(void *ptr)
+{
+  if(ptr)
+    HIP_TRY(hipHostFree(ptr));
   return SSD_OK;
 }
 

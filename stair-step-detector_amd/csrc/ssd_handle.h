@@ -37,8 +37,11 @@ struct ssd_handle
   bool haveLast = false;
   ssd_frame_risers *dRisers = nullptr;      /* vertical faces (extension), allocated by ssd_set_risers */
   ssd_frame_risers *hRisers = nullptr;      /* pinned */
-  float *dFrames = nullptr;                 /* staging for ssd_process_host */
-  size_t dFramesCap = 0;                    /* frames */
+  /* ssd_process_host / ssd_process_depth_host: two device staging buffers, a copy and a compute stream (ssd_capi.hip) */
+  void *ingestBuf[2] = { nullptr, nullptr };
+  size_t ingestCap = 0;                     /* bytes per buffer */
+  hipStream_t ingestCopy = nullptr, ingestCompute = nullptr;
+  hipEvent_t ingestCopied[2] = { nullptr, nullptr }, ingestConsumed[2] = { nullptr, nullptr };
   ssd::DebugFrame *dDebug = nullptr;
   unsigned long long *dDebugImg = nullptr;
   bool debug = false;

@@ -177,8 +177,14 @@ constexpr int kBinsPerGroup = 4;      /* 128 bins -> 32 groups: one 32-bit mask 
 constexpr int kWavesPerBlock = kThreads / 64;
 constexpr int kCell = 64;                         /* points per cell */
 constexpr int kCellsPerTile = kTile / kCell;      /* 16 */
-constexpr int kMaxTilesPerBlock = 32;             /* chunkPoints <= 32 * 1024 (choose_chunk, kMaxTilesPerBlockHost) */
+/* a block's chunk is at most this many tiles (choose_chunk; ssd_launch.h holds the same numbers for the host): K1 keeps the
+ * chunk's cell masks in LDS, K2 / K4 / K6 the list of its wanted cells.  K2 gets tall chunks: its waves walk down cell
+ * columns and pay a window flush at every column change (measured, XGA batch: 2.5 ms with 8-row chunks, 1.5 with 16,
+ * 1.0 with 32) */
+constexpr int kMaxTilesPerBlock = 32;
 constexpr int kMaxCellsPerBlock = kMaxTilesPerBlock * kCellsPerTile;
+constexpr int kMaxTilesPerBlockRaster = 128;
+constexpr int kMaxCellsPerBlockRaster = kMaxTilesPerBlockRaster * kCellsPerTile;
 
 /* OR over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1): every lane of the row gets the row's result */
 __device__ __forceinline__ unsigned int row_or_u32(unsigned int v)
@@ -243,24 +249,32 @@ __device__ __forceinline__ void load_cell(const float *__restrict__ base, int ce
   }
 }
 
-template<int SRC>
-__global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
-                                                   FrameState *__restrict__ st, unsigned int *__restrict__ tileMasks,
-                                                   size_t tileMaskStride, int chunkPoints, DepthSrc D)
+/* The streaming kernels are written as block bodies over an explicit LDS struct, (frame, chunk) given by the caller:
+ * the kernels below pass blockIdx (tools and experiments have paired two bodies in one launch: DESIGN.md section 3). */
+struct HistLds
 {
-  __shared__ unsigned int lMasks[kMaxCellsPerBlock];
+  unsigned int lMasks[kMaxCellsPerBlock];
   /* [bin][copy]: a vote goes to copy = lane & 31, i.e. LDS bank = copy: the 32 lanes the LDS serves per
    * cycle never collide, whatever their bins (a camera row sweeping one plateau puts all 64 lanes in one bin) */
-  __shared__ unsigned int lh[kMaxBins * kHistCopies];
-  __shared__ unsigned int lNonZero;
+  unsigned int lh[kMaxBins * kHistCopies];
+  unsigned int lNonZero;
+};
+
+template<int SRC>
+__device__ __forceinline__ void hist_block(HistLds &L, const float *__restrict__ xyz, size_t strideFloats, const PointParams &P,
+                                           FrameState *__restrict__ st, unsigned int *__restrict__ tileMasks,
+                                           size_t tileMaskStride, int chunkPoints, const DepthSrc &D, const int frame, const int chunkIdx)
+{
+  unsigned int (&lMasks)[kMaxCellsPerBlock] = L.lMasks;
+  unsigned int (&lh)[kMaxBins * kHistCopies] = L.lh;
+  unsigned int &lNonZero = L.lNonZero;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int frame = blockIdx.x;                /* frame on the fast grid axis: see launch note on XCD balance */
   /* strideFloats counts floats, or 16-bit depth values for kSrcDepth16 */
   const float *base = SRC == kSrcDepth16
     ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(xyz) + static_cast<size_t>(frame) * strideFloats)
     : xyz + static_cast<size_t>(frame) * strideFloats;
-  const int begin = blockIdx.y * chunkPoints;
+  const int begin = chunkIdx * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
 
   for(int i = tid; i < kMaxBins * kHistCopies; i += kThreads)
@@ -317,6 +331,15 @@ __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ 
     for(int i = tid; i < it * kCellsPerTile; i += kThreads)
       dst[i] = lMasks[i];
   }
+}
+
+template<int SRC>
+__global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
+                                                   FrameState *__restrict__ st, unsigned int *__restrict__ tileMasks,
+                                                   size_t tileMaskStride, int chunkPoints, DepthSrc D)
+{
+  __shared__ HistLds L;
+  hist_block<SRC>(L, xyz, strideFloats, P, st, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);   /* frame on the fast grid axis: see launch note on XCD balance */
 }
 
 /* ========================================================================= */
@@ -668,22 +691,33 @@ __device__ __forceinline__ bool image_pixel(const PointParams &P, const PixelPar
   return ix >= 0 && ix < X.W && iy >= 0 && iy < X.H;
 }
 
-template<int SRC>
-__global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
-                                                        PixelParams X, FrameState *__restrict__ st,
-                                                        unsigned long long *__restrict__ stepImg,
-                                                        const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
+struct RasterLds
 {
-  __shared__ unsigned long long wins[kThreads / 64][kWinWords];
-  __shared__ unsigned int wmiss[kThreads / 64][kWaveMissWords];
-  __shared__ ImageBox boxes[kMaxStepImages];
-  __shared__ unsigned char lut[kMaxBins];
-  __shared__ unsigned int lOob;
-  __shared__ unsigned short cellList[kMaxCellsPerBlock];
-  __shared__ unsigned int listScratch[kWavesPerBlock];
+  unsigned long long wins[kThreads / 64][kWinWords];
+  unsigned int wmiss[kThreads / 64][kWaveMissWords];
+  ImageBox boxes[kMaxStepImages];
+  unsigned char lut[kMaxBins];
+  unsigned int lOob;
+  unsigned short cellList[kMaxCellsPerBlockRaster];
+  unsigned int listScratch[kWavesPerBlock];
+};
+
+template<int SRC>
+__device__ __forceinline__ void raster_block(RasterLds &L, const float *__restrict__ xyz, size_t strideFloats, const PointParams &P,
+                                             const PixelParams &X, FrameState *__restrict__ st,
+                                             unsigned long long *__restrict__ stepImg,
+                                             const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, const DepthSrc &D,
+                                             const int frame, const int chunkIdx)
+{
+  unsigned long long (&wins)[kThreads / 64][kWinWords] = L.wins;
+  unsigned int (&wmiss)[kThreads / 64][kWaveMissWords] = L.wmiss;
+  ImageBox (&boxes)[kMaxStepImages] = L.boxes;
+  unsigned char (&lut)[kMaxBins] = L.lut;
+  unsigned int &lOob = L.lOob;
+  unsigned short (&cellList)[kMaxCellsPerBlockRaster] = L.cellList;
+  unsigned int (&listScratch)[kWavesPerBlock] = L.listScratch;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int frame = blockIdx.x;                /* frame on the fast grid axis: see launch note on XCD balance */
   FrameState &fs = st[frame];
   const int nImg = fs.nStepImages;
   if(nImg == 0)
@@ -709,7 +743,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
   const float *base = SRC == kSrcDepth16
     ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(xyz) + static_cast<size_t>(frame) * strideFloats)
     : xyz + static_cast<size_t>(frame) * strideFloats;
-  const int begin = blockIdx.y * chunkPoints;
+  const int begin = chunkIdx * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
   const unsigned int imgWords = static_cast<unsigned int>(X.H) * X.W64;
   unsigned long long *frameImg = stepImg + static_cast<size_t>(frame) * X.maxStepImages * imgWords;
@@ -793,6 +827,16 @@ __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict_
     atomicAdd(&fs.nOob, lOob);
     atomicOr(&fs.status, static_cast<unsigned int>(SSD_ST_OOB_PIXEL));
   }
+}
+
+template<int SRC>
+__global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
+                                                        PixelParams X, FrameState *__restrict__ st,
+                                                        unsigned long long *__restrict__ stepImg,
+                                                        const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
+{
+  __shared__ RasterLds L;
+  raster_block<SRC>(L, xyz, strideFloats, P, X, st, stepImg, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
 }
 
 /* ========================================================================= */
@@ -1613,26 +1657,41 @@ __device__ __forceinline__ long long z_plus_magic_bits(double z)
 }
 constexpr long long kMagicBits = 0x40B8000000000000ll;       /* bits of 6144.0 */
 
-template<int SRC>
-__global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
-                                                        PixelParams X, FrameState *__restrict__ st,
-                                                        unsigned long long *__restrict__ groundImg,
-                                                        const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
+struct InquadLds
 {
-  __shared__ unsigned long long wins[kThreads / 64][kWinWords];
-  __shared__ unsigned int wmiss[kThreads / 64][kWaveMissWords];
-  __shared__ ImageBox box[1];
-  __shared__ QuadTest qts[kMaxPlateaus + 1];
-  __shared__ unsigned char lut[kMaxBins];
-  __shared__ unsigned char active[kMaxPlateaus + 1];
-  __shared__ unsigned long long lsum[kMaxPlateaus + 1][8];
-  __shared__ unsigned int lcnt[kMaxPlateaus + 1][8];
-  __shared__ unsigned int lOob;
-  __shared__ unsigned short cellList[kMaxCellsPerBlock];
-  __shared__ unsigned int listScratch[kWavesPerBlock];
+  unsigned long long wins[kThreads / 64][kWinWords];
+  unsigned int wmiss[kThreads / 64][kWaveMissWords];
+  ImageBox box[1];
+  QuadTest qts[kMaxPlateaus + 1];
+  unsigned char lut[kMaxBins];
+  unsigned char active[kMaxPlateaus + 1];
+  unsigned long long lsum[kMaxPlateaus + 1][8];
+  unsigned int lcnt[kMaxPlateaus + 1][8];
+  unsigned int lOob;
+  unsigned short cellList[kMaxCellsPerBlock];
+  unsigned int listScratch[kWavesPerBlock];
+};
+
+template<int SRC>
+__device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restrict__ xyz, size_t strideFloats, const PointParams &P,
+                                             const PixelParams &X, FrameState *__restrict__ st,
+                                             unsigned long long *__restrict__ groundImg,
+                                             const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, const DepthSrc &D,
+                                             const int frame, const int chunkIdx)
+{
+  unsigned long long (&wins)[kThreads / 64][kWinWords] = L.wins;
+  unsigned int (&wmiss)[kThreads / 64][kWaveMissWords] = L.wmiss;
+  ImageBox (&box)[1] = L.box;
+  QuadTest (&qts)[kMaxPlateaus + 1] = L.qts;
+  unsigned char (&lut)[kMaxBins] = L.lut;
+  unsigned char (&active)[kMaxPlateaus + 1] = L.active;
+  unsigned long long (&lsum)[kMaxPlateaus + 1][8] = L.lsum;
+  unsigned int (&lcnt)[kMaxPlateaus + 1][8] = L.lcnt;
+  unsigned int &lOob = L.lOob;
+  unsigned short (&cellList)[kMaxCellsPerBlock] = L.cellList;
+  unsigned int (&listScratch)[kWavesPerBlock] = L.listScratch;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int frame = blockIdx.x;                /* frame on the fast grid axis: see launch note on XCD balance */
   FrameState &fs = st[frame];
   if(!fs.anyActive)                                         /* block-uniform: set by k_quads */
     return;
@@ -1677,7 +1736,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
   const float *base = SRC == kSrcDepth16
     ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(xyz) + static_cast<size_t>(frame) * strideFloats)
     : xyz + static_cast<size_t>(frame) * strideFloats;
-  const int begin = blockIdx.y * chunkPoints;
+  const int begin = chunkIdx * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
   unsigned long long *gimg = groundImg + static_cast<size_t>(frame) * X.H * X.W64;
   const int copy = lane & 7;
@@ -1794,6 +1853,16 @@ __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict_
       atomicOr(&fs.status, static_cast<unsigned int>(SSD_ST_OOB_PIXEL));
     }
   }
+}
+
+template<int SRC>
+__global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
+                                                        PixelParams X, FrameState *__restrict__ st,
+                                                        unsigned long long *__restrict__ groundImg,
+                                                        const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
+{
+  __shared__ InquadLds L;
+  inquad_block<SRC>(L, xyz, strideFloats, P, X, st, groundImg, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
 }
 
 /* ========================================================================= */

@@ -10,6 +10,7 @@ constexpr int kTileHost = 1024;
 /* kTileHost = kThreads * kPts of ssd_kernels.hip: chunk sizes are multiples of it; a block's chunk is at most
  * kMaxTilesPerBlockHost tiles (K1 keeps the chunk's cell masks, K2/K4/K6 the list of its wanted cells, in LDS) */
 constexpr int kMaxTilesPerBlockHost = 32;
+constexpr int kMaxTilesPerBlockRasterHost = 128;   /* K2 only */
 constexpr int kCellHost = 64;               /* points per cell (one gating mask each) */
 
 void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned int *tileMasks, size_t tileMaskStride,
