@@ -289,6 +289,16 @@ def main():
                     traffic = None if ref is None else ref * F / 1024.0
             except Exception:
                 traffic = None
+        pipeline_moved = None
+        pm = os.path.join(ROOT, "profiles", "pmc_pipeline.json")
+        if os.path.exists(pm) and not fhd and not depth_in and F == 1024:
+            try:
+                j = json.load(open(pm))
+                pipeline_moved = {"hbm_read_bytes": j["hbm_read_bytes"], "hbm_write_bytes": j["hbm_write_bytes"],
+                                  "over_algorithmic": j["bytes_moved_over_algorithmic"],
+                                  "source": "profiles/pmc_pipeline.json (PMC passes of this command, committed; not re-measured in this run)"}
+            except Exception:
+                pipeline_moved = None
         out = {
             "metric": METRIC_FHD if fhd else METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
@@ -306,6 +316,7 @@ def main():
                                            "of this command, committed; not re-measured in this run)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms},
             "stage_ms": stage,
+            "pipeline_bytes_moved": pipeline_moved,
             "pipeline_bytes_algorithmic_frac_of_peak": (alg_bytes * args.steps / dt_max / 1e9) / HBM_PEAK_GBS,
         }
         if world > 1:

@@ -56,9 +56,36 @@ def main():
                        "hbm_bytes_per_launch_at_1024x768x1024": total,
                        "algorithmic_bytes_per_launch": 12.0 * 1024 * 768 * 1024,
                        "ratio": total / (12.0 * 1024 * 768 * 1024)}, open(os.path.join(dst, "pmc_k_hist.json"), "w"), indent=1)
-    b = os.path.join(src, "bench.json")
-    if os.path.exists(b) and os.path.getsize(b):
-        shutil.copy(b, os.path.join(dst, tag + "_bench.json"))
+    moved_r = sum((v["hbm_read_bytes"] or 0.0) for k, v in out["kernels"].items() if "synth" not in k)
+    moved_w = sum((v["hbm_write_bytes"] or 0.0) for k, v in out["kernels"].items() if "synth" not in k)
+    if moved_r:
+        json.dump({"source": "profiles/%s_hbm_traffic.json (all kernels of one pass over 1024 XGA frames; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % tag,
+                   "hbm_read_bytes": moved_r, "hbm_write_bytes": moved_w, "algorithmic_bytes": 12.0 * 1024 * 768 * 1024,
+                   "bytes_moved_over_algorithmic": (moved_r + moved_w) / (12.0 * 1024 * 768 * 1024)},
+                  open(os.path.join(dst, "pmc_pipeline.json"), "w"), indent=1)
+    for name, to in (("bench.json", "_bench.json"), ("bench_fhd.json", "_bench_fhd_stress.json"), ("bench_depth16.json", "_bench_depth16.json"),
+                     ("hostfed.json", "_hostfed.json"), ("latency.txt", "_latency.txt")):
+        b = os.path.join(src, name)
+        if os.path.exists(b) and os.path.getsize(b):
+            shutil.copy(b, os.path.join(dst, tag + to))
+    stats = glob.glob(os.path.join(src, "trace_fhd", "*", "*kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats_fhd_stress.csv"))
+    # instruction / issue counters of a tools/pmc.sh run (optional second argument: its tag)
+    if len(sys.argv) > 2:
+        agg = collections.defaultdict(dict)
+        for f in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_" + sys.argv[2], "*", "*", "*counter_collection.csv")):
+            per = collections.defaultdict(lambda: collections.defaultdict(list))
+            for r in csv.DictReader(open(f)):
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                if k.startswith("ssd::k_") and "synth" not in k:
+                    per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            for k in per:
+                for c, v in per[k].items():
+                    agg[k][c] = round(sum(v) / len(v), 3)
+        json.dump({"note": "rocprofv3 --kernel-trace --pmc <set> -- python3 bench.py --steps 2 --warmup 1 --no-cpu (one pass per counter set, "
+                           "tools/pmc.sh); per launch = 1024 XGA frames", "kernels": {k: dict(sorted(v.items())) for k, v in sorted(agg.items())}},
+                  open(os.path.join(dst, tag + "_pmc_issue.json"), "w"), indent=1)
     print(open(os.path.join(dst, tag + "_hbm_traffic.json")).read()[:1500])
 
 
