@@ -313,6 +313,8 @@ static int make_params(const ssd_config &c, const ssd_calibration &k, Params &P)
     return fail(SSD_E_ARG, "config: max_step_plateaus out of range");
   P.maxStepImages = c.max_step_plateaus;
   P.pt.xMin = c.x_min; P.pt.xMax = c.x_max; P.pt.yMin = c.y_min; P.pt.yMax = c.y_max; P.pt.zMin = c.z_min; P.pt.zMax = c.z_max;
+  P.pt.boxX = 256.0 / (c.x_max - c.x_min);
+  P.pt.boxY = 256.0 / (c.y_max - c.y_min);
   P.pt.nPoints = P.nPoints;
   P.pt.nBins = P.nBins;
   P.px.xToImage = P.xToImage; P.px.yToImage = P.yToImage;
@@ -393,7 +395,7 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   HIP_TRY_H(hipMalloc(&h->dStepImg, stepBytes));
   HIP_TRY_H(hipMalloc(&h->dGroundImg, groundBytes));
   h->tileMaskStride = (static_cast<size_t>(P.nPoints) + kTileHost - 1) / kTileHost * (kTileHost / kCellHost);   /* masks (u32) per frame */
-  HIP_TRY_H(hipMalloc(&h->dTileMasks, h->tileMaskStride * 4 * h->F));
+  HIP_TRY_H(hipMalloc(&h->dTileMasks, h->tileMaskStride * sizeof(uint2) * h->F));
   HIP_TRY_H(hipMalloc(&h->dResults, sizeof(ssd_frame_result) * h->F * 2));
   HIP_TRY_H(hipHostMalloc(&h->hResults, sizeof(ssd_frame_result) * h->F * 2, hipHostMallocDefault));
   HIP_TRY_H(hipEventCreateWithFlags(&h->resultsReady[0], hipEventDisableTiming));
@@ -405,7 +407,7 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   HIP_TRY_H(hipMemset(h->dResults, 0, sizeof(ssd_frame_result) * h->F * 2));
   HIP_TRY_H(hipDeviceSynchronize());
 #undef HIP_TRY_H
-  h->bytes = sizeof(FrameState) * h->F + stepBytes + groundBytes + h->tileMaskStride * 4 * h->F + sizeof(ssd_frame_result) * h->F;
+  h->bytes = sizeof(FrameState) * h->F + stepBytes + groundBytes + h->tileMaskStride * sizeof(uint2) * h->F + sizeof(ssd_frame_result) * h->F;
   *out = h;
   return SSD_OK;
 }
@@ -606,6 +608,17 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
     if(tiles * kTileHost > chunkRaster)
       chunkRaster = tiles * kTileHost;
   }
+  /* K4 walks a third of the cells: taller chunks amortise a block's start (copy of the live table, list of its cells) */
+  int chunkInquad = chunk;
+  {
+    int tiles = env_int("SSD_K4_CHUNK_TILES", 32);
+    if(tiles > kMaxTilesPerBlockInquadHost) tiles = kMaxTilesPerBlockInquadHost;
+    const long long totalTiles = (static_cast<long long>(P.nPoints) + kTileHost - 1) / kTileHost * nframes;
+    while(tiles > chunk / kTileHost && totalTiles / tiles < 8192)
+      tiles /= 2;
+    if(tiles * kTileHost > chunkInquad)
+      chunkInquad = tiles * kTileHost;
+  }
   DebugFrame *dbg = h->debug ? h->dDebug : nullptr;
   unsigned long long *dbgImg = h->debug ? h->dDebugImg : nullptr;
   const bool timing = h->timing && !h->ev.empty();
@@ -641,7 +654,7 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
     launch_quads(P, h->dState, nframes, dbg, s);
   mark();
   if(stages & SSD_STAGE_INQUAD)
-    launch_inquad(xyz, strideFloats, P, h->dState, h->dGroundImg, h->dTileMasks, h->tileMaskStride, nframes, chunk, depth, s);
+    launch_inquad(xyz, strideFloats, P, h->dState, h->dGroundImg, h->dTileMasks, h->tileMaskStride, nframes, chunkInquad, depth, s);
   mark();
   if(stages & SSD_STAGE_FINAL)
   {

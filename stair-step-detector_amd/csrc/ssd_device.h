@@ -23,6 +23,7 @@ constexpr int kMaxPlateaus = SSD_MAX_PLATEAUS;
 constexpr int kMaxStepImages = SSD_MAX_STEP_IMAGES;
 constexpr int kGroundAcc = kMaxPlateaus;          /* accumulator slot of the ground quadrilateral */
 constexpr int kMaxRisers = SSD_MAX_RISERS;
+constexpr int kMaxLive = kMaxStepImages + 1;      /* quadrilaterals a frame can have points tested against: one per step image + the ground */
 constexpr int kZFixShift = 40;                    /* mean z accumulates round(z * 2^40) in int64 */
 
 /* the four horizontal edges of a plateau outline, in this order everywhere (segmentation.cpp:585-589) */
@@ -36,6 +37,7 @@ struct PointParams
   double a[9], b[3];                          /* CameraToWorld: w = a * x + b (transformation.h:59-64) */
   double xMin, xMax, yMin, yMax, zMin, zMax;  /* Configuration::MeasuringRange (configuration.h:40-46) */
   double recip;                               /* 1 / heightInterval */
+  double boxX, boxY;                          /* 256 / (xMax - xMin), 256 / (yMax - yMin): grid of the cells' bounding boxes */
   int nPoints, nBins;
 };
 
@@ -126,13 +128,22 @@ struct FrameState
   int imgXMin[kMaxStepImages + 1], imgXMax[kMaxStepImages + 1];
   PlateauState pl[kMaxPlateaus];
   double groundQuadWorld[8];
-  QuadTest qt[kMaxPlateaus + 1];   /* [kGroundAcc] = ground */
+  /* the live quadrilateral tests, compact (k_quads): slot k belongs to accumulator liveAcc[k] (treads ascending, the
+   * ground last); lutLive: height bin -> slot; liveGroups: the groups of 4 height bins of the slot's plateau */
+  QuadTest qtLive[kMaxLive];
+  unsigned char liveAcc[kMaxLive];
+  unsigned char lutLive[kMaxBins];
+  unsigned int liveGroups[kMaxLive];
+  int nLive;
   unsigned char accActive[kMaxPlateaus + 1];
   /* gates of K2 / K4 against K1's tile masks: groups of 8 height bins that hold a bin of a step plateau /
    * of a live quadrilateral; anyActive = some accumulator is live */
   unsigned int wantedSteps, wantedQuads, anyActive;
+  /* fixed-point z sums and counts: [kGroundAcc] = the ground points INSIDE the ground quadrilateral; [k] of a tread =
+   * its points OUTSIDE its quadrilateral (k_inquad); totZ[slot] = all points of the tread in image slot `slot` (k_raster) */
   long long sumZ[kMaxPlateaus + 1];
   unsigned int cnt[kMaxPlateaus + 1];
+  long long totZ[kMaxStepImages];
   /* vertical faces (extension): written by k_final, accumulated by k_risers */
   int nRisers;
   unsigned int wantedRisers;

@@ -18,7 +18,7 @@ struct ssd_handle
   ssd::FrameState *dState = nullptr;
   unsigned long long *dStepImg = nullptr;
   unsigned long long *dGroundImg = nullptr;
-  unsigned int *dTileMasks = nullptr;       /* per cell (64 points): which groups of 4 height bins occur; K1 -> K2, K4, K6 */
+  uint2 *dTileMasks = nullptr;             /* per cell (64 points): which groups of 4 height bins occur; K1 -> K2, K4, K6 */
   size_t tileMaskStride = 0;
   float *dDepthMaps = nullptr;              /* xmap[W] then ymap[H] (ssd_set_intrinsics) */
   ssd_intrinsics intr{};

@@ -185,6 +185,8 @@ constexpr int kMaxTilesPerBlock = 32;
 constexpr int kMaxCellsPerBlock = kMaxTilesPerBlock * kCellsPerTile;
 constexpr int kMaxTilesPerBlockRaster = 128;
 constexpr int kMaxCellsPerBlockRaster = kMaxTilesPerBlockRaster * kCellsPerTile;
+constexpr int kMaxTilesPerBlockInquad = 128;
+constexpr int kMaxCellsPerBlockInquad = kMaxTilesPerBlockInquad * kCellsPerTile;
 
 /* OR over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1): every lane of the row gets the row's result */
 __device__ __forceinline__ unsigned int row_or_u32(unsigned int v)
@@ -196,12 +198,61 @@ __device__ __forceinline__ unsigned int row_or_u32(unsigned int v)
   return v;
 }
 
+/* K1 also leaves, per cell, the bounding box of its in-range points in world x / y on a 256 x 256 grid over the measuring
+ * range (one byte per bound: x0, x1, y0, y1; a cell with no in-range point has an empty mask and a meaningless box).
+ * k_inquad decides from it, without loading the cell, that all its points lie outside the ground quadrilateral, or all
+ * inside a tread's (cell_box_world widens by a margin far above any rounding). */
+__device__ __forceinline__ unsigned int cell_box_pack(unsigned int mn, unsigned int mx)
+{
+  const unsigned int x0 = min(mn & 0xffffu, 255u), y0 = min(mn >> 16, 255u), x1 = min(mx & 0xffffu, 255u), y1 = min(mx >> 16, 255u);
+  return x0 | (x1 << 8) | (y0 << 16) | (y1 << 24);
+}
+__device__ __forceinline__ void cell_box_world(const PointParams &P, unsigned int box, double &x0, double &x1, double &y0, double &y1)
+{
+  const double ux = 1.0 / P.boxX, uy = 1.0 / P.boxY, margin = 1.0e-9;
+  x0 = P.xMin + static_cast<double>(box & 0xffu) * ux - margin;
+  x1 = P.xMin + static_cast<double>(((box >> 8) & 0xffu) + 1u) * ux + margin;
+  y0 = P.yMin + static_cast<double>((box >> 16) & 0xffu) * uy - margin;
+  y1 = P.yMin + static_cast<double>((box >> 24) + 1u) * uy + margin;
+}
+
+/* component-wise min / max of two u16 pairs packed in 32 bits (v_pk_min_u16 / v_pk_max_u16) */
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pk_min_u16(unsigned int a, unsigned int b)
+{
+  return __builtin_bit_cast(unsigned int, __builtin_elementwise_min(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
+}
+__device__ __forceinline__ unsigned int pk_max_u16(unsigned int a, unsigned int b)
+{
+  return __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
+}
+/* the same over the 16 lanes of a DPP row */
+__device__ __forceinline__ unsigned int row_pk_min_u16(unsigned int v)
+{
+  v = pk_min_u16(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x128, 0xf, 0xf, false)));
+  v = pk_min_u16(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x124, 0xf, 0xf, false)));
+  v = pk_min_u16(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x122, 0xf, 0xf, false)));
+  v = pk_min_u16(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x121, 0xf, 0xf, false)));
+  return v;
+}
+__device__ __forceinline__ unsigned int row_pk_max_u16(unsigned int v)
+{
+  v = pk_max_u16(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x128, 0xf, 0xf, false)));
+  v = pk_max_u16(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x124, 0xf, 0xf, false)));
+  v = pk_max_u16(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x122, 0xf, 0xf, false)));
+  v = pk_max_u16(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x121, 0xf, 0xf, false)));
+  return v;
+}
+
 /* The list of the cells of a block's chunk whose mask meets `wanted`, in LDS, COLUMN-major: the cells of one
  * cell column (`cols` cells apart: vertically adjacent in the camera image) follow each other, so a wave that walks
  * the list stays on one patch of the top-down image that creeps down row by row — what its LDS write-combining
  * window needs — and jumps only at a column change.  Entries are cell indices relative to the chunk's first cell.
+ * wantCell(record) decides from the cell's record (x = mask of the groups of 4 height bins that occur, y = bounding box,
+ * see cell_box_pack) whether the cell is walked.
  * All threads of the block call it; returns the number of entries (block-uniform).  scratch: kWavesPerBlock words. */
-__device__ __forceinline__ int cell_list_build(const unsigned int *__restrict__ cellMasks, int nCells, int cols, unsigned int wanted,
+template<typename Want>
+__device__ __forceinline__ int cell_list_build(const uint2 *__restrict__ cellInfo, int nCells, int cols, Want wantCell,
                                                unsigned short *list, unsigned int *scratch)
 {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -212,7 +263,7 @@ __device__ __forceinline__ int cell_list_build(const unsigned int *__restrict__ 
     const int i = i0 + tid;
     const int cx = i / rows, r = i - cx * rows;
     const int c = r * cols + cx;
-    const bool want = cx < cols && c < nCells && (cellMasks[c] & wanted) != 0u;
+    const bool want = cx < cols && c < nCells && wantCell(cellInfo[c]);
     const unsigned long long b = __ballot(want);
     if(lane == 0)
       scratch[wave] = static_cast<unsigned int>(__popcll(b));
@@ -253,7 +304,7 @@ __device__ __forceinline__ void load_cell(const float *__restrict__ base, int ce
  * the kernels below pass blockIdx (tools and experiments have paired two bodies in one launch: DESIGN.md section 3). */
 struct HistLds
 {
-  unsigned int lMasks[kMaxCellsPerBlock];
+  uint2 lInfo[kMaxCellsPerBlock];
   /* [bin][copy]: a vote goes to copy = lane & 31, i.e. LDS bank = copy: the 32 lanes the LDS serves per
    * cycle never collide, whatever their bins (a camera row sweeping one plateau puts all 64 lanes in one bin) */
   unsigned int lh[kMaxBins * kHistCopies];
@@ -262,10 +313,10 @@ struct HistLds
 
 template<int SRC>
 __device__ __forceinline__ void hist_block(HistLds &L, const float *__restrict__ xyz, size_t strideFloats, const PointParams &P,
-                                           FrameState *__restrict__ st, unsigned int *__restrict__ tileMasks,
+                                           FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
                                            size_t tileMaskStride, int chunkPoints, const DepthSrc &D, const int frame, const int chunkIdx)
 {
-  unsigned int (&lMasks)[kMaxCellsPerBlock] = L.lMasks;
+  uint2 (&lInfo)[kMaxCellsPerBlock] = L.lInfo;
   unsigned int (&lh)[kMaxBins * kHistCopies] = L.lh;
   unsigned int &lNonZero = L.lNonZero;
 
@@ -288,6 +339,7 @@ __device__ __forceinline__ void hist_block(HistLds &L, const float *__restrict__
   int it = 0;
   SSD_STREAM_LOOP(
     unsigned int groups = 0u;
+    unsigned int boxMin = 0xffffffffu, boxMax = 0u;                     /* (x, y) of the in-range points on a 256 x 256 grid, packed u16 pairs */
     _Pragma("unroll") for(int j = 0; j < kPts; j++)
     {
       double wx, wy, wz;
@@ -297,11 +349,17 @@ __device__ __forceinline__ void hist_block(HistLds &L, const float *__restrict__
         const int b = height_bin(P, wz);
         atomicAdd(mine + b * kHistCopies, 1u);                          /* ++hist[bin], pointcloud.cpp:199-202 */
         groups |= 1u << (b / kBinsPerGroup);
+        const unsigned int qx = static_cast<unsigned int>((wx - P.xMin) * P.boxX), qy = static_cast<unsigned int>((wy - P.yMin) * P.boxY);
+        const unsigned int q = qx | (qy << 16);
+        boxMin = pk_min_u16(boxMin, q);
+        boxMax = pk_max_u16(boxMax, q);
       }
     }
     groups = row_or_u32(groups);
-    if((lane & 15) == 0)
-      lMasks[it * kCellsPerTile + (tid >> 4)] = groups;          /* cell = 64 consecutive points = lanes 16q .. 16q+15 */
+    boxMin = row_pk_min_u16(boxMin);
+    boxMax = row_pk_max_u16(boxMax);
+    if((lane & 15) == 0)                                         /* cell = 64 consecutive points = lanes 16q .. 16q+15 */
+      lInfo[it * kCellsPerTile + (tid >> 4)] = make_uint2(groups, cell_box_pack(boxMin, boxMax));
     it++;
   )
 
@@ -325,17 +383,17 @@ __device__ __forceinline__ void hist_block(HistLds &L, const float *__restrict__
   }
   if(tid == 0 && lNonZero)
     atomicAdd(&fs.nNonZero, lNonZero);
-  /* the block's cell masks, in one burst */
+  /* the block's cell records, in one burst */
   {
-    unsigned int *dst = tileMasks + static_cast<size_t>(frame) * tileMaskStride + static_cast<size_t>(begin / kCell);
+    uint2 *dst = tileMasks + static_cast<size_t>(frame) * tileMaskStride + static_cast<size_t>(begin / kCell);
     for(int i = tid; i < it * kCellsPerTile; i += kThreads)
-      dst[i] = lMasks[i];
+      dst[i] = lInfo[i];
   }
 }
 
 template<int SRC>
 __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
-                                                   FrameState *__restrict__ st, unsigned int *__restrict__ tileMasks,
+                                                   FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
                                                    size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
   __shared__ HistLds L;
@@ -691,6 +749,21 @@ __device__ __forceinline__ bool image_pixel(const PointParams &P, const PixelPar
   return ix >= 0 && ix < X.W && iy >= 0 && iy < X.H;
 }
 
+/* round(z * 2^40) without a double->int64 conversion (a long software sequence on this ISA): adding
+ * 1.5 * 2^12 puts z (|z| < 2048) on the 2^-40 grid of [4096, 8192), rounded to nearest even by the add;
+ * the mantissa difference to the constant is the integer.  Same value as llrint(z * 2^40). */
+__device__ __forceinline__ long long z_to_fixed(double z)
+{
+  const double magic = 6144.0;
+  return __double_as_longlong(z + magic) - __double_as_longlong(magic);
+}
+/* the same in two halves for running sums: n values of z_plus_magic_bits minus n * kMagicBits */
+__device__ __forceinline__ long long z_plus_magic_bits(double z)
+{
+  return __double_as_longlong(z + 6144.0);
+}
+constexpr long long kMagicBits = 0x40B8000000000000ll;       /* bits of 6144.0 */
+
 struct RasterLds
 {
   unsigned long long wins[kThreads / 64][kWinWords];
@@ -700,13 +773,14 @@ struct RasterLds
   unsigned int lOob;
   unsigned short cellList[kMaxCellsPerBlockRaster];
   unsigned int listScratch[kWavesPerBlock];
+  unsigned long long ltot[kMaxStepImages][8];       /* sum of round(z * 2^40) over ALL points of each step plateau (this block's share) */
 };
 
 template<int SRC>
 __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restrict__ xyz, size_t strideFloats, const PointParams &P,
                                              const PixelParams &X, FrameState *__restrict__ st,
                                              unsigned long long *__restrict__ stepImg,
-                                             const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, const DepthSrc &D,
+                                             const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, const DepthSrc &D,
                                              const int frame, const int chunkIdx)
 {
   unsigned long long (&wins)[kThreads / 64][kWinWords] = L.wins;
@@ -716,6 +790,7 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
   unsigned int &lOob = L.lOob;
   unsigned short (&cellList)[kMaxCellsPerBlockRaster] = L.cellList;
   unsigned int (&listScratch)[kWavesPerBlock] = L.listScratch;
+  unsigned long long (&ltot)[kMaxStepImages][8] = L.ltot;
 
   const int tid = threadIdx.x, lane = tid & 63;
   FrameState &fs = st[frame];
@@ -731,6 +806,8 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
   }
   if(tid < kMaxStepImages)
     boxes[tid] = ImageBox{ 0x7fffffff, -1, 0x7fffffff, -1 };
+  if(tid < kMaxStepImages * 8)
+    (&ltot[0][0])[tid] = 0ull;
   if(tid == 0)
     lOob = 0;
   for(int i = tid; i < (kThreads / 64) * kWinWords; i += kThreads)
@@ -751,14 +828,25 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
   unsigned int *wm = wmiss[tid >> 6];
   WaveWindow win;
   unsigned int oob = 0;
+  /* The z sum of EVERY point of each step plateau, in and out of its outline (the count is the histogram's): k_inquad
+   * then only has to visit the cells that can hold points OUTSIDE the quadrilateral and take those off again.  A lane
+   * walks down a camera column, so its hits nearly always stay on one plateau: running sum in registers. */
+  int curT = -1;
+  unsigned long long accT = 0;
+  auto flushT = [&]()
+  {
+    if(curT >= 0)
+      atomicAdd(&ltot[curT][lane & 7], accT);
+  };
 
   /* Only the cells that hold a bin of a step plateau are walked (cell_list_build), four per wave iteration, with the
    * loads of the NEXT group issued before the current one is processed: a wave that waits for its own loads each
    * iteration leaves the SIMD to seven others, which no longer cover the memory latency once the body is this short. */
   const int cell0 = begin / kCell;
   const int nCells = (end - begin + kCell - 1) / kCell;
-  const int count = cell_list_build(tileMasks + static_cast<size_t>(frame) * tileMaskStride + cell0, nCells, X.cellCols, fs.wantedSteps,
-                                    cellList, listScratch);
+  const unsigned int wantedSteps = fs.wantedSteps;
+  const int count = cell_list_build(tileMasks + static_cast<size_t>(frame) * tileMaskStride + cell0, nCells, X.cellCols,
+                                    [&](const uint2 info) { return (info.x & wantedSteps) != 0u; }, cellList, listScratch);
   const int nGroups = (count + 3) >> 2;
   int g = (tid >> 6) * nGroups / kWavesPerBlock;
   const int gEnd = ((tid >> 6) + 1) * nGroups / kWavesPerBlock;
@@ -790,6 +878,13 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
       const bool inside = image_pixel(P, X, wx, wy, ix, iy);
       if(!okxy)
         continue;
+      if(slot != curT)
+      {
+        flushT();
+        curT = slot;
+        accT = 0;
+      }
+      accT += static_cast<unsigned long long>(z_to_fixed(wz));
       oob += inside ? 0u : 1u;                                /* quirk Q5 */
       const unsigned long long bit = 1ull << (ix & 63);
       const int xw = ix >> 6;
@@ -814,9 +909,19 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
   }
   wavewin_flush(ww, win, frameImg, imgWords, X.W64, X.winShift, boxes, lane);
   wavemiss_flush(wm, boxes, lane);
+  flushT();
   if(oob)
     atomicAdd(&lOob, oob);
   __syncthreads();
+  if(tid < nImg)
+  {
+    unsigned long long t = 0;
+#pragma unroll
+    for(int k = 0; k < 8; k++)
+      t += ltot[tid][k];
+    if(t)
+      atomicAdd(reinterpret_cast<unsigned long long *>(&fs.totZ[tid]), t);
+  }
   if(tid < nImg && boxes[tid].yMax >= 0)
   {
     atomicMin(&fs.imgYMin[tid], boxes[tid].yMin); atomicMax(&fs.imgYMax[tid], boxes[tid].yMax);
@@ -833,7 +938,7 @@ template<int SRC>
 __global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                         PixelParams X, FrameState *__restrict__ st,
                                                         unsigned long long *__restrict__ stepImg,
-                                                        const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
+                                                        const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
   __shared__ RasterLds L;
   raster_block<SRC>(L, xyz, strideFloats, P, X, st, stepImg, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
@@ -1596,14 +1701,40 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
       quad[k] = src[k];
     build_quad_test(quad, t);
     err = t.err;
-    fs.qt[groundLane ? kGroundAcc : lane] = t;
+    /* one quadrilateral the reference would throw on ends the frame (quadrilateralTest.cpp:283-372) */
+    const bool threwHere = __ballot(err != 0) != 0ull;
+    /* The live quadrilaterals go into a compact table (at most one per image slot + the ground): k_inquad copies it
+     * whole, without asking which entries matter.  Slot order = accumulator order (treads ascending, ground last). */
+    const unsigned long long liveMask = threwHere ? 0ull : __ballot(true);
+    if(!threwHere)
+    {
+      const int slot = __popcll(liveMask & ((1ull << lane) - 1ull));
+      if(slot < kMaxLive)
+      {
+        fs.qtLive[slot] = t;
+        fs.liveAcc[slot] = static_cast<unsigned char>(lane);
+        /* the groups of 4 height bins this accumulator's plateau occupies (matched against the cells' masks) */
+        unsigned int groups = 0u;
+        const PlateauState &pl = fs.pl[groundLane ? groundInd : lane];
+        for(int b = pl.effLo; b <= pl.effHi; b++)
+          groups |= 1u << (b / kBinsPerGroup);
+        fs.liveGroups[slot] = groups;
+      }
+    }
   }
-  /* one quadrilateral the reference would throw on ends the frame (quadrilateralTest.cpp:283-372) */
   const bool threw = __ballot(err != 0) != 0ull;
   const bool active = (groundLane || valid) && !threw;
   if(lane <= kMaxPlateaus)
     fs.accActive[lane] = active ? 1 : 0;
   const unsigned long long activeMask = __ballot(active);
+  /* bin -> slot of the live table (0xff = no live quadrilateral takes this bin) */
+  for(int b = lane; b < kMaxBins; b += 64)
+  {
+    const int p = b < P.nBins ? fs.lut[b] : 0xff;
+    const int acc = p == groundInd ? kGroundAcc : p;
+    const bool live = p != 0xff && ((activeMask >> acc) & 1ull);
+    fs.lutLive[b] = live ? static_cast<unsigned char>(__popcll(activeMask & ((1ull << acc) - 1ull))) : static_cast<unsigned char>(0xff);
+  }
 
   unsigned int wanted = 0u;
   for(int b = lane; b < P.nBins; b += 64)
@@ -1622,6 +1753,7 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
       fs.status |= SSD_ST_THROW;
     fs.wantedQuads = wanted;
     fs.anyActive = activeMask != 0ull ? 1u : 0u;
+    fs.nLive = min(__popcll(activeMask), kMaxLive);
   }
   if(dbg)
   {
@@ -1642,54 +1774,44 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
 /* ========================================================================= */
 /* K4: in-quadrilateral filter, z sums, ground image                           */
 
-/* round(z * 2^40) without a double->int64 conversion (a long software sequence on this ISA): adding
- * 1.5 * 2^12 puts z (|z| < 2048) on the 2^-40 grid of [4096, 8192), rounded to nearest even by the add;
- * the mantissa difference to the constant is the integer.  Same value as llrint(z * 2^40). */
-__device__ __forceinline__ long long z_to_fixed(double z)
-{
-  const double magic = 6144.0;
-  return __double_as_longlong(z + magic) - __double_as_longlong(magic);
-}
-/* the same in two halves for running sums: n values of z_plus_magic_bits minus n * kMagicBits */
-__device__ __forceinline__ long long z_plus_magic_bits(double z)
-{
-  return __double_as_longlong(z + 6144.0);
-}
-constexpr long long kMagicBits = 0x40B8000000000000ll;       /* bits of 6144.0 */
-
 struct InquadLds
 {
   unsigned long long wins[kThreads / 64][kWinWords];
   unsigned int wmiss[kThreads / 64][kWaveMissWords];
   ImageBox box[1];
-  QuadTest qts[kMaxPlateaus + 1];
-  unsigned char lut[kMaxBins];
-  unsigned char active[kMaxPlateaus + 1];
-  unsigned long long lsum[kMaxPlateaus + 1][8];
-  unsigned int lcnt[kMaxPlateaus + 1][8];
+  QuadTest qts[kMaxLive];                       /* FrameState::qtLive: slot k = accumulator liveAcc[k] */
+  unsigned char lut[kMaxBins];                  /* bin -> live slot */
+  unsigned long long lsum[kMaxLive][8];
+  unsigned int lcnt[kMaxLive][8];
   unsigned int lOob;
-  unsigned short cellList[kMaxCellsPerBlock];
+  unsigned short cellList[kMaxCellsPerBlockInquad];
   unsigned int listScratch[kWavesPerBlock];
+  unsigned int liveGroups[kMaxLive];
+  unsigned char liveAcc[kMaxLive];
+  int nLive, groundSlot;
 };
 
 template<int SRC>
 __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restrict__ xyz, size_t strideFloats, const PointParams &P,
                                              const PixelParams &X, FrameState *__restrict__ st,
                                              unsigned long long *__restrict__ groundImg,
-                                             const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, const DepthSrc &D,
+                                             const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, const DepthSrc &D,
                                              const int frame, const int chunkIdx)
 {
   unsigned long long (&wins)[kThreads / 64][kWinWords] = L.wins;
   unsigned int (&wmiss)[kThreads / 64][kWaveMissWords] = L.wmiss;
   ImageBox (&box)[1] = L.box;
-  QuadTest (&qts)[kMaxPlateaus + 1] = L.qts;
+  QuadTest (&qts)[kMaxLive] = L.qts;
   unsigned char (&lut)[kMaxBins] = L.lut;
-  unsigned char (&active)[kMaxPlateaus + 1] = L.active;
-  unsigned long long (&lsum)[kMaxPlateaus + 1][8] = L.lsum;
-  unsigned int (&lcnt)[kMaxPlateaus + 1][8] = L.lcnt;
+  unsigned long long (&lsum)[kMaxLive][8] = L.lsum;
+  unsigned int (&lcnt)[kMaxLive][8] = L.lcnt;
   unsigned int &lOob = L.lOob;
-  unsigned short (&cellList)[kMaxCellsPerBlock] = L.cellList;
+  unsigned short (&cellList)[kMaxCellsPerBlockInquad] = L.cellList;
   unsigned int (&listScratch)[kWavesPerBlock] = L.listScratch;
+  unsigned int (&liveGroups)[kMaxLive] = L.liveGroups;
+  unsigned char (&liveAcc)[kMaxLive] = L.liveAcc;
+  int &nLive = L.nLive;
+  int &groundSlot = L.groundSlot;
 
   const int tid = threadIdx.x, lane = tid & 63;
   FrameState &fs = st[frame];
@@ -1702,15 +1824,19 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
   }
 
   if(tid < kMaxBins)
+    lut[tid] = fs.lutLive[tid];                 /* bin -> slot of the live table, 0xff = nothing to do for this bin */
+  if(tid < kMaxLive)
   {
-    /* bin -> accumulator of a live quadrilateral, 0xff = nothing to do for this bin */
-    const int p = fs.lut[tid];
-    const int q = p == fs.groundInd ? kGroundAcc : p;
-    lut[tid] = (p != 0xff && fs.accActive[q]) ? static_cast<unsigned char>(q) : static_cast<unsigned char>(0xff);
+    liveAcc[tid] = fs.liveAcc[tid];
+    liveGroups[tid] = fs.liveGroups[tid];
   }
-  if(tid <= kMaxPlateaus)
-    active[tid] = fs.accActive[tid];
-  for(int i = tid; i < (kMaxPlateaus + 1) * 8; i += kThreads)
+  if(tid == 0)
+  {
+    const int n = fs.nLive;
+    nLive = n;
+    groundSlot = (n > 0 && fs.accActive[kGroundAcc]) ? n - 1 : -1;     /* the ground is the last accumulator */
+  }
+  for(int i = tid; i < kMaxLive * 8; i += kThreads)
   {
     (&lsum[0][0])[i] = 0ull;
     (&lcnt[0][0])[i] = 0u;
@@ -1721,13 +1847,13 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
     wavemiss_init(wmiss[tid]);
   {
     /* copy the live quadrilateral tests as 32-bit words */
-    const unsigned int *src = reinterpret_cast<const unsigned int *>(fs.qt);
+    const unsigned int *src = reinterpret_cast<const unsigned int *>(fs.qtLive);
     unsigned int *dst = reinterpret_cast<unsigned int *>(qts);
     constexpr int wordsPer = sizeof(QuadTest) / 4;
-    /* all of them, unconditionally: independent loads the compiler can issue together — asking "is it live?" first made
-     * every element two dependent round trips, a large part of a block's life */
-#pragma unroll 8
-    for(int i = tid; i < (kMaxPlateaus + 1) * wordsPer; i += kThreads)
+    /* the whole table, unconditionally: independent loads the compiler can issue together — asking "how many are live?"
+     * first made every element two dependent round trips, a large part of a block's life */
+#pragma unroll 4
+    for(int i = tid; i < kMaxLive * wordsPer; i += kThreads)
       dst[i] = src[i];
   }
   __syncthreads();
@@ -1763,8 +1889,33 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
   /* only the cells that hold a bin of a live quadrilateral are walked, four per wave iteration (cell_list_build) */
   const int cell0 = begin / kCell;
   const int nCells = (end - begin + kCell - 1) / kCell;
-  const int count = cell_list_build(tileMasks + static_cast<size_t>(frame) * tileMaskStride + cell0, nCells, X.cellCols, fs.wantedQuads,
-                                    cellList, listScratch);
+  /* A cell is walked only if it can change a sum.  Ground: its points INSIDE the ground quadrilateral are added (and
+   * rastered) — a cell whose bounding box lies outside the quadrilateral's (strict) bounding box has none.  Treads: k_raster
+   * already summed every point of the plateau, so the points OUTSIDE the quadrilateral are taken off here — a cell whose
+   * bounding box lies inside the quadrilateral's large constant cell (QuadTest::fx0 ..) has none.  The box covers all
+   * in-range points of the cell, whatever their plateau: conservative for each of them. */
+  const unsigned int wantedQuads = fs.wantedQuads;
+  const int gSlot = groundSlot;
+  const int count = cell_list_build(tileMasks + static_cast<size_t>(frame) * tileMaskStride + cell0, nCells, X.cellCols,
+                                    [&](const uint2 info)
+                                    {
+                                      if((info.x & wantedQuads) == 0u)
+                                        return false;
+                                      double x0, x1, y0, y1;
+                                      cell_box_world(P, info.y, x0, x1, y0, y1);
+                                      bool need = false;
+                                      for(int q = 0; q < nLive; q++)
+                                      {
+                                        if((info.x & liveGroups[q]) == 0u)
+                                          continue;
+                                        const QuadTest &t = qts[q];
+                                        if(q == gSlot)
+                                          need = need || !(x1 <= t.bxLo || x0 >= t.bxUp || y1 <= t.byLo || y0 >= t.byUp);
+                                        else
+                                          need = need || !(x0 >= t.fx0 && x1 < t.fx1 && y0 >= t.fy0 && y1 < t.fy1);
+                                      }
+                                      return need;
+                                    }, cellList, listScratch);
   const int nGroups = (count + 3) >> 2;
   const int gEnd = ((tid >> 6) + 1) * nGroups / kWavesPerBlock;
   for(int g = (tid >> 6) * nGroups / kWavesPerBlock; g < gEnd; g++)
@@ -1785,10 +1936,11 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
       if(!(okz && q != 0xff))
         continue;
       {
+        /* ground: the points inside its quadrilateral count; treads: the points outside theirs */
         const bool okxy = world_xy(P, v[j], wx, wy);
         const QuadTest &t = qts[q];
         const bool fast = wx >= t.fx0 && wx < t.fx1 && wy >= t.fy0 && wy < t.fy1;
-        if(!okxy || (!fast && !quad_test(t, wx, wy)))
+        if(!okxy || ((fast || quad_test(t, wx, wy)) != (q == gSlot)))
           continue;
       }
       if(q != curQ)
@@ -1798,7 +1950,7 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
       }
       accZ += static_cast<unsigned long long>(z_plus_magic_bits(wz));                        /* the constant's bits come off at the flush */
       accN++;
-      if(q == kGroundAcc)
+      if(q == gSlot)
       {
         /* projectToBinaryImage(pointsInQuadri) (pointcloud.cpp:531); the lane's pending word (pY, pXw, pMask) goes
          * out when the next pixel falls into another word */
@@ -1825,7 +1977,7 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
   if(oob)
     atomicAdd(&lOob, oob);
   __syncthreads();
-  if(tid <= kMaxPlateaus && active[tid])
+  if(tid < nLive)
   {
     unsigned long long s = 0;
     unsigned int c = 0;
@@ -1836,8 +1988,9 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
     }
     if(c)
     {
-      atomicAdd(reinterpret_cast<unsigned long long *>(&fs.sumZ[tid]), s);
-      atomicAdd(&fs.cnt[tid], c);
+      const int acc = liveAcc[tid];
+      atomicAdd(reinterpret_cast<unsigned long long *>(&fs.sumZ[acc]), s);
+      atomicAdd(&fs.cnt[acc], c);
     }
   }
   if(tid == 0)
@@ -1859,7 +2012,7 @@ template<int SRC>
 __global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                         PixelParams X, FrameState *__restrict__ st,
                                                         unsigned long long *__restrict__ groundImg,
-                                                        const unsigned int *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
+                                                        const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
   __shared__ InquadLds L;
   inquad_block<SRC>(L, xyz, strideFloats, P, X, st, groundImg, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
@@ -2050,7 +2203,11 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
       {
         if(!fs.pl[k].valid)
           continue;
-        const double meanZ = (static_cast<double>(fs.sumZ[k]) / static_cast<double>(1ll << kZFixShift)) / fs.cnt[k];
+        /* calcAverageZ over the plateau's points inside its quadrilateral = all of them (k_raster's sum, the histogram's
+         * count) minus the ones outside (k_inquad's sum and count) */
+        const long long inZ = fs.totZ[k - fs.firstStep] - fs.sumZ[k];
+        const unsigned int inN = static_cast<unsigned int>(fs.pl[k].nPoints) - fs.cnt[k];
+        const double meanZ = (static_cast<double>(inZ) / static_cast<double>(1ll << kZFixShift)) / inN;
         double *s = stepsWorld[n];
         s[0] = meanZ;
         for(int c = 0; c < 8; c++) s[1 + c] = fs.pl[k].quadWorld[c];
@@ -2058,8 +2215,8 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
         if(dbg)
         {
           ssd_debug_plateau &p = dbg[frame].d.plateaus[k];
-          p.n_in_quad = static_cast<int>(fs.cnt[k]);
-          p.sum_z_fix = fs.sumZ[k];
+          p.n_in_quad = static_cast<int>(inN);
+          p.sum_z_fix = inZ;
           p.mean_z = meanZ;
         }
       }
@@ -2159,7 +2316,7 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
 
 template<int SRC>
 __global__ __launch_bounds__(kThreads, 8) void k_risers(const float *__restrict__ xyz, size_t strideFloats, PointParams P, double tol,
-                                                        FrameState *__restrict__ st, const unsigned int *__restrict__ tileMasks,
+                                                        FrameState *__restrict__ st, const uint2 *__restrict__ tileMasks,
                                                         size_t tileMaskStride, int chunkPoints, int cellCols, DepthSrc D)
 {
   __shared__ unsigned short cellList[kMaxCellsPerBlock];
@@ -2209,7 +2366,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_risers(const float *__restrict_
   /* only the cells that hold a bin of a riser are walked (as k_raster / k_inquad) */
   const int cell0 = begin / kCell;
   const int nCells = (end - begin + kCell - 1) / kCell;
-  const int count = cell_list_build(tileMasks + static_cast<size_t>(frame) * tileMaskStride + cell0, nCells, cellCols, wanted, cellList, listScratch);
+  const int count = cell_list_build(tileMasks + static_cast<size_t>(frame) * tileMaskStride + cell0, nCells, cellCols,
+                                    [&](const uint2 info) { return (info.x & wanted) != 0u; }, cellList, listScratch);
   const int nGroups = (count + 3) >> 2;
   const int gEnd = ((tid >> 6) + 1) * nGroups / kWavesPerBlock;
   for(int g = (tid >> 6) * nGroups / kWavesPerBlock; g < gEnd; g++)
@@ -2319,7 +2477,7 @@ static inline bool aligned16(const float *xyz, size_t strideFloats, int nPoints)
   return (reinterpret_cast<uintptr_t>(xyz) & 15u) == 0 && (strideFloats & 3u) == 0 && (nPoints & 3) == 0;
 }
 
-void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned int *tileMasks, size_t tileMaskStride,
+void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, uint2 *tileMasks, size_t tileMaskStride,
                  int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
@@ -2341,7 +2499,7 @@ void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg,
   hipLaunchKernelGGL(k_peaks, dim3(nframes), dim3(64), 0, s, P, st, nframes, dbg);
 }
 void launch_raster(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *stepImg,
-                   const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
+                   const uint2 *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
   if(depth)
@@ -2361,7 +2519,7 @@ void launch_quads(const Params &P, FrameState *st, int nframes, DebugFrame *dbg,
   hipLaunchKernelGGL(k_quads, dim3(nframes), dim3(64), 0, s, P, st, nframes, dbg);
 }
 void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *groundImg,
-                   const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
+                   const uint2 *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
   if(depth)
@@ -2375,7 +2533,7 @@ void launch_final(const Params &P, FrameState *st, unsigned long long *groundImg
 {
   hipLaunchKernelGGL(k_final, dim3(nframes), dim3(kThreads), 0, s, P, st, groundImg, results, dbg, dbgImg);
 }
-void launch_risers(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, const unsigned int *tileMasks, size_t tileMaskStride,
+void launch_risers(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, const uint2 *tileMasks, size_t tileMaskStride,
                    ssd_frame_risers *out, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));

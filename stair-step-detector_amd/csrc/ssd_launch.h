@@ -11,19 +11,20 @@ constexpr int kTileHost = 1024;
  * kMaxTilesPerBlockHost tiles (K1 keeps the chunk's cell masks, K2/K4/K6 the list of its wanted cells, in LDS) */
 constexpr int kMaxTilesPerBlockHost = 32;
 constexpr int kMaxTilesPerBlockRasterHost = 128;   /* K2 only */
+constexpr int kMaxTilesPerBlockInquadHost = 128;   /* K4 only */
 constexpr int kCellHost = 64;               /* points per cell (one gating mask each) */
 
-void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned int *tileMasks, size_t tileMaskStride,
+void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, uint2 *tileMasks, size_t tileMaskStride,
                  int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s);
 void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s);
 void launch_raster(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *stepImg,
-                   const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s);
+                   const uint2 *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s);
 void launch_outline(const Params &P, FrameState *st, unsigned long long *stepImg, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s);
 void launch_quads(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s);
 void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *groundImg,
-                   const unsigned int *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s);
+                   const uint2 *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s);
 void launch_final(const Params &P, FrameState *st, unsigned long long *groundImg, ssd_frame_result *results, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s);
-void launch_risers(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, const unsigned int *tileMasks, size_t tileMaskStride,
+void launch_risers(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, const uint2 *tileMasks, size_t tileMaskStride,
                    ssd_frame_risers *out, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s);
 }
 

@@ -121,7 +121,7 @@ long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, 
     layout[2] = offsetof(FrameState, lut);
     layout[3] = offsetof(FrameState, imgYMin);
     layout[4] = offsetof(FrameState, pl);
-    layout[5] = offsetof(FrameState, qt);
+    layout[5] = offsetof(FrameState, qtLive);
     layout[6] = offsetof(FrameState, sumZ);
     layout[7] = offsetof(FrameState, cnt);
   }
