@@ -366,6 +366,23 @@ def main():
                                                  "sample": "%d frames (%d distinct), one frame per thread, %.1f s wall" % (len(work), len(keep), adt)}
             out["parity"] = {"frames_checked_against_oracle": checked, "max_abs_height_err_m": rep.get("max_height_err", 0.0),
                              "max_abs_corner_err_m": rep.get("max_corner_err", 0.0), "bar_m": 1e-4}
+        if world == 1 and not depth_in:
+            # BASELINE configs[1]: ONE frame resident in HBM through the whole path (enqueue + fetch); GPU-latency-bound
+            one = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=1), trans, device)
+            one.set_timing(True)
+            lat, st1 = [], {k: 0.0 for k in ssd.STAGE_NAMES}
+            for i in range(8 + 48):
+                c0 = time.perf_counter()
+                one.enqueue(frames.data_ptr(), 1, stream=stream)
+                one.fetch(1)
+                if i >= 8:
+                    lat.append(time.perf_counter() - c0)
+                    for k, v in one.stage_times_ms().items():
+                        st1[k] += v / 48
+            one.close()
+            out["single_frame"] = {"latency_ms_device_resident": sorted(lat)[len(lat) // 2] * 1e3, "stage_ms": st1,
+                                   "note": "one %dx%d frame already in HBM, ssd_enqueue + ssd_fetch (7 launches, state memset, result copy); "
+                                           "median of 48; bounded by the GPU-side latency of the launches' serial sections, not by HBM" % (W, H)}
         if world == 1 and not args.no_hostfed and not fhd:
             det.close()
             del frames

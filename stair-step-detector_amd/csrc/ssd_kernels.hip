@@ -433,70 +433,92 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
     total += __shfl_xor(total, o);
   __syncthreads();
 
+  /* findPeaks (pointcloud.cpp:214-241) + filterPeaks (:243-256), all lanes: lane l looks at bins l and l + 64.  The
+   * reference walks the bins with one carried flag: a bin is a peak when the count falls after it and the last CHANGE
+   * before it was a rise (so a flat top reports its last index, quirk Q1).  Here: rise / fall bits of all bins by two
+   * ballots each, then "the highest changed bin below me is a rise" by bit scans. */
+  unsigned long long peakBits[2];
+  {
+    unsigned long long up[2], down[2];
+#pragma unroll
+    for(int w = 0; w < 2; w++)
+    {
+      const int i = lane + 64 * w;
+      const bool inRange = i < nb - 1;
+      const unsigned int c = hist[min(i, kMaxBins - 1)], succ = hist[min(i + 1, kMaxBins)];
+      up[w] = __ballot(inRange && c < succ);
+      down[w] = __ballot(inRange && c > succ);
+    }
+    const unsigned long long changed[2] = { up[0] | down[0], up[1] | down[1] };
+#pragma unroll
+    for(int w = 0; w < 2; w++)
+    {
+      const int i = lane + 64 * w;
+      bool peak = false;
+      if((down[w] >> lane) & 1ull)
+      {
+        const unsigned long long below = changed[w] & ((1ull << lane) - 1ull);
+        bool lastWasRise = false;
+        if(below)
+          lastWasRise = (up[w] >> (63 - __clzll(static_cast<long long>(below)))) & 1ull;
+        else if(w == 1 && changed[0])
+          lastWasRise = (up[0] >> (63 - __clzll(static_cast<long long>(changed[0])))) & 1ull;
+        if(lastWasRise)
+        {
+          const unsigned int np = hist[i];
+          peak = np >= 2000u && (np * 2u - hist[i - 1] - hist[i + 1]) * 2u > np;     /* filterPeaks; i >= 1 after a rise */
+        }
+      }
+      peakBits[w] = __ballot(peak);
+    }
+  }
+
   if(lane == 0)
   {
-    /* findPeaks (pointcloud.cpp:214-241) + filterPeaks (:243-256) */
     int nPl = 0;
     int consumedUpTo = -1;           /* every bin <= this has already left pointsHt */
-    bool ascending = false, overflow = false;
+    bool overflow = false;
     int nPeaksDbg = 0;
-    unsigned int curr = hist[0];
-    for(int i = 0; i < nb - 1; i++)
-    {
-      const unsigned int succ = hist[i + 1];
-      const unsigned int c = curr;
-      curr = succ;
-      if(c < succ)
+    for(int w = 0; w < 2; w++)
+      for(unsigned long long bits = peakBits[w]; bits; bits &= bits - 1ull)
       {
-        ascending = true;
-        continue;
-      }
-      if(c > succ)
-      {
-        if(ascending)
+        const int i = 64 * w + __ffsll(static_cast<long long>(bits)) - 1;
+        const unsigned int succ = hist[i + 1];
+        if(nPeaksDbg < kMaxPlateaus)
+          dbgPeaks[nPeaksDbg] = i;
+        nPeaksDbg++;
+        if(nPl >= kMaxPlateaus)
+          overflow = true;
+        else
         {
-          const unsigned int np = c;
-          if(np >= 2000u && (np * 2u - hist[i - 1] - succ) * 2u > np)
+          /* extractPlateauPoints (:300-335): choose the pair, then take what is left of it */
+          int hMin, hMax;
+          if(hist[i - 1] > succ) { hMin = i - 1; hMax = i; }
+          else { hMin = i; hMax = i + 1; }
+          int lo, hi;
+          if(hMin == 0)
           {
-            if(nPeaksDbg < kMaxPlateaus)
-              dbgPeaks[nPeaksDbg] = i;
-            nPeaksDbg++;
-            if(nPl >= kMaxPlateaus)
-              overflow = true;
-            else
-            {
-              /* extractPlateauPoints (:300-335): choose the pair, then take what is left of it */
-              int hMin, hMax;
-              if(hist[i - 1] > succ) { hMin = i - 1; hMax = i; }
-              else { hMin = i; hMax = i + 1; }
-              int lo, hi;
-              if(hMin == 0)
-              {
-                /* quirk Q4: Height_t(heightMin - 1) wraps to 65535: everything goes to the remainder */
-                lo = 1; hi = 0;
-                consumedUpTo = nb;
-              }
-              else
-              {
-                lo = max(hMin, consumedUpTo + 1);
-                hi = hMax;
-                consumedUpTo = max(consumedUpTo, hMax);
-              }
-              unsigned int cnt = 0;
-              for(int b = lo; b <= hi; b++)
-              {
-                cnt += hist[b];
-                lut[b] = static_cast<unsigned char>(nPl);
-              }
-              plPeak[nPl] = i; plLo[nPl] = hMin; plHi[nPl] = hMax; plEffLo[nPl] = lo; plEffHi[nPl] = hi;
-              plN[nPl] = static_cast<int>(cnt);
-              nPl++;
-            }
+            /* quirk Q4: Height_t(heightMin - 1) wraps to 65535: everything goes to the remainder */
+            lo = 1; hi = 0;
+            consumedUpTo = nb;
           }
+          else
+          {
+            lo = max(hMin, consumedUpTo + 1);
+            hi = hMax;
+            consumedUpTo = max(consumedUpTo, hMax);
+          }
+          unsigned int cnt = 0;
+          for(int b = lo; b <= hi; b++)
+          {
+            cnt += hist[b];
+            lut[b] = static_cast<unsigned char>(nPl);
+          }
+          plPeak[nPl] = i; plLo[nPl] = hMin; plHi[nPl] = hMax; plEffLo[nPl] = lo; plEffHi[nPl] = hi;
+          plN[nPl] = static_cast<int>(cnt);
+          nPl++;
         }
-        ascending = false;
       }
-    }
 
     /* ground = most populous plateau below minHeight (pointcloud.cpp:402-418) */
     int groundInd = -1, i = 0;

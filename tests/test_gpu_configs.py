@@ -114,3 +114,19 @@ def test_bench_refuses_two_ranks_without_two_gpus():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "8", "--steps", "1", "--warmup", "0", "--no-cpu"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode != 0 and "n_gpus" not in p.stdout
+
+
+def test_native_driver_shards_frames_over_device_threads(ssd):
+    """detect-stairs-amd --device-list: one host thread + one handle per listed device, contiguous frame ranges, frames kept in
+    HBM; the lines must come out in frame order and equal the single-handle run's.  Three
+    shards on the one GPU of this box (a device may be listed more than once)."""
+    exe = os.path.join(os.path.dirname(ssd.LIB_PATH), "detect-stairs-amd")
+    args = [exe, "--width", "640", "--height", "480", "--frames", "10", "--steps", "3", "--seed", "99"]
+    single = subprocess.run(args, check=True, capture_output=True, text=True, timeout=600).stdout.splitlines()
+    sharded = subprocess.run(args + ["--device-list", "0,0,0"], check=True, capture_output=True, text=True, timeout=600)
+    assert sharded.stdout.splitlines() == single and len(single) == 10
+    assert "3 device shard(s)" in sharded.stderr
+    assert all(l.startswith('["stairs",["stairSteps",4]') for l in single)
+    bad = subprocess.run(args + ["--device-list", "0,7"], capture_output=True, text=True, timeout=600)
+    if ssd.device_count() < 8:
+        assert bad.returncode != 0 and "not present" in bad.stderr
