@@ -166,6 +166,8 @@ def main():
                     help="float3 = xyz vertices (the metric's input); depth16 = 16-bit depth frames deprojected on the fly (SURVEY 8f rank 1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-hostfed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg reported beside `value`")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (profiling passes: its 56 one-frame "
+                                                               "launches would be averaged into the per-kernel statistics)")
     ap.add_argument("--risers", action="store_true",
                     help="also gather the evidence of the vertical faces (extension beyond the reference, SURVEY 8f rank 4); off for the metric")
     args = ap.parse_args()
@@ -366,7 +368,7 @@ def main():
                                                  "sample": "%d frames (%d distinct), one frame per thread, %.1f s wall" % (len(work), len(keep), adt)}
             out["parity"] = {"frames_checked_against_oracle": checked, "max_abs_height_err_m": rep.get("max_height_err", 0.0),
                              "max_abs_corner_err_m": rep.get("max_corner_err", 0.0), "bar_m": 1e-4}
-        if world == 1 and not depth_in:
+        if world == 1 and not depth_in and not args.no_latency:
             # BASELINE configs[1]: ONE frame resident in HBM through the whole path (enqueue + fetch); GPU-latency-bound
             one = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=1), trans, device)
             one.set_timing(True)

@@ -151,16 +151,22 @@ __device__ __forceinline__ void load_points(const float *__restrict__ base, int 
 /* The streaming kernels (K1, K2, K4) share one loop shape: a block owns a contiguous chunk of a frame and
  * walks it in tiles of 1024 points; the loads of the next tile are issued before the current tile is
  * processed (register double buffer), so that HBM requests stay in flight while the SIMDs do the fp64 work. */
-#define SSD_STREAM_LOOP(...)                                                                        \
+/* body(v) is called once per tile with the lane's four points.  Two register buffers used alternately (the loop is
+ * unrolled by two tiles) instead of one copied into the other after every tile: 12 moves fewer per tile. */
+#define SSD_STREAM_LOOP(body)                                                                       \
   {                                                                                                 \
-    F3 v[kPts], vn[kPts];                                                                           \
-    load_points<SRC>(base, begin + kPts * tid, end, v, D);                                         \
-    for(int i0 = begin; i0 < end; i0 += kTile)                                                      \
+    F3 va[kPts], vb[kPts];                                                                          \
+    load_points<SRC>(base, begin + kPts * tid, end, va, D);                                        \
+    for(int i0 = begin; i0 < end; i0 += 2 * kTile)                                                  \
     {                                                                                               \
       if(i0 + kTile < end)                                                                          \
-        load_points<SRC>(base, i0 + kTile + kPts * tid, end, vn, D);                               \
-      __VA_ARGS__                                                                                   \
-      _Pragma("unroll") for(int j = 0; j < kPts; j++) v[j] = vn[j];                                 \
+        load_points<SRC>(base, i0 + kTile + kPts * tid, end, vb, D);                               \
+      body(va);                                                                                     \
+      if(i0 + kTile >= end)                                                                         \
+        break;                                                                                      \
+      if(i0 + 2 * kTile < end)                                                                      \
+        load_points<SRC>(base, i0 + 2 * kTile + kPts * tid, end, va, D);                           \
+      body(vb);                                                                                     \
     }                                                                                               \
   }
 
@@ -337,10 +343,12 @@ __device__ __forceinline__ void hist_block(HistLds &L, const float *__restrict__
   unsigned int *mine = lh + (lane & (kHistCopies - 1));
   unsigned int nz = 0;
   int it = 0;
-  SSD_STREAM_LOOP(
+  auto tileBody = [&](const F3 (&v)[kPts])
+  {
     unsigned int groups = 0u;
     unsigned int boxMin = 0xffffffffu, boxMax = 0u;                     /* (x, y) of the in-range points on a 256 x 256 grid, packed u16 pairs */
-    _Pragma("unroll") for(int j = 0; j < kPts; j++)
+#pragma unroll
+    for(int j = 0; j < kPts; j++)
     {
       double wx, wy, wz;
       nz += v[j].z > 0.0f ? 1u : 0u;
@@ -361,7 +369,8 @@ __device__ __forceinline__ void hist_block(HistLds &L, const float *__restrict__
     if((lane & 15) == 0)                                         /* cell = 64 consecutive points = lanes 16q .. 16q+15 */
       lInfo[it * kCellsPerTile + (tid >> 4)] = make_uint2(groups, cell_box_pack(boxMin, boxMax));
     it++;
-  )
+  };
+  SSD_STREAM_LOOP(tileBody)
 
   /* wave-reduce the non-zero count */
 #pragma unroll
