@@ -207,21 +207,12 @@ __device__ __forceinline__ unsigned int row_or_u32(unsigned int v)
 /* K1 also leaves, per cell, the bounding box of its in-range points in world x / y on a 256 x 256 grid over the measuring
  * range (one byte per bound: x0, x1, y0, y1; a cell with no in-range point has an empty mask and a meaningless box).
  * k_inquad decides from it, without loading the cell, that all its points lie outside the ground quadrilateral, or all
- * inside a tread's (cell_box_world widens by a margin far above any rounding). */
+ * inside a tread's (its thresholds on this grid carry a margin far above any rounding: InquadLds::liveBox). */
 __device__ __forceinline__ unsigned int cell_box_pack(unsigned int mn, unsigned int mx)
 {
   const unsigned int x0 = min(mn & 0xffffu, 255u), y0 = min(mn >> 16, 255u), x1 = min(mx & 0xffffu, 255u), y1 = min(mx >> 16, 255u);
   return x0 | (x1 << 8) | (y0 << 16) | (y1 << 24);
 }
-__device__ __forceinline__ void cell_box_world(const PointParams &P, unsigned int box, double &x0, double &x1, double &y0, double &y1)
-{
-  const double ux = 1.0 / P.boxX, uy = 1.0 / P.boxY, margin = 1.0e-9;
-  x0 = P.xMin + static_cast<double>(box & 0xffu) * ux - margin;
-  x1 = P.xMin + static_cast<double>(((box >> 8) & 0xffu) + 1u) * ux + margin;
-  y0 = P.yMin + static_cast<double>((box >> 16) & 0xffu) * uy - margin;
-  y1 = P.yMin + static_cast<double>((box >> 24) + 1u) * uy + margin;
-}
-
 /* component-wise min / max of two u16 pairs packed in 32 bits (v_pk_min_u16 / v_pk_max_u16) */
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned int pk_min_u16(unsigned int a, unsigned int b)
@@ -1685,6 +1676,9 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
 __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__ st, int nframes, DebugFrame *__restrict__ dbg)
 {
   static_assert(kMaxPlateaus + 1 <= 64, "one lane per accumulator");
+  __shared__ QuadBuildScratch sScratch[kMaxPlateaus + 1];
+  __shared__ QuadTest sTest[kMaxPlateaus + 1];
+  __shared__ double sQuad[kMaxPlateaus + 1][8];
   const int frame = blockIdx.x, lane = threadIdx.x;
   if(frame >= nframes)
     return;
@@ -1724,13 +1718,14 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
   }
   if(groundLane || valid)
   {
-    /* built in private memory, stored once: the builder re-reads what it writes */
-    double quad[8];
-    QuadTest t;
+    /* built in LDS (the builder indexes its arrays at run time and re-reads what it writes: as locals they were scratch
+     * memory, 24 us per frame), stored to the frame's table once */
+    double (&quad)[8] = sQuad[lane];
+    QuadTest &t = sTest[lane];
     const double *src = groundLane ? fs.groundQuadWorld : fs.pl[lane].quadWorld;
     for(int k = 0; k < 8; k++)
       quad[k] = src[k];
-    build_quad_test(quad, t);
+    build_quad_test(quad, t, sScratch[lane]);
     err = t.err;
     /* one quadrilateral the reference would throw on ends the frame (quadrilateralTest.cpp:283-372) */
     const bool threwHere = __ballot(err != 0) != 0ull;
@@ -1818,6 +1813,7 @@ struct InquadLds
   unsigned short cellList[kMaxCellsPerBlockInquad];
   unsigned int listScratch[kWavesPerBlock];
   unsigned int liveGroups[kMaxLive];
+  int4 liveBox[kMaxLive];                       /* per live quadrilateral: thresholds of the cell classification on K1's grid */
   unsigned char liveAcc[kMaxLive];
   int nLive, groundSlot;
 };
@@ -1840,6 +1836,7 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
   unsigned short (&cellList)[kMaxCellsPerBlockInquad] = L.cellList;
   unsigned int (&listScratch)[kWavesPerBlock] = L.listScratch;
   unsigned int (&liveGroups)[kMaxLive] = L.liveGroups;
+  int4 (&liveBox)[kMaxLive] = L.liveBox;
   unsigned char (&liveAcc)[kMaxLive] = L.liveAcc;
   int &nLive = L.nLive;
   int &groundSlot = L.groundSlot;
@@ -1888,6 +1885,31 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
       dst[i] = src[i];
   }
   __syncthreads();
+  if(tid < nLive)
+  {
+    /* A cell's box [x0, x1] x [y0, y1] on the grid holds points with xMin + x0 / boxX <= x < xMin + (x1 + 1) / boxX (K1
+     * truncates).  Ground: wholly outside the quadrilateral's strict bounding box iff x1 <= b.x, x0 >= b.y, ... ; tread:
+     * wholly inside the constant cell iff x0 >= b.x, x1 <= b.y, ... — with a 1e-9 m margin against the truncation's rounding. */
+    const QuadTest &t = qts[tid];
+    const double m = 1.0e-9;
+    int4 b;
+    if(tid == groundSlot)
+    {
+      b.x = static_cast<int>(floor((t.bxLo - P.xMin - m) * P.boxX)) - 1;
+      b.y = static_cast<int>(ceil((t.bxUp - P.xMin + m) * P.boxX));
+      b.z = static_cast<int>(floor((t.byLo - P.yMin - m) * P.boxY)) - 1;
+      b.w = static_cast<int>(ceil((t.byUp - P.yMin + m) * P.boxY));
+    }
+    else
+    {
+      b.x = static_cast<int>(ceil((t.fx0 - P.xMin + m) * P.boxX));
+      b.y = static_cast<int>(floor((t.fx1 - P.xMin - m) * P.boxX)) - 1;
+      b.z = static_cast<int>(ceil((t.fy0 - P.yMin + m) * P.boxY));
+      b.w = static_cast<int>(floor((t.fy1 - P.yMin - m) * P.boxY)) - 1;
+    }
+    liveBox[tid] = b;
+  }
+  __syncthreads();
 
   /* strideFloats counts floats, or 16-bit depth values for kSrcDepth16 */
   const float *base = SRC == kSrcDepth16
@@ -1932,18 +1954,20 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
                                     {
                                       if((info.x & wantedQuads) == 0u)
                                         return false;
-                                      double x0, x1, y0, y1;
-                                      cell_box_world(P, info.y, x0, x1, y0, y1);
+                                      /* the box on K1's 256 x 256 grid against each live quadrilateral's thresholds on the
+                                       * same grid (liveBox, computed once per block from the doubles,
+                                       * margin included) */
+                                      const int x0 = info.y & 0xffu, x1 = (info.y >> 8) & 0xffu, y0 = (info.y >> 16) & 0xffu, y1 = info.y >> 24;
                                       bool need = false;
                                       for(int q = 0; q < nLive; q++)
                                       {
                                         if((info.x & liveGroups[q]) == 0u)
                                           continue;
-                                        const QuadTest &t = qts[q];
+                                        const int4 b = liveBox[q];
                                         if(q == gSlot)
-                                          need = need || !(x1 <= t.bxLo || x0 >= t.bxUp || y1 <= t.byLo || y0 >= t.byUp);
+                                          need = need || !(x1 <= b.x || x0 >= b.y || y1 <= b.z || y0 >= b.w);      /* not wholly outside */
                                         else
-                                          need = need || !(x0 >= t.fx0 && x1 < t.fx1 && y0 >= t.fy0 && y1 < t.fy1);
+                                          need = need || !(x0 >= b.x && x1 <= b.y && y0 >= b.z && y1 <= b.w);      /* not wholly inside */
                                       }
                                       return need;
                                     }, cellList, listScratch);

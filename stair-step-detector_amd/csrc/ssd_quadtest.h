@@ -30,8 +30,18 @@ __device__ __forceinline__ bool sector_overlaps(double lo, double up, double olo
   return lo < oup && up > olo;
 }
 
+/* the builder's working arrays: indexed at run time, so as locals they would live in scratch (global) memory — k_quads
+ * passes a slice of LDS instead (a frame's quadrilaterals are built by one lane each, one wave per frame: latency) */
+struct QuadBuildScratch
+{
+  SegTmp box[4];
+  double xs[4], ys[4], rowUpper[3], cellUpper[3][3];
+  int nCells[3];
+  unsigned char cellMask[3][3], cellCnt[3][3], cellConst[3][3];
+};
+
 /* QuadrilateralTest::QuadrilateralTest (quadrilateralTest.cpp:275-443) flattened into tables */
-__device__ inline void build_quad_test(const double *q /* 4 x (x,y) */, QuadTest &t)
+__device__ inline void build_quad_test(const double *q /* 4 x (x,y) */, QuadTest &t, QuadBuildScratch &w)
 {
   t.err = 0;
   t.fx0 = 1.0; t.fx1 = 0.0; t.fy0 = 1.0; t.fy1 = 0.0;
@@ -42,7 +52,7 @@ __device__ inline void build_quad_test(const double *q /* 4 x (x,y) */, QuadTest
 
   /* segments counterclockwise: 0->1, 1->3, 3->2, 2->0 */
   const int sp[4] = { 0, 1, 3, 2 }, sq[4] = { 1, 3, 2, 0 };
-  SegTmp box[4];
+  SegTmp (&box)[4] = w.box;
   for(int s = 0; s < 4; s++)
   {
     const double px = q[2 * sp[s]], py = q[2 * sp[s] + 1], qx = q[2 * sq[s]], qy = q[2 * sq[s] + 1];
@@ -78,7 +88,9 @@ __device__ inline void build_quad_test(const double *q /* 4 x (x,y) */, QuadTest
     return;
   }
 
-  double xs[4] = { q[0], q[2], q[4], q[6] }, ys[4] = { q[1], q[3], q[5], q[7] };
+  double (&xs)[4] = w.xs, (&ys)[4] = w.ys;
+  xs[0] = q[0]; xs[1] = q[2]; xs[2] = q[4]; xs[3] = q[6];
+  ys[0] = q[1]; ys[1] = q[3]; ys[2] = q[5]; ys[3] = q[7];
   for(int i = 1; i < 4; i++)                 /* insertion sort of 4 */
   {
     const double vx = xs[i], vy = ys[i];
@@ -91,10 +103,10 @@ __device__ inline void build_quad_test(const double *q /* 4 x (x,y) */, QuadTest
   }
 
   int nRows = 0;
-  double rowUpper[3];
-  int nCells[3];
-  double cellUpper[3][3];
-  unsigned char cellMask[3][3], cellCnt[3][3], cellConst[3][3];
+  double (&rowUpper)[3] = w.rowUpper;
+  int (&nCells)[3] = w.nCells;
+  double (&cellUpper)[3][3] = w.cellUpper;
+  unsigned char (&cellMask)[3][3] = w.cellMask, (&cellCnt)[3][3] = w.cellCnt, (&cellConst)[3][3] = w.cellConst;
   double lowerY = ys[0];
   for(int yi = 1; yi < 4; yi++)
   {
@@ -211,6 +223,12 @@ __device__ inline void build_quad_test(const double *q /* 4 x (x,y) */, QuadTest
       }
     }
   }
+}
+
+__device__ inline void build_quad_test(const double *q, QuadTest &t)
+{
+  QuadBuildScratch w;
+  build_quad_test(q, t, w);
 }
 
 /* QuadrilateralTest::isPointWithin (quadrilateralTest.cpp:445-451 and the selector lambdas :487-571) */

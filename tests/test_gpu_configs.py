@@ -130,3 +130,36 @@ def test_native_driver_shards_frames_over_device_threads(ssd):
     bad = subprocess.run(args + ["--device-list", "0,7"], capture_output=True, text=True, timeout=600)
     if ssd.device_count() < 8:
         assert bad.returncode != 0 and "not present" in bad.stderr
+
+
+def test_host_fed_ingest_slices_pinned_and_pageable(ssd, oracle, gpu_device):
+    """ssd_process_host / ssd_process_depth_host on 70 VGA frames = three ingest slices (32 + 32 + 6) over two staging
+    buffers, from pinned (ssd_host_alloc) and from pageable memory, as vertices and as 16-bit depth: every result equals the
+    single-frame call's bytewise, and every 10th frame the oracle's."""
+    n, W, H = 70, 640, 480
+    sc_list = scenes.batch_scenes(ssd, W, H, n, base_seed=31000, rng_seed=5)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    cfg = ssd.default_config(W, H, max_frames_per_batch=64)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    intr = ssd.intrinsics_for_scene(sc_list[0])
+    det.set_intrinsics(intr)
+    xyz = ssd.synth_host(sc_list)
+    depth = ssd.synth_depth_host(sc_list)
+    pin_x = ssd.PinnedArray(xyz.shape, np.float32)
+    pin_x.array[...] = xyz
+    pin_d = ssd.PinnedArray(depth.shape, np.uint16)
+    pin_d.array[...] = depth
+    ref_x = [det.process_host(xyz[i])[0] for i in range(n)]
+    ref_d = [det.process_depth_host(depth[i])[0] for i in range(n)]
+    for arr, run, ref in ((xyz, det.process_host, ref_x), (pin_x.array, det.process_host, ref_x),
+                          (depth, det.process_depth_host, ref_d), (pin_d.array, det.process_depth_host, ref_d)):
+        for _ in range(2):                                     # twice: the staging buffers and the workspace are reused
+            got = run(arr)
+            assert len(got) == n
+            assert [bytes(g) for g in got] == [bytes(r) for r in ref]
+    for i in range(0, n, 10):
+        parity.check_results_only(ssd, oracle, cfg, trans.constants, xyz[i], ref_x[i])
+        parity.check_results_only(ssd, oracle, cfg, trans.constants, oracle.deproject(intr, depth[i]), ref_d[i])
+    pin_x.free()
+    pin_d.free()
+    det.close()
