@@ -1663,8 +1663,7 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
     {
       const int ry = idx / cw;
       const size_t o = static_cast<size_t>(cy0 + ry) * P.W64 + cc0 + (idx - ry * cw);
-      if(img[o])
-        img[o] = 0ull;
+      img[o] = 0ull;                                 /* unconditionally: a load first would make every word a round trip */
     }
   }
 }
@@ -2360,8 +2359,7 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
     {
       const int ry = idx / cw;
       const size_t o = static_cast<size_t>(cy0 + ry) * P.W64 + cc0 + (idx - ry * cw);
-      if(img[o])
-        img[o] = 0ull;
+      img[o] = 0ull;                                 /* unconditionally: a load first would make every word a round trip */
     }
   }
 }
