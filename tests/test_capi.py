@@ -88,6 +88,19 @@ def test_compute_entry_points_fail_loudly_without_gpu(ssd):
         ssd.Detector(cfg, ssd.GeometricTransformation())
     with pytest.raises(ssd.SsdError):
         ssd.Pointcloud(ssd.Window("w"), ssd.GeometricTransformation()).process(np.zeros((480, 640, 3), np.float32))
+    with pytest.raises(ssd.SsdError, match="no HIP device"):
+        ssd.PinnedArray((4, 4), np.float32)                       # ssd_host_alloc
+    with pytest.raises(ssd.SsdError, match="no HIP device"):
+        ssd.DeviceBuffer(1024)                                    # ssd_device_alloc
+    sc = ssd.make_scene(64, 48)
+    with pytest.raises(ssd.SsdError, match="no HIP device"):
+        ssd.synth_device([sc], 4096)                              # the frame source's device generator (libssd_source.so)
+    # the reference's main over this build (lib/detect-stairs-ref) ends with an error, not with a made-up line
+    import subprocess
+    exe = os.path.join(os.path.dirname(ssd.LIB_PATH), "detect-stairs-ref")
+    if os.path.exists(exe):
+        p = subprocess.run([exe], capture_output=True, text=True, timeout=120, cwd=os.path.dirname(exe))
+        assert p.returncode != 0 and "stairs" not in p.stdout
 
 
 def test_create_rejects_bad_arguments(ssd):
