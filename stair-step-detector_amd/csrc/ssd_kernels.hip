@@ -82,6 +82,11 @@ __device__ __forceinline__ int height_bin(const PointParams &P, double wz)
 /* ========================================================================= */
 /* K1: histogram                                                              */
 
+/* k_raster is built for 7 waves per SIMD: 72 VGPRs / 96 SGPRs end its scratch spills (measured: XGA batch 1.015 -> 1.006 ms,
+ * FHD stress 1.083 -> 1.037; 6 waves: slower again) */
+#ifndef SSD_K2_WAVES
+#define SSD_K2_WAVES 7
+#endif
 constexpr int kThreads = 256;
 constexpr int kPts = 4;                 /* points per thread per iteration: four CONSECUTIVE points (48 B) */
 constexpr int kTile = kThreads * kPts;  /* 1024 points per block iteration */
@@ -957,7 +962,7 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
 }
 
 template<int SRC>
-__global__ __launch_bounds__(kThreads, 8) void k_raster(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
+__global__ __launch_bounds__(kThreads, SSD_K2_WAVES) void k_raster(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                         PixelParams X, FrameState *__restrict__ st,
                                                         unsigned long long *__restrict__ stepImg,
                                                         const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
