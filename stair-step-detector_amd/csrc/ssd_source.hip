@@ -6,9 +6,11 @@
  */
 #include "ssd_synth.h"
 
+#include <charconv>
 #include <cmath>
 #include <cstdio>
 #include <string>
+#include <utility>
 
 using namespace ssd;
 
@@ -230,31 +232,45 @@ int ssd_source_write_calibration(const ssd_scene *scene, const double world_mark
 {
   if(!scene || !world_marks || !directory)
     return fail(SSD_E_ARG, "ssd_source_write_calibration: null argument");
+  /* numbers through std::to_chars: the files must read back with operator>> in the classic locale whatever LC_NUMERIC the
+   * host application has set (a decimal comma would end the reference's parse) */
+  auto num = [](double v, bool asFloat)
+  {
+    char buf[64];
+    const std::to_chars_result r = asFloat ? std::to_chars(buf, buf + sizeof(buf), static_cast<float>(v))
+                                           : std::to_chars(buf, buf + sizeof(buf), v);
+    return std::string(buf, r.ptr);
+  };
   const std::string dir(directory);
-  FILE *t = std::fopen((dir + "/calibration-triangle").c_str(), "w");
-  if(!t)
-    return fail(SSD_E_ARG, "ssd_source_write_calibration: cannot write calibration-triangle");
-  std::fprintf(t, "calibration triangle\n");
+  std::string tri = "calibration triangle\n";
   for(int n = 0; n < 3; n++)
-    std::fprintf(t, "x%d = %.17g, y%d = %.17g, z%d = %.17g\n", n + 1, world_marks[3 * n], n + 1, world_marks[3 * n + 1], n + 1, world_marks[3 * n + 2]);
-  std::fprintf(t, "lowerQuadrant = right\n");
-  std::fclose(t);
-  FILE *p = std::fopen((dir + "/calibration-points").c_str(), "w");
-  if(!p)
-    return fail(SSD_E_ARG, "ssd_source_write_calibration: cannot write calibration-points");
-  std::fprintf(p, "calibration points\n");
-  float cam[9];
+  {
+    const std::string k = std::to_string(n + 1);
+    tri += "x" + k + " = " + num(world_marks[3 * n], false) + ", y" + k + " = " + num(world_marks[3 * n + 1], false) + ", z" + k + " = " +
+           num(world_marks[3 * n + 2], false) + "\n";
+  }
+  tri += "lowerQuadrant = right\n";
+  std::string pts = "calibration points\n", row;
   for(int n = 0; n < 3; n++)
   {
     const double ground[3] = { world_marks[3 * n], world_marks[3 * n + 1], 0.0 };     /* the marks lie on the ground */
     double c[3];
     ssd_synth_scene_to_camera(scene, ground, c);
-    for(int k = 0; k < 3; k++)
-      cam[3 * n + k] = static_cast<float>(c[k]);                                      /* MarkerPoint3_t = Point3f */
+    row += num(c[0], true) + ", " + num(c[1], true) + ", " + num(c[2], true) + (n < 2 ? "; " : "\n");   /* MarkerPoint3_t = Point3f */
   }
-  for(int row = 0; row < 10; row++)                                                   /* __numIterations = 10 */
-    std::fprintf(p, "%.9g, %.9g, %.9g; %.9g, %.9g, %.9g; %.9g, %.9g, %.9g\n", cam[0], cam[1], cam[2], cam[3], cam[4], cam[5], cam[6], cam[7], cam[8]);
-  std::fclose(p);
+  for(int k = 0; k < 10; k++)                                                         /* __numIterations = 10 */
+    pts += row;
+  const std::pair<const char *, const std::string *> files[2] = { { "/calibration-triangle", &tri }, { "/calibration-points", &pts } };
+  for(const auto &f : files)
+  {
+    FILE *fp = std::fopen((dir + f.first).c_str(), "w");
+    if(!fp || std::fwrite(f.second->data(), 1, f.second->size(), fp) != f.second->size())
+    {
+      if(fp) std::fclose(fp);
+      return fail(SSD_E_ARG, std::string("ssd_source_write_calibration: cannot write ") + (dir + f.first));
+    }
+    std::fclose(fp);
+  }
   return SSD_OK;
 }
 
