@@ -603,7 +603,8 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
     int tiles = env_int("SSD_K2_CHUNK_TILES", 32);
     if(tiles > kMaxTilesPerBlockRasterHost) tiles = kMaxTilesPerBlockRasterHost;
     const long long totalTiles = (static_cast<long long>(P.nPoints) + kTileHost - 1) / kTileHost * nframes;
-    while(tiles > chunk / kTileHost && totalTiles / tiles < 4096)
+    const int minBlocks = env_int("SSD_K2_MIN_BLOCKS", 4096);
+    while(tiles > chunk / kTileHost && totalTiles / tiles < minBlocks)
       tiles /= 2;
     if(tiles * kTileHost > chunkRaster)
       chunkRaster = tiles * kTileHost;
@@ -614,7 +615,8 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
     int tiles = env_int("SSD_K4_CHUNK_TILES", 32);
     if(tiles > kMaxTilesPerBlockInquadHost) tiles = kMaxTilesPerBlockInquadHost;
     const long long totalTiles = (static_cast<long long>(P.nPoints) + kTileHost - 1) / kTileHost * nframes;
-    while(tiles > chunk / kTileHost && totalTiles / tiles < 8192)
+    const int minBlocks = env_int("SSD_K4_MIN_BLOCKS", 8192);
+    while(tiles > chunk / kTileHost && totalTiles / tiles < minBlocks)
       tiles /= 2;
     if(tiles * kTileHost > chunkInquad)
       chunkInquad = tiles * kTileHost;
