@@ -597,29 +597,21 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   const DepthSrc depthSrc{ h->dDepthMaps, h->dDepthMaps ? h->dDepthMaps + P.W : nullptr, h->intr.depth_units, P.W, P.H };
   const DepthSrc *depth = depthInput ? &depthSrc : nullptr;
   const int chunk = choose_chunk(P.nPoints, nframes);
-  /* K2 walks cell columns: the taller its chunks the fewer window flushes — as long as the launch keeps >= 4096 blocks */
-  int chunkRaster = chunk;
+  /* K2 and K4 walk cell columns: the taller a block's chunk, the fewer window flushes and block starts per cell — worth more
+   * than block count as long as the launch keeps a few hundred blocks (measured, XGA, tools/exp_frames.sh: 16 frames
+   * 39.8 k -> 52.1 k frames/s, 64 frames 112 k -> 126 k; from 256 frames on the general chunk is as tall already).
+   * K2: up to 32 tiles; K4 (a third of the cells, more state per block): up to 16. */
+  int chunkRaster = chunk, chunkInquad = chunk;
   {
-    int tiles = env_int("SSD_K2_CHUNK_TILES", 32);
-    if(tiles > kMaxTilesPerBlockRasterHost) tiles = kMaxTilesPerBlockRasterHost;
     const long long totalTiles = (static_cast<long long>(P.nPoints) + kTileHost - 1) / kTileHost * nframes;
-    const int minBlocks = env_int("SSD_K2_MIN_BLOCKS", 4096);
-    while(tiles > chunk / kTileHost && totalTiles / tiles < minBlocks)
-      tiles /= 2;
-    if(tiles * kTileHost > chunkRaster)
-      chunkRaster = tiles * kTileHost;
-  }
-  /* K4 walks a third of the cells: taller chunks amortise a block's start (copy of the live table, list of its cells) */
-  int chunkInquad = chunk;
-  {
-    int tiles = env_int("SSD_K4_CHUNK_TILES", 32);
-    if(tiles > kMaxTilesPerBlockInquadHost) tiles = kMaxTilesPerBlockInquadHost;
-    const long long totalTiles = (static_cast<long long>(P.nPoints) + kTileHost - 1) / kTileHost * nframes;
-    const int minBlocks = env_int("SSD_K4_MIN_BLOCKS", 8192);
-    while(tiles > chunk / kTileHost && totalTiles / tiles < minBlocks)
-      tiles /= 2;
-    if(tiles * kTileHost > chunkInquad)
-      chunkInquad = tiles * kTileHost;
+    const int minBlocks = env_int("SSD_K24_MIN_BLOCKS", 600);
+    int t2 = env_int("SSD_K2_CHUNK_TILES", 32), t4 = env_int("SSD_K4_CHUNK_TILES", 16);
+    if(t2 > kMaxTilesPerBlockRasterHost) t2 = kMaxTilesPerBlockRasterHost;
+    if(t4 > kMaxTilesPerBlockInquadHost) t4 = kMaxTilesPerBlockInquadHost;
+    while(t2 > 1 && totalTiles / t2 < minBlocks) t2 /= 2;
+    while(t4 > 1 && totalTiles / t4 < minBlocks) t4 /= 2;
+    if(t2 * kTileHost > chunkRaster) chunkRaster = t2 * kTileHost;
+    if(t4 * kTileHost > chunkInquad) chunkInquad = t4 * kTileHost;
   }
   DebugFrame *dbg = h->debug ? h->dDebug : nullptr;
   unsigned long long *dbgImg = h->debug ? h->dDebugImg : nullptr;
