@@ -183,7 +183,7 @@ __device__ __forceinline__ void load_points(const float *__restrict__ base, int 
  * tools/storebench.hip).  The later passes gather the cells that hold a bin they care about into a compact
  * list per block and walk only those (cell_list_build / SSD_CELL_LOOP below): nothing else is loaded, and
  * every wave iteration works on four wanted cells instead of on 256 consecutive points of which half are
- * somebody else's (wave-tile gating: 52 % of the tiles at 57 % lane use in K2; cells: 34 % at 88 %). */
+ * somebody else's (wave-tile gating: 52 % of the tiles at 52 % lane use in K2; cells: 34 % at 79 %; tools/cell_analysis.py). */
 constexpr int kBinsPerGroup = 4;      /* 128 bins -> 32 groups: one 32-bit mask per cell */
 constexpr int kWavesPerBlock = kThreads / 64;
 constexpr int kCell = 64;                         /* points per cell */
