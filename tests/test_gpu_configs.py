@@ -163,3 +163,44 @@ def test_host_fed_ingest_slices_pinned_and_pageable(ssd, oracle, gpu_device):
     pin_x.free()
     pin_d.free()
     det.close()
+
+
+def test_calls_on_different_streams_are_ordered_by_the_library(ssd, oracle, gpu_device):
+    """A handle's workspace is single-buffered: an enqueue on one stream followed at once by work on another
+    (a second user stream, then ssd_process_host's own ingest streams, then the default stream) must see its predecessor
+    finished — the library inserts the event wait.  Every result must equal the oracle's."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")          # the runtime libssd_hip.so already runs on (torch would bring its own copy into this process)
+    streams = []
+    for _ in range(2):
+        st = C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(st), 1) == 0          # hipStreamNonBlocking
+        streams.append(st)
+    n, W, H = 24, 640, 480
+    sc_list = scenes.batch_scenes(ssd, W, H, 2 * n, base_seed=52000, rng_seed=9)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    cfg = ssd.default_config(W, H, max_frames_per_batch=n)
+    host = ssd.synth_host(sc_list)
+    a = ssd.DeviceBuffer(W * H * 12 * n, gpu_device)
+    b = ssd.DeviceBuffer(W * H * 12 * n, gpu_device)
+    a.upload(host[:n])
+    b.upload(host[n:])
+    det = ssd.Detector(cfg, trans, gpu_device)
+    for rep in range(3):
+        det.enqueue(a.ptr, n, stream=streams[0].value)
+        det.enqueue(b.ptr, n, stream=streams[1].value)         # other stream, no host synchronisation in between
+        rb = det.fetch_list(n)
+        ra = [ssd.FrameResult.from_buffer_copy(r) for r in det.fetch(n, back=1)]
+        rh = det.process_host(host[:n])                         # the ingest streams
+        det.enqueue(b.ptr, n)                                   # the default stream
+        rb2 = det.fetch_list(n)
+        for i in range(0, n, 5):
+            parity.check_results_only(ssd, oracle, cfg, trans.constants, host[i], ra[i])
+            parity.check_results_only(ssd, oracle, cfg, trans.constants, host[n + i], rb[i])
+        assert [bytes(x) for x in rh] == [bytes(x) for x in ra]
+        assert [bytes(x) for x in rb2] == [bytes(x) for x in rb]
+    det.close()
+    a.free()
+    b.free()
+    for st in streams:
+        hip.hipStreamDestroy(st)
