@@ -43,8 +43,14 @@ for F in [int(a) for a in sys.argv[1:]] or [16, 64, 256]:
         torch.cuda.synchronize()
         return reps * F / (time.perf_counter() - t0)
 
-    one, two = run(1), run(2)
-    out[F] = {"one_handle_frames_per_s": round(one), "two_handles_frames_per_s": round(two), "gain": round(two / one, 3)}
+    for d in dets:
+        d.set_timing(True)
+    one = run(1)
+    st1 = {k: round(sum(dets[0].stage_times_ms(b)[k] for b in range(4)) / 4, 4) for k in ssd.STAGE_NAMES}
+    two = run(2)
+    st2 = {k: round(sum(dets[j].stage_times_ms(b)[k] for j in range(2) for b in range(2)) / 4, 4) for k in ssd.STAGE_NAMES}
+    out[F] = {"one_handle_frames_per_s": round(one), "two_handles_frames_per_s": round(two), "gain": round(two / one, 3),
+              "stage_ms_one": st1, "stage_ms_two": st2}
     for d in dets:
         d.close()
     buf.free()
