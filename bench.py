@@ -389,23 +389,16 @@ def main():
             # Two handles (each with its own workspace) on two streams, fed alternately, no timing events: the launches of one
             # batch fill the gaps the other's small, latency-bound kernels leave.  Reported beside `value`, which stays the
             # single-handle rate the roofline's live per-kernel durations belong to (timing events keep launches from overlapping).
-            import ctypes as C
-            hip = C.CDLL("libamdhip64.so")
-            lanes = []
-            for _ in range(2):
-                st = C.c_void_p()
-                hip.hipStreamCreateWithFlags(C.byref(st), 1)
-                lanes.append((ssd.Detector(cfg, trans, device), st))
+            pipe = ssd.Pipeline(cfg, trans, device, depth=2)
             torch.cuda.synchronize()
 
             def overlapped(n_steps):
                 for i in range(n_steps):
-                    d, st = lanes[i % 2]
-                    if i >= 2:
-                        d.fetch(F)
-                    d.enqueue(frames.data_ptr(), F, stream=st.value)
-                for d, _ in lanes[:min(2, n_steps)]:
-                    d.fetch(F)
+                    if pipe.pending() == 2:
+                        pipe.next(copy=False)
+                    pipe.submit(frames.data_ptr(), F)
+                while pipe.pending():
+                    pipe.next(copy=False)
 
             overlapped(2)
             torch.cuda.synchronize()
@@ -413,12 +406,10 @@ def main():
             overlapped(args.steps)
             torch.cuda.synchronize()
             odt = time.perf_counter() - c0
-            for d, st in lanes:
-                d.close()
-                hip.hipStreamDestroy(st)
-            out["overlapped_two_handles"] = {"value": F * args.steps / odt, "unit": "frames/s", "ms_per_step": odt / args.steps * 1e3,
-                                             "note": "same batch, same K steps, two ssd handles on two HIP streams fed alternately, per-stage "
-                                                     "timing events off (tools/two_handles.py; INTEGRATION.md section 4)"}
+            pipe.close()
+            out["pipelined_depth2"] = {"value": F * args.steps / odt, "unit": "frames/s", "ms_per_step": odt / args.steps * 1e3,
+                                             "note": "same batch, same K steps through ssd_pipeline_* with depth 2 (two handles on two HIP streams fed "
+                                                     "alternately, per-stage timing events off; INTEGRATION.md section 4)"}
         if world == 1 and not args.no_hostfed and not fhd:
             det.close()
             del frames

@@ -130,6 +130,8 @@ EXPORTS = [
     "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
     "ssd_device_count", "ssd_device_alloc", "ssd_device_free", "ssd_device_upload", "ssd_device_download",
     "ssd_device_sync", "ssd_host_alloc", "ssd_host_free",
+    "ssd_pipeline_create", "ssd_pipeline_destroy", "ssd_pipeline_submit", "ssd_pipeline_next", "ssd_pipeline_pending",
+    "ssd_pipeline_last_error",
 ]
 # libssd_source.so — the frame source standing in for the camera (include/ssd_source.h)
 SOURCE_EXPORTS = [
@@ -194,6 +196,12 @@ def lib():
     L.ssd_device_sync.argtypes = [i32]
     L.ssd_host_alloc.argtypes = [sz, C.POINTER(vp)]
     L.ssd_host_free.argtypes = [vp]
+    L.ssd_pipeline_create.argtypes = [C.POINTER(Config), C.POINTER(Calibration), i32, i32, C.POINTER(vp)]
+    L.ssd_pipeline_destroy.argtypes = [vp]
+    L.ssd_pipeline_submit.argtypes = [vp, vp, sz, i32]
+    L.ssd_pipeline_next.argtypes = [vp, C.POINTER(FrameResult), i32, C.POINTER(i32)]
+    L.ssd_pipeline_pending.argtypes = [vp]
+    L.ssd_pipeline_last_error.restype = C.c_char_p
     _lib = L
     return L
 
@@ -422,6 +430,53 @@ class Detector:
         out = np.empty((self.cfg.height, self.cfg.width), dtype=np.uint8)
         _check(lib().ssd_get_debug_image(self._h, frame, step_slot, 1 if closed else 0, out.ctypes.data_as(C.c_void_p)))
         return out
+
+
+class Pipeline:
+    """ssd_pipeline_*: `depth` handles on `depth` streams, batches dealt out round-robin, results in submission order."""
+
+    def __init__(self, cfg, trans, device=0, depth=2):
+        self.cfg, self.depth = cfg, depth
+        self._p = C.c_void_p()
+        cal = trans.constants if isinstance(trans, GeometricTransformation) else trans
+        rc = lib().ssd_pipeline_create(C.byref(cfg), C.byref(cal), device, depth, C.byref(self._p))
+        if rc < 0:
+            raise SsdError("ssd_pipeline_create: %d: %s" % (rc, lib().ssd_pipeline_last_error().decode()))
+        self._res = (FrameResult * cfg.max_frames_per_batch)()
+
+    def submit(self, d_ptr, nframes, stride_bytes=None):
+        rc = lib().ssd_pipeline_submit(self._p, C.c_void_p(d_ptr), stride_bytes or self.cfg.width * self.cfg.height * 12, nframes)
+        if rc < 0:
+            raise SsdError("ssd_pipeline_submit: %d: %s" % (rc, lib().ssd_pipeline_last_error().decode()))
+
+    def pending(self):
+        return lib().ssd_pipeline_pending(self._p)
+
+    def next(self, copy=True):
+        """-> the oldest unfetched batch's results: a list of independent FrameResult copies, or (copy=False) the frame count
+        with the results left in self.results (reused by the next call)"""
+        n = C.c_int(0)
+        rc = lib().ssd_pipeline_next(self._p, self._res, len(self._res), C.byref(n))
+        if rc < 0:
+            raise SsdError("ssd_pipeline_next: %d: %s" % (rc, lib().ssd_pipeline_last_error().decode()))
+        if not copy:
+            return n.value
+        return [FrameResult.from_buffer_copy(self._res[i]) for i in range(n.value)]
+
+    @property
+    def results(self):
+        return self._res
+
+    def close(self):
+        if self._p:
+            lib().ssd_pipeline_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Pointcloud:

@@ -204,3 +204,46 @@ def test_calls_on_different_streams_are_ordered_by_the_library(ssd, oracle, gpu_
     b.free()
     for st in streams:
         hip.hipStreamDestroy(st)
+
+
+def test_pipeline_overlaps_batches_and_returns_them_in_order(ssd, oracle, gpu_device):
+    """ssd_pipeline_*: two handles on two streams, batches dealt out round-robin.  Seven batches of different sizes through a
+    depth-2 pipeline come back in submission order, each bytewise what a single handle returns; a third unfetched submit is
+    refused (SSD_E_CAP) and every 7th frame equals the oracle's."""
+    W, H = 640, 480
+    sizes = [12, 5, 12, 1, 9, 12, 3]
+    sc_list = scenes.batch_scenes(ssd, W, H, sum(sizes), base_seed=61000, rng_seed=11)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    cfg = ssd.default_config(W, H, max_frames_per_batch=12)
+    fb = W * H * 12
+    buf = ssd.DeviceBuffer(fb * sum(sizes), gpu_device)
+    ssd.synth_device(sc_list, buf.ptr, device=gpu_device)
+    host = ssd.synth_host(sc_list)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    want, at = [], 0
+    for n in sizes:
+        det.enqueue(buf.ptr + at * fb, n)
+        want.append(det.fetch_list(n))
+        at += n
+    det.close()
+    pipe = ssd.Pipeline(cfg, trans, gpu_device, depth=2)
+    got, at = [], 0
+    for i, n in enumerate(sizes):
+        if pipe.pending() == 2:
+            got.append(pipe.next())
+        pipe.submit(buf.ptr + at * fb, n)
+        at += n
+    with pytest.raises(ssd.SsdError, match="unfetched"):
+        pipe.submit(buf.ptr, 1)                                    # both handles hold a batch
+    while pipe.pending():
+        got.append(pipe.next())
+    with pytest.raises(ssd.SsdError, match="nothing submitted"):
+        pipe.next()
+    pipe.close()
+    assert [len(g) for g in got] == sizes
+    for g, w in zip(got, want):
+        assert [bytes(x) for x in g] == [bytes(x) for x in w]
+    flat = [r for g in got for r in g]
+    for i in range(0, len(flat), 7):
+        parity.check_results_only(ssd, oracle, cfg, trans.constants, host[i], flat[i])
+    buf.free()
