@@ -150,7 +150,11 @@ int ssd_fetch_back(ssd_handle *h, ssd_frame_result *results, int nframes, int ba
 typedef struct ssd_pipeline ssd_pipeline;
 int ssd_pipeline_create(const ssd_config *cfg, const ssd_calibration *cal, int device, int depth, ssd_pipeline **out);
 int ssd_pipeline_destroy(ssd_pipeline *p);
+/* The pipeline's streams are its own (non-blocking): ssd_pipeline_submit expects the frames to be complete in device memory
+ * (their producer synchronised); ssd_pipeline_submit_after orders the batch behind the work `producer_stream` holds at the
+ * time of the call (use_producer != 0; producer_stream NULL = the default stream). */
 int ssd_pipeline_submit(ssd_pipeline *p, const void *d_xyz, size_t frame_stride_bytes, int nframes);
+int ssd_pipeline_submit_after(ssd_pipeline *p, const void *d_xyz, size_t frame_stride_bytes, int nframes, void *producer_stream, int use_producer);
 /* results of the OLDEST unfetched batch (waits for it); *nframes = its frame count; capacity = length of `results` */
 int ssd_pipeline_next(ssd_pipeline *p, ssd_frame_result *results, int capacity, int *nframes);
 int ssd_pipeline_pending(const ssd_pipeline *p);        /* batches submitted and not yet fetched */

@@ -130,7 +130,7 @@ EXPORTS = [
     "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
     "ssd_device_count", "ssd_device_alloc", "ssd_device_free", "ssd_device_upload", "ssd_device_download",
     "ssd_device_sync", "ssd_host_alloc", "ssd_host_free",
-    "ssd_pipeline_create", "ssd_pipeline_destroy", "ssd_pipeline_submit", "ssd_pipeline_next", "ssd_pipeline_pending",
+    "ssd_pipeline_create", "ssd_pipeline_destroy", "ssd_pipeline_submit", "ssd_pipeline_submit_after", "ssd_pipeline_next", "ssd_pipeline_pending",
     "ssd_pipeline_last_error",
 ]
 # libssd_source.so — the frame source standing in for the camera (include/ssd_source.h)
@@ -199,6 +199,7 @@ def lib():
     L.ssd_pipeline_create.argtypes = [C.POINTER(Config), C.POINTER(Calibration), i32, i32, C.POINTER(vp)]
     L.ssd_pipeline_destroy.argtypes = [vp]
     L.ssd_pipeline_submit.argtypes = [vp, vp, sz, i32]
+    L.ssd_pipeline_submit_after.argtypes = [vp, vp, sz, i32, vp, i32]
     L.ssd_pipeline_next.argtypes = [vp, C.POINTER(FrameResult), i32, C.POINTER(i32)]
     L.ssd_pipeline_pending.argtypes = [vp]
     L.ssd_pipeline_last_error.restype = C.c_char_p
@@ -444,8 +445,13 @@ class Pipeline:
             raise SsdError("ssd_pipeline_create: %d: %s" % (rc, lib().ssd_pipeline_last_error().decode()))
         self._res = (FrameResult * cfg.max_frames_per_batch)()
 
-    def submit(self, d_ptr, nframes, stride_bytes=None):
-        rc = lib().ssd_pipeline_submit(self._p, C.c_void_p(d_ptr), stride_bytes or self.cfg.width * self.cfg.height * 12, nframes)
+    def submit(self, d_ptr, nframes, stride_bytes=None, after_stream=False):
+        """after_stream: False = the frames are complete; None / an integer hipStream_t = order the batch behind that stream"""
+        stride = stride_bytes or self.cfg.width * self.cfg.height * 12
+        if after_stream is False:
+            rc = lib().ssd_pipeline_submit(self._p, C.c_void_p(d_ptr), stride, nframes)
+        else:
+            rc = lib().ssd_pipeline_submit_after(self._p, C.c_void_p(d_ptr), stride, nframes, C.c_void_p(after_stream or 0), 1)
         if rc < 0:
             raise SsdError("ssd_pipeline_submit: %d: %s" % (rc, lib().ssd_pipeline_last_error().decode()))
 

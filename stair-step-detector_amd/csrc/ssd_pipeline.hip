@@ -18,6 +18,7 @@ struct ssd_pipeline
   int device = 0, depth = 0;
   std::vector<ssd_handle *> handles;
   std::vector<hipStream_t> streams;
+  std::vector<hipEvent_t> produced;       /* ssd_pipeline_submit_after: recorded on the producer's stream */
   std::vector<int> frames;                /* frames of the batch each handle holds, 0 = idle */
   unsigned long long submitted = 0, fetched = 0;
 };
@@ -49,6 +50,8 @@ int ssd_pipeline_destroy(ssd_pipeline *p)
     ssd_destroy(h);
   for(hipStream_t s : p->streams)
     if(s) (void)hipStreamDestroy(s);
+  for(hipEvent_t e : p->produced)
+    if(e) (void)hipEventDestroy(e);
   delete p;
   return SSD_OK;
 }
@@ -79,13 +82,20 @@ int ssd_pipeline_create(const ssd_config *cfg, const ssd_calibration *cal, int d
       return pfail(SSD_E_HIP, "ssd_pipeline_create: hipStreamCreateWithFlags failed");
     }
     p->streams.push_back(s);
+    hipEvent_t e = nullptr;
+    if(hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+    {
+      ssd_pipeline_destroy(p);
+      return pfail(SSD_E_HIP, "ssd_pipeline_create: hipEventCreateWithFlags failed");
+    }
+    p->produced.push_back(e);
     p->frames.push_back(0);
   }
   *out = p;
   return SSD_OK;
 }
 
-int ssd_pipeline_submit(ssd_pipeline *p, const void *d_xyz, size_t frame_stride_bytes, int nframes)
+int ssd_pipeline_submit_after(ssd_pipeline *p, const void *d_xyz, size_t frame_stride_bytes, int nframes, void *producer_stream, int use_producer)
 {
   if(!p)
     return pfail(SSD_E_ARG, "ssd_pipeline_submit: null pipeline");
@@ -93,12 +103,24 @@ int ssd_pipeline_submit(ssd_pipeline *p, const void *d_xyz, size_t frame_stride_
   if(p->submitted - p->fetched >= static_cast<unsigned long long>(p->depth))
     return pfail(SSD_E_CAP, "ssd_pipeline_submit: every handle holds an unfetched batch: call ssd_pipeline_next first");
   const int k = static_cast<int>(p->submitted % static_cast<unsigned long long>(p->depth));
+  if(use_producer)
+  {
+    /* the pipeline's streams are its own: order this batch behind whatever the producer's stream holds now */
+    if(hipSetDevice(p->device) != hipSuccess || hipEventRecord(p->produced[k], static_cast<hipStream_t>(producer_stream)) != hipSuccess ||
+       hipStreamWaitEvent(p->streams[k], p->produced[k], 0) != hipSuccess)
+      return pfail(SSD_E_HIP, "ssd_pipeline_submit_after: could not order the batch behind the producer's stream");
+  }
   const int rc = ssd_enqueue(p->handles[k], d_xyz, frame_stride_bytes, nframes, p->streams[k]);
   if(rc != SSD_OK)
     return rc;
   p->frames[k] = nframes;
   p->submitted++;
   return SSD_OK;
+}
+
+int ssd_pipeline_submit(ssd_pipeline *p, const void *d_xyz, size_t frame_stride_bytes, int nframes)
+{
+  return ssd_pipeline_submit_after(p, d_xyz, frame_stride_bytes, nframes, nullptr, 0);
 }
 
 int ssd_pipeline_pending(const ssd_pipeline *p)

@@ -231,7 +231,7 @@ def test_pipeline_overlaps_batches_and_returns_them_in_order(ssd, oracle, gpu_de
     for i, n in enumerate(sizes):
         if pipe.pending() == 2:
             got.append(pipe.next())
-        pipe.submit(buf.ptr + at * fb, n)
+        pipe.submit(buf.ptr + at * fb, n, after_stream=None if i % 2 else False)     # alternately behind the default stream
         at += n
     with pytest.raises(ssd.SsdError, match="unfetched"):
         pipe.submit(buf.ptr, 1)                                    # both handles hold a batch
