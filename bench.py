@@ -389,27 +389,28 @@ def main():
             # Two handles (each with its own workspace) on two streams, fed alternately, no timing events: the launches of one
             # batch fill the gaps the other's small, latency-bound kernels leave.  Reported beside `value`, which stays the
             # single-handle rate the roofline's live per-kernel durations belong to (timing events keep launches from overlapping).
-            pipe = ssd.Pipeline(cfg, trans, device, depth=2)
-            torch.cuda.synchronize()
+            out["pipelined"] = {"note": "same batch, same K steps through ssd_pipeline_* (depth handles on depth HIP streams fed "
+                                         "round-robin, per-stage timing events off; INTEGRATION.md section 4)", "unit": "frames/s"}
+            for depth in (2, 4):
+                pipe = ssd.Pipeline(cfg, trans, device, depth=depth)
+                torch.cuda.synchronize()
 
-            def overlapped(n_steps):
-                for i in range(n_steps):
-                    if pipe.pending() == 2:
+                def overlapped(n_steps):
+                    for i in range(n_steps):
+                        if pipe.pending() == depth:
+                            pipe.next(copy=False)
+                        pipe.submit(frames.data_ptr(), F)
+                    while pipe.pending():
                         pipe.next(copy=False)
-                    pipe.submit(frames.data_ptr(), F)
-                while pipe.pending():
-                    pipe.next(copy=False)
 
-            overlapped(2)
-            torch.cuda.synchronize()
-            c0 = time.perf_counter()
-            overlapped(args.steps)
-            torch.cuda.synchronize()
-            odt = time.perf_counter() - c0
-            pipe.close()
-            out["pipelined_depth2"] = {"value": F * args.steps / odt, "unit": "frames/s", "ms_per_step": odt / args.steps * 1e3,
-                                             "note": "same batch, same K steps through ssd_pipeline_* with depth 2 (two handles on two HIP streams fed "
-                                                     "alternately, per-stage timing events off; INTEGRATION.md section 4)"}
+                overlapped(depth)
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                overlapped(args.steps)
+                torch.cuda.synchronize()
+                odt = time.perf_counter() - c0
+                pipe.close()
+                out["pipelined"]["depth%d" % depth] = {"value": F * args.steps / odt, "ms_per_step": odt / args.steps * 1e3}
         if world == 1 and not args.no_hostfed and not fhd:
             det.close()
             del frames

@@ -145,8 +145,8 @@ int ssd_fetch_back(ssd_handle *h, ssd_frame_result *results, int nframes, int ba
  * `depth` handles (each with its own workspace: memory = depth x ssd_workspace_bytes) on `depth` streams of its own and
  * deals the submitted batches out round-robin; results come back in submission order.  At most `depth` batches are
  * unfetched at any time (ssd_pipeline_submit returns SSD_E_CAP otherwise); the frames of a submitted batch must stay
- * untouched until its results were fetched.  depth 2 is where the gain is (XGA, frames/s: 64 frames per batch
- * 126 k -> 199 k, 256: 202 k -> 242 k, 1024: 247 k -> 255 k). */
+ * untouched until its results were fetched.  XGA, frames/s at depth 1 / 2 / 3 / 4: 64 frames per
+ * batch 130 k / 207 k / 235 k / 199 k, 256: 191 k / 238 k / 250 k / 245 k, 1024: 246 k / 258 k / 262 k / 271 k. */
 typedef struct ssd_pipeline ssd_pipeline;
 int ssd_pipeline_create(const ssd_config *cfg, const ssd_calibration *cal, int device, int depth, ssd_pipeline **out);
 int ssd_pipeline_destroy(ssd_pipeline *p);
