@@ -601,6 +601,16 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
    * than block count as long as the launch keeps a few hundred blocks (measured, XGA, tools/exp_frames.sh: 16 frames
    * 39.8 k -> 52.1 k frames/s, 64 frames 112 k -> 126 k; from 256 frames on the general chunk is as tall already).
    * K2: up to 32 tiles; K4 (a third of the cells, more state per block): up to 16. */
+  /* K1 ends every block with up to 121 global atomics into the frame's histogram: with one-tile chunks (single frames) 768
+   * blocks queue up on the same addresses; at most SSD_K1_BLOCKS_PER_FRAME blocks per frame keeps that short */
+  int chunkHist = chunk;
+  {
+    const int perFrame = env_int("SSD_K1_BLOCKS_PER_FRAME", 256);
+    const int tilesPerFrame = (P.nPoints + kTileHost - 1) / kTileHost;
+    int t = (tilesPerFrame + perFrame - 1) / perFrame;
+    if(t > kMaxTilesPerBlockHost) t = kMaxTilesPerBlockHost;
+    if(t * kTileHost > chunkHist) chunkHist = t * kTileHost;
+  }
   int chunkRaster = chunk, chunkInquad = chunk;
   {
     const long long totalTiles = (static_cast<long long>(P.nPoints) + kTileHost - 1) / kTileHost * nframes;
@@ -633,7 +643,7 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   }
   mark();
   if(stages & SSD_STAGE_HIST)
-    launch_hist(xyz, strideFloats, P, h->dState, h->dTileMasks, h->tileMaskStride, nframes, chunk, depth, s);
+    launch_hist(xyz, strideFloats, P, h->dState, h->dTileMasks, h->tileMaskStride, nframes, chunkHist, depth, s);
   mark();
   if(stages & SSD_STAGE_PEAKS)
     launch_peaks(P, h->dState, nframes, dbg, s);
