@@ -97,6 +97,17 @@ struct QuadTest
   int err;                         /* 0 or the negative code of the reference's throw */
 };
 
+/* A live quadrilateral's four edges as half-planes on the grid of K1's cell boxes (k_quads builds them, k_inquad's cell
+ * classification uses them): a box [x0, x1] x [y0, y1] of grid cells lies wholly inside the quadrilateral iff, for every
+ * edge s, g[s][0] * xs + g[s][1] * ys + g[s][2] > 0 at the box corner (xs, ys) that minimises it (xs = x0 when
+ * g[s][0] > 0, else x1 + 1; likewise ys).  The margin of the boxes' truncation is folded into g[s][2].
+ * ok = 0: the reference's cell map does not agree with the geometry somewhere (see build_grid_segs) - do not use. */
+struct QuadGridSegs
+{
+  double g[4][3];
+  int ok, pad;
+};
+
 struct PlateauState
 {
   int peakBin, binLo, binHi;       /* Plateau::height, chosen pair */
@@ -131,6 +142,7 @@ struct FrameState
   /* the live quadrilateral tests, compact (k_quads): slot k belongs to accumulator liveAcc[k] (treads ascending, the
    * ground last); lutLive: height bin -> slot; liveGroups: the groups of 4 height bins of the slot's plateau */
   QuadTest qtLive[kMaxLive];
+  QuadGridSegs segLive[kMaxLive];
   unsigned char liveAcc[kMaxLive];
   unsigned char lutLive[kMaxBins];
   unsigned int liveGroups[kMaxLive];

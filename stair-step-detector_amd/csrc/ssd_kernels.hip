@@ -1742,6 +1742,7 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
       if(slot < kMaxLive)
       {
         fs.qtLive[slot] = t;
+        build_grid_segs(t, P.pt.xMin, P.pt.yMin, P.pt.boxX, P.pt.boxY, fs.segLive[slot]);
         fs.liveAcc[slot] = static_cast<unsigned char>(lane);
         /* the groups of 4 height bins this accumulator's plateau occupies (matched against the cells' masks) */
         unsigned int groups = 0u;
@@ -1810,6 +1811,7 @@ struct InquadLds
   unsigned int wmiss[kThreads / 64][kWaveMissWords];
   ImageBox box[1];
   QuadTest qts[kMaxLive];                       /* FrameState::qtLive: slot k = accumulator liveAcc[k] */
+  QuadGridSegs segs[kMaxLive];                  /* FrameState::segLive */
   unsigned char lut[kMaxBins];                  /* bin -> live slot */
   unsigned long long lsum[kMaxLive][8];
   unsigned int lcnt[kMaxLive][8];
@@ -1833,6 +1835,7 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
   unsigned int (&wmiss)[kThreads / 64][kWaveMissWords] = L.wmiss;
   ImageBox (&box)[1] = L.box;
   QuadTest (&qts)[kMaxLive] = L.qts;
+  QuadGridSegs (&segs)[kMaxLive] = L.segs;
   unsigned char (&lut)[kMaxBins] = L.lut;
   unsigned long long (&lsum)[kMaxLive][8] = L.lsum;
   unsigned int (&lcnt)[kMaxLive][8] = L.lcnt;
@@ -1887,6 +1890,10 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
 #pragma unroll 4
     for(int i = tid; i < kMaxLive * wordsPer; i += kThreads)
       dst[i] = src[i];
+    const unsigned int *srcS = reinterpret_cast<const unsigned int *>(fs.segLive);
+    unsigned int *dstS = reinterpret_cast<unsigned int *>(segs);
+    for(int i = tid; i < kMaxLive * static_cast<int>(sizeof(QuadGridSegs) / 4); i += kThreads)
+      dstS[i] = srcS[i];
   }
   __syncthreads();
   if(tid < nLive)
@@ -1971,7 +1978,23 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
                                         if(q == gSlot)
                                           need = need || !(x1 <= b.x || x0 >= b.y || y1 <= b.z || y0 >= b.w);      /* not wholly outside */
                                         else
-                                          need = need || !(x0 >= b.x && x1 <= b.y && y0 >= b.z && y1 <= b.w);      /* not wholly inside */
+                                        {
+                                          bool in = x0 >= b.x && x1 <= b.y && y0 >= b.z && y1 <= b.w;   /* wholly inside the constant cell */
+                                          const QuadGridSegs &sg = segs[q];
+                                          if(!in && sg.ok)
+                                          {
+                                            /* wholly inside all four edges (the tread is turned against the axes) */
+                                            const double dx0 = x0, dx1 = x1 + 1, dy0 = y0, dy1 = y1 + 1;
+                                            in = true;
+#pragma unroll
+                                            for(int s = 0; s < 4; s++)
+                                            {
+                                              const double gx = sg.g[s][0], gy = sg.g[s][1];
+                                              in = in && (gx * (gx > 0 ? dx0 : dx1) + gy * (gy > 0 ? dy0 : dy1) + sg.g[s][2] > 0);
+                                            }
+                                          }
+                                          need = need || !in;
+                                        }
                                       }
                                       return need;
                                     }, cellList, listScratch);

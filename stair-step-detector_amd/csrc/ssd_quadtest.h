@@ -260,6 +260,52 @@ __device__ __forceinline__ bool quad_test(const QuadTest &t, double x, double y)
   return ok;
 }
 
+/* The edges of a built test as half-planes on K1's box grid (QuadGridSegs, ssd_device.h), for k_inquad's "is this cell wholly
+ * inside the tread?" — sharper than the constant cell (fx0 ..) when the tread is turned against the axes.
+ * A point that lies inside all four half-planes by the margin passes isPointWithin whichever cell of the 3 x 3 map it falls
+ * into, PROVIDED the map itself agrees with the geometry: a cell that holds segments tests only those (all pass), a cell
+ * without segments answers with its constant.  Such a cell is crossed by no edge, so it lies wholly inside or wholly
+ * outside the quadrilateral; ok = 0 when one that lies inside (tested at its centre) carries the constant "outside". */
+__device__ inline void build_grid_segs(const QuadTest &t, double xMin, double yMin, double boxX, double boxY, QuadGridSegs &o)
+{
+  const double margin = 4.0e-9;
+  o.ok = t.err == 0 ? 1 : 0;
+  o.pad = 0;
+  double cx[4], cy[4], cc[4];                       /* sign-adjusted: inside <=> cx * x + cy * y + cc > 0 */
+  for(int s = 0; s < 4; s++)
+  {
+    const bool positiveInside = (t.segLeftIfPositive[s] != 0) == (t.insideIsLeft != 0);
+    const double sgn = positiveInside ? 1.0 : -1.0;
+    const double k = t.segK[s];
+    cx[s] = sgn * (t.segSteep[s] ? 1.0 : k);
+    cy[s] = sgn * (t.segSteep[s] ? k : 1.0);
+    cc[s] = sgn * t.segC[s];
+    o.g[s][0] = cx[s] / boxX;
+    o.g[s][1] = cy[s] / boxY;
+    o.g[s][2] = (cc[s] + cx[s] * xMin + cy[s] * yMin) - margin * (fabs(cx[s]) + fabs(cy[s]));
+    if(!(fabs(o.g[s][0]) < 1.0e6 && fabs(o.g[s][1]) < 1.0e6 && fabs(o.g[s][2]) < 1.0e6))
+      o.ok = 0;                                     /* degenerate edge (infinite or NaN slope) */
+  }
+  for(int r = 0; r < t.nRows && r < 3; r++)
+  {
+    const double y0 = r == 0 ? t.byLo : t.yTrans[r - 1];
+    const double y1 = r == t.nRows - 1 ? t.byUp : t.yTrans[r];
+    for(int c = 0; c < t.nCells[r] && c < 3; c++)
+    {
+      if(t.cellMask[r][c] != 0 || t.cellConst[r][c] != 0)
+        continue;
+      const double x0 = c == 0 ? t.bxLo : t.xTrans[r][c - 1];
+      const double x1 = c == t.nCells[r] - 1 ? t.bxUp : t.xTrans[r][c];
+      const double mx = (x0 + x1) / 2, my = (y0 + y1) / 2;
+      bool inside = true;
+      for(int s = 0; s < 4; s++)
+        inside = inside && (cx[s] * mx + cy[s] * my + cc[s] > 0);
+      if(inside)
+        o.ok = 0;
+    }
+  }
+}
+
 } // namespace ssd
 
 #endif /* SSD_QUADTEST_H_ */
