@@ -84,6 +84,11 @@ __device__ __forceinline__ int height_bin(const PointParams &P, double wz)
 
 /* k_raster is built for 7 waves per SIMD: 72 VGPRs / 96 SGPRs end its scratch spills (measured: XGA batch 1.015 -> 1.006 ms,
  * FHD stress 1.083 -> 1.037; 6 waves: slower again) */
+/* k_inquad: 8 waves per SIMD although that costs it 48 scalar-register spills (v_readlane in the loop): 7 / 6 waves spill
+ * 33 / 10 and run 3 % / 10 % slower (measured, XGA batch) */
+#ifndef SSD_K4_WAVES
+#define SSD_K4_WAVES 8
+#endif
 #ifndef SSD_K2_WAVES
 #define SSD_K2_WAVES 7
 #endif
@@ -2091,7 +2096,7 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
 }
 
 template<int SRC>
-__global__ __launch_bounds__(kThreads, 8) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
+__global__ __launch_bounds__(kThreads, SSD_K4_WAVES) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                         PixelParams X, FrameState *__restrict__ st,
                                                         unsigned long long *__restrict__ groundImg,
                                                         const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
