@@ -654,7 +654,7 @@ struct WaveWindow
 };
 
 /* Bits that miss the window go straight to memory; their bounding box is kept per WAVE in LDS (wm[2..5] = row min /
- * max, word column min / max; wm[6] = the image slots touched), next to the miss bookkeeping wm[0..1] below: four LDS
+ * max, word column min / max; wm[6] = the image slots touched; wm[0..1], wm[7] unused): four LDS
  * min/max per miss, no per-lane state.  One box for all slots of the wave: a wave that misses in several images
  * (outliers) widens each of them to the union — boxes only bound the region K3 / K5 visit and clear. */
 constexpr int kWaveMissWords = 8;
@@ -726,51 +726,84 @@ __device__ __forceinline__ void wavewin_flush(unsigned long long *ww, const Wave
   }
 }
 
-/* What missed the window during one tile is noted per WAVE, in two LDS words next to the window (wm[0] = lowest
- * (slot, row, word column) that missed, packed; wm[1] = number of words that missed): the miss path is rare and
- * per-lane registers for it would have to be merged at every exit of the per-point control flow. */
-constexpr unsigned int kNoMiss = 0xffffffffu;
-
-/* one word's worth of bits of image `slot`: into the window when it is inside, straight to memory otherwise */
-__device__ __forceinline__ void wavewin_or(unsigned long long *ww, unsigned int *wm, const WaveWindow &w, unsigned long long *__restrict__ images,
-                                           unsigned int imgWords, int W64, int winShift,
-                                           int slot, int iy, int xw, unsigned long long mask)
+/* A lit pixel as one sortable word: image slot (5 bits) | row (13) | column (13); width and height <= 8192 (ssd_create).
+ * kNoPixel sorts last.  (key >> 6) names the pixel's 64-bit image word. */
+constexpr unsigned int kNoPixel = 0xffffffffu;
+__device__ __forceinline__ unsigned int pixel_key(int slot, int iy, int ix)
 {
-  const unsigned int r = static_cast<unsigned int>(iy - w.row0), c = static_cast<unsigned int>(xw - w.col0);
-  if(slot == w.slot && r < (static_cast<unsigned int>(kWinWords) >> winShift) && c < (1u << winShift))
+  return (static_cast<unsigned int>(slot) << 26) | (static_cast<unsigned int>(iy) << 13) | static_cast<unsigned int>(ix);
+}
+
+__device__ __forceinline__ unsigned int wave_min_u32(unsigned int v)
+{
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1)
+    v = min(v, static_cast<unsigned int>(__shfl_xor(static_cast<int>(v), o)));
+  return v;
+}
+
+/* Before a tile's pixels go out, all 64 lanes; `first` = the lane's lowest pixel_key of this tile (kNoPixel: none).
+ * When more than half of the lanes that have pixels would miss the window, it is flushed and re-anchored at the lowest
+ * such key FIRST — deciding only after the tile had gone out (round 1 / 2a) sent every wave's first tile and the tile
+ * after each change of cell column straight to memory: 10.5 % of all words, 2.2 % now (tools/window_sim.py). */
+__device__ __forceinline__ void wavewin_prepare(unsigned long long *ww, WaveWindow &w, unsigned long long *__restrict__ images,
+                                                unsigned int imgWords, int W64, int winShift, ImageBox *boxes, unsigned int first, int lane)
+{
+  const bool has = first != kNoPixel;
+  const unsigned int r = ((first >> 13) & 0x1fffu) - static_cast<unsigned int>(w.row0);
+  const unsigned int c = ((first & 0x1fffu) >> 6) - static_cast<unsigned int>(w.col0);
+  const bool miss = has && !(static_cast<int>(first >> 26) == w.slot && r < (static_cast<unsigned int>(kWinWords) >> winShift) && c < (1u << winShift));
+  const unsigned long long missing = __ballot(miss);
+  if(missing == 0ull || 2 * __popcll(missing) <= __popcll(__ballot(has)))
+    return;
+  const unsigned int lowest = __builtin_amdgcn_readfirstlane(wave_min_u32(miss ? first : kNoPixel));
+  wavewin_flush(ww, w, images, imgWords, W64, winShift, boxes, lane);
+  w.slot = static_cast<int>(lowest >> 26);
+  w.row0 = static_cast<int>((lowest >> 13) & 0x1fffu);
+  w.col0 = max(0, min(static_cast<int>((lowest & 0x1fffu) >> 6) - 1, W64 - (1 << winShift)));
+}
+
+/* one word's worth of bits (key = any pixel_key of the word): into the window when it is inside, straight to memory
+ * otherwise — the bounding box of what went straight to memory is kept per wave (wavemiss_*) */
+__device__ __forceinline__ void wavewin_or(unsigned long long *ww, unsigned int *wm, const WaveWindow &w, unsigned long long *__restrict__ images,
+                                           unsigned int imgWords, int W64, int winShift, unsigned int key, unsigned long long mask)
+{
+  const unsigned int slot = key >> 26, iy = (key >> 13) & 0x1fffu, xw = (key & 0x1fffu) >> 6;
+  const unsigned int r = iy - static_cast<unsigned int>(w.row0), c = xw - static_cast<unsigned int>(w.col0);
+  if(static_cast<int>(slot) == w.slot && r < (static_cast<unsigned int>(kWinWords) >> winShift) && c < (1u << winShift))
     atomicOr(&ww[(r << winShift) + c], mask);
   else
   {
-    atomicOr(images + (static_cast<unsigned int>(slot) * imgWords + static_cast<unsigned int>(iy) * static_cast<unsigned int>(W64) + static_cast<unsigned int>(xw)), mask);
-    atomicMin(&wm[0], (((static_cast<unsigned int>(slot) << 16) | static_cast<unsigned int>(iy)) << 6) | static_cast<unsigned int>(xw));
-    atomicAdd(&wm[1], 1u);
+    atomicOr(images + (slot * imgWords + iy * static_cast<unsigned int>(W64) + xw), mask);
     int *b = reinterpret_cast<int *>(wm);
-    atomicMin(&b[2], iy); atomicMax(&b[3], iy);
-    atomicMin(&b[4], xw); atomicMax(&b[5], xw);
+    atomicMin(&b[2], static_cast<int>(iy)); atomicMax(&b[3], static_cast<int>(iy));
+    atomicMin(&b[4], static_cast<int>(xw)); atomicMax(&b[5], static_cast<int>(xw));
     atomicOr(&wm[6], 1u << slot);
   }
 }
 
-/* end of a tile, all 64 lanes; `emitted` = this lane sent at least one word: nothing to do unless something
- * missed; re-anchor at the lowest miss when the misses outnumber half of the emitting lanes */
-__device__ __forceinline__ void wavewin_end_of_tile(unsigned long long *ww, unsigned int *wm, WaveWindow &w, unsigned long long *__restrict__ images,
-                                                    unsigned int imgWords, int W64, int winShift, ImageBox *boxes, bool emitted, int lane)
+/* A lane's (up to four) pixels of one tile, as keys: neighbouring pixels usually share one 64-bit word and are merged
+ * before they touch LDS.  All 64 lanes (wavewin_prepare votes). */
+__device__ __forceinline__ void wavewin_emit(unsigned long long *ww, unsigned int *wm, WaveWindow &w, unsigned long long *__restrict__ images,
+                                             unsigned int imgWords, int W64, int winShift, ImageBox *boxes, const unsigned int (&key)[4], int lane)
 {
-  const unsigned int missed = __builtin_amdgcn_readfirstlane(wm[1]);
-  if(missed == 0u)
-    return;
-  const unsigned int packed = __builtin_amdgcn_readfirstlane(wm[0]);
-  if(lane == 0)
+  wavewin_prepare(ww, w, images, imgWords, W64, winShift, boxes, min(min(key[0], key[1]), min(key[2], key[3])), lane);
+  unsigned int pend = kNoPixel;
+  unsigned long long pMask = 0;
+#pragma unroll
+  for(int j = 0; j < 4; j++)
   {
-    wm[0] = kNoMiss;
-    wm[1] = 0u;
+    const unsigned int k = key[j];
+    const bool valid = k != kNoPixel;
+    const bool same = ((k ^ pend) >> 6) == 0u;               /* a valid key (bit 31 clear) never equals kNoPixel's word */
+    if(valid && !same && pend != kNoPixel)
+      wavewin_or(ww, wm, w, images, imgWords, W64, winShift, pend, pMask);
+    const unsigned long long bit = 1ull << (k & 63u);
+    pMask = valid ? (same ? (pMask | bit) : bit) : pMask;
+    pend = valid ? k : pend;
   }
-  if(2u * missed <= static_cast<unsigned int>(__popcll(__ballot(emitted))))
-    return;
-  wavewin_flush(ww, w, images, imgWords, W64, winShift, boxes, lane);
-  w.slot = static_cast<int>(packed >> 22);
-  w.row0 = static_cast<int>((packed >> 6) & 0xffffu);
-  w.col0 = max(0, min(static_cast<int>(packed & 63u) - 1, W64 - (1 << winShift)));
+  if(pend != kNoPixel)
+    wavewin_or(ww, wm, w, images, imgWords, W64, winShift, pend, pMask);
 }
 
 /* Projection2D::worldToImage (pointcloud.cpp:79-83); false = outside the image (quirk Q5) */
@@ -891,15 +924,12 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
     const bool more = g + 1 < gEnd;
     if(more)
       load_cell<SRC>(base, cell0, cellList, 4 * (g + 1) + (lane >> 4), count, lane, P.nPoints, vn, D);
-    /* the lane's four neighbouring pixels usually share one 64-bit word: merge them before touching LDS */
-    int pSlot = -1;
-    int pY = 0;
-    int pXw = 0;
-    unsigned long long pMask = 0;
+    unsigned int key[kPts];
     #pragma unroll
     for(int j = 0; j < kPts; j++)
     {
       /* few, flat decisions per point (see k_inquad) */
+      key[j] = kNoPixel;
       double wx, wy, wz;
       const bool okz = world_z_flat(P, v[j], wz);
       const int slot = lut[okz ? height_bin(P, wz) : 0];
@@ -918,19 +948,9 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
       }
       accT += static_cast<unsigned long long>(z_to_fixed(wz));
       oob += inside ? 0u : 1u;                                /* quirk Q5 */
-      const unsigned long long bit = 1ull << (ix & 63);
-      const int xw = ix >> 6;
-      const bool same = slot == pSlot && iy == pY && xw == pXw;
-      if(inside && !same && pSlot >= 0)
-        wavewin_or(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, pSlot, pY, pXw, pMask);
-      pMask = inside ? (same ? (pMask | bit) : bit) : pMask;
-      pSlot = inside ? slot : pSlot;
-      pY = inside ? iy : pY;
-      pXw = inside ? xw : pXw;
+      key[j] = inside ? pixel_key(slot, iy, ix) : kNoPixel;
     }
-    if(pSlot >= 0)
-      wavewin_or(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, pSlot, pY, pXw, pMask);
-    wavewin_end_of_tile(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, boxes, pSlot >= 0, lane);
+    wavewin_emit(ww, wm, win, frameImg, imgWords, X.W64, X.winShift, boxes, key, lane);
     if(!more)
       break;
     g++;
@@ -2009,12 +2029,11 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
   {
     F3 v[kPts];
     load_cell<SRC>(base, cell0, cellList, 4 * g + (lane >> 4), count, lane, P.nPoints, v, D);
-    int pY = -1;
-    int pXw = 0;
-    unsigned long long pMask = 0;
+    unsigned int key[kPts];
     #pragma unroll
     for(int j = 0; j < kPts; j++)
     {
+      key[j] = kNoPixel;
       /* few, flat decisions per point: every nested divergent exit costs exec-mask registers and copies at its
        * join, more than the handful of predicated instructions it skips */
       double wx, wy, wz;
@@ -2039,24 +2058,14 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
       accN++;
       if(q == gSlot)
       {
-        /* projectToBinaryImage(pointsInQuadri) (pointcloud.cpp:531); the lane's pending word (pY, pXw, pMask) goes
-         * out when the next pixel falls into another word */
+        /* projectToBinaryImage(pointsInQuadri) (pointcloud.cpp:531): the pixel goes out with the lane's others (wavewin_emit) */
         int ix, iy;
         const bool inside = image_pixel(P, X, wx, wy, ix, iy);
         oob += inside ? 0u : 1u;                              /* quirk Q5 */
-        const unsigned long long bit = 1ull << (ix & 63);
-        const int xw = ix >> 6;
-        const bool same = iy == pY && xw == pXw;
-        if(inside && !same && pY >= 0)
-          wavewin_or(ww, wm, win, gimg, imgWords, X.W64, X.winShiftGround, 0, pY, pXw, pMask);
-        pMask = inside ? (same ? (pMask | bit) : bit) : pMask;
-        pY = inside ? iy : pY;
-        pXw = inside ? xw : pXw;
+        key[j] = inside ? pixel_key(0, iy, ix) : kNoPixel;
       }
     }
-    if(pY >= 0)
-      wavewin_or(ww, wm, win, gimg, imgWords, X.W64, X.winShiftGround, 0, pY, pXw, pMask);
-    wavewin_end_of_tile(ww, wm, win, gimg, imgWords, X.W64, X.winShiftGround, box, pY >= 0, lane);
+    wavewin_emit(ww, wm, win, gimg, imgWords, X.W64, X.winShiftGround, box, key, lane);
   }
   wavewin_flush(ww, win, gimg, imgWords, X.W64, X.winShiftGround, box, lane);
   wavemiss_flush(wm, box, lane);
