@@ -742,6 +742,20 @@ __device__ __forceinline__ unsigned int wave_min_u32(unsigned int v)
   return v;
 }
 
+/* The window's origin as a pixel_key (slot, row0, 64 * col0): for a pixel key k of the same image at or beyond the origin,
+ * d = k - base is (row - row0) << 13 | (column - 64 * col0); a pixel of another image, a higher row, or a column left of
+ * the origin borrows into the upper fields and fails the bounds below (64 * col0 + window width <= 8192), so one
+ * subtraction and two compares decide "inside the window".  kNoWindow (bit 31, which no pixel key has) fails for all. */
+constexpr unsigned int kNoWindow = 0x80000000u;
+__device__ __forceinline__ unsigned int window_base(const WaveWindow &w)
+{
+  return w.slot < 0 ? kNoWindow : pixel_key(w.slot, w.row0, w.col0 << 6);
+}
+__device__ __forceinline__ bool window_hit(unsigned int d, int winShift)
+{
+  return (d >> 13) < (static_cast<unsigned int>(kWinWords) >> winShift) && (d & 0x1fffu) < (64u << winShift);
+}
+
 /* Before a tile's pixels go out, all 64 lanes; `first` = the lane's lowest pixel_key of this tile (kNoPixel: none).
  * When more than half of the lanes that have pixels would miss the window, it is flushed and re-anchored at the lowest
  * such key FIRST — deciding only after the tile had gone out (round 1 / 2a) sent every wave's first tile and the tile
@@ -750,9 +764,7 @@ __device__ __forceinline__ void wavewin_prepare(unsigned long long *ww, WaveWind
                                                 unsigned int imgWords, int W64, int winShift, ImageBox *boxes, unsigned int first, int lane)
 {
   const bool has = first != kNoPixel;
-  const unsigned int r = ((first >> 13) & 0x1fffu) - static_cast<unsigned int>(w.row0);
-  const unsigned int c = ((first & 0x1fffu) >> 6) - static_cast<unsigned int>(w.col0);
-  const bool miss = has && !(static_cast<int>(first >> 26) == w.slot && r < (static_cast<unsigned int>(kWinWords) >> winShift) && c < (1u << winShift));
+  const bool miss = has && !window_hit(first - window_base(w), winShift);
   const unsigned long long missing = __ballot(miss);
   if(missing == 0ull || 2 * __popcll(missing) <= __popcll(__ballot(has)))
     return;
@@ -763,47 +775,34 @@ __device__ __forceinline__ void wavewin_prepare(unsigned long long *ww, WaveWind
   w.col0 = max(0, min(static_cast<int>((lowest & 0x1fffu) >> 6) - 1, W64 - (1 << winShift)));
 }
 
-/* one word's worth of bits (key = any pixel_key of the word): into the window when it is inside, straight to memory
- * otherwise — the bounding box of what went straight to memory is kept per wave (wavemiss_*) */
-__device__ __forceinline__ void wavewin_or(unsigned long long *ww, unsigned int *wm, const WaveWindow &w, unsigned long long *__restrict__ images,
-                                           unsigned int imgWords, int W64, int winShift, unsigned int key, unsigned long long mask)
-{
-  const unsigned int slot = key >> 26, iy = (key >> 13) & 0x1fffu, xw = (key & 0x1fffu) >> 6;
-  const unsigned int r = iy - static_cast<unsigned int>(w.row0), c = xw - static_cast<unsigned int>(w.col0);
-  if(static_cast<int>(slot) == w.slot && r < (static_cast<unsigned int>(kWinWords) >> winShift) && c < (1u << winShift))
-    atomicOr(&ww[(r << winShift) + c], mask);
-  else
-  {
-    atomicOr(images + (slot * imgWords + iy * static_cast<unsigned int>(W64) + xw), mask);
-    int *b = reinterpret_cast<int *>(wm);
-    atomicMin(&b[2], static_cast<int>(iy)); atomicMax(&b[3], static_cast<int>(iy));
-    atomicMin(&b[4], static_cast<int>(xw)); atomicMax(&b[5], static_cast<int>(xw));
-    atomicOr(&wm[6], 1u << slot);
-  }
-}
-
-/* A lane's (up to four) pixels of one tile, as keys: neighbouring pixels usually share one 64-bit word and are merged
- * before they touch LDS.  All 64 lanes (wavewin_prepare votes). */
+/* A lane's (up to four) pixels of one tile, as keys; all 64 lanes (wavewin_prepare votes).  One 32-bit LDS atomic per pixel
+ * (the window's 64-bit words as pairs of halves), no merging of the lane's neighbouring pixels first: with range noise
+ * they shared a word only 1.4 to 1, and the bookkeeping for it cost more instructions than the atomics it saved.  A pixel
+ * outside the window goes straight to memory (the bounding box of those is kept per wave, wavemiss_*), so the result never
+ * depends on where the window is. */
 __device__ __forceinline__ void wavewin_emit(unsigned long long *ww, unsigned int *wm, WaveWindow &w, unsigned long long *__restrict__ images,
                                              unsigned int imgWords, int W64, int winShift, ImageBox *boxes, const unsigned int (&key)[4], int lane)
 {
   wavewin_prepare(ww, w, images, imgWords, W64, winShift, boxes, min(min(key[0], key[1]), min(key[2], key[3])), lane);
-  unsigned int pend = kNoPixel;
-  unsigned long long pMask = 0;
+  const unsigned int base = window_base(w);
+  unsigned int *ww32 = reinterpret_cast<unsigned int *>(ww);
 #pragma unroll
   for(int j = 0; j < 4; j++)
   {
-    const unsigned int k = key[j];
-    const bool valid = k != kNoPixel;
-    const bool same = ((k ^ pend) >> 6) == 0u;               /* a valid key (bit 31 clear) never equals kNoPixel's word */
-    if(valid && !same && pend != kNoPixel)
-      wavewin_or(ww, wm, w, images, imgWords, W64, winShift, pend, pMask);
-    const unsigned long long bit = 1ull << (k & 63u);
-    pMask = valid ? (same ? (pMask | bit) : bit) : pMask;
-    pend = valid ? k : pend;
+    const unsigned int k = key[j], d = k - base;
+    const unsigned int bit = 1u << (k & 31u);
+    if(window_hit(d, winShift))
+      atomicOr(&ww32[((d >> 13) << (winShift + 1)) + ((d & 0x1fffu) >> 5)], bit);
+    else if(k != kNoPixel)
+    {
+      const unsigned int slot = k >> 26, iy = (k >> 13) & 0x1fffu, ix = k & 0x1fffu, xw = ix >> 6;
+      atomicOr(reinterpret_cast<unsigned int *>(images + (slot * imgWords + iy * static_cast<unsigned int>(W64) + xw)) + ((ix >> 5) & 1u), bit);
+      int *b = reinterpret_cast<int *>(wm);
+      atomicMin(&b[2], static_cast<int>(iy)); atomicMax(&b[3], static_cast<int>(iy));
+      atomicMin(&b[4], static_cast<int>(xw)); atomicMax(&b[5], static_cast<int>(xw));
+      atomicOr(&wm[6], 1u << slot);
+    }
   }
-  if(pend != kNoPixel)
-    wavewin_or(ww, wm, w, images, imgWords, W64, winShift, pend, pMask);
 }
 
 /* Projection2D::worldToImage (pointcloud.cpp:79-83); false = outside the image (quirk Q5) */
