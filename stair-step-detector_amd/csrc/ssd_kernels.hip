@@ -45,6 +45,21 @@ __device__ __forceinline__ bool world_point(const PointParams &P, const F3 &v, d
   return wx > P.xMin && wx < P.xMax && wy > P.yMin && wy < P.yMax && wz > P.zMin && wz < P.zMax;
 }
 
+/* world_point as flat code for k_hist: all three rows, then the seven tests combined without short circuit.  Early exits
+ * only pay when all 64 lanes of a wave take them, which a camera image next to never offers; as nested branches they cost
+ * the default values of everything the point contributes, re-materialised at every level (9 moves per point in K1's ISA). */
+__device__ __forceinline__ bool world_point_flat(const PointParams &P, const F3 &v, double &wx, double &wy, double &wz)
+{
+  const double x = v.x, y = v.y, z = v.z;
+  wx = (P.a[0] * x + P.a[1] * y) + P.a[2] * z;
+  wy = (P.a[3] * x + P.a[4] * y) + P.a[5] * z;
+  wz = (P.a[6] * x + P.a[7] * y) + P.a[8] * z;
+  wx = wx + P.b[0];
+  wy = wy + P.b[1];
+  wz = wz + P.b[2];
+  return (v.z > 0.0f) & (wx > P.xMin) & (wx < P.xMax) & (wy > P.yMin) & (wy < P.yMax) & (wz > P.zMin) & (wz < P.zMax);
+}
+
 /* The same decisions taken height first, for the passes that drop most points on their height bin: the z row
  * and the z tests, then (only for points whose bin matters) the x and y rows and their tests.  The
  * conjunction of tests and every operation are those of world_point. */
@@ -353,11 +368,11 @@ __device__ __forceinline__ void hist_block(HistLds &L, const float *__restrict__
     {
       double wx, wy, wz;
       nz += v[j].z > 0.0f ? 1u : 0u;
-      if(world_point(P, v[j], wx, wy, wz))
+      if(world_point_flat(P, v[j], wx, wy, wz))
       {
-        const int b = height_bin(P, wz);
+        const unsigned int b = static_cast<unsigned int>(height_bin(P, wz));     /* in [0, nBins) for a point in range */
         atomicAdd(mine + b * kHistCopies, 1u);                          /* ++hist[bin], pointcloud.cpp:199-202 */
-        groups |= 1u << (b / kBinsPerGroup);
+        groups |= 1u << (b / static_cast<unsigned int>(kBinsPerGroup));
         const unsigned int qx = static_cast<unsigned int>((wx - P.xMin) * P.boxX), qy = static_cast<unsigned int>((wy - P.yMin) * P.boxY);
         const unsigned int q = qx | (qy << 16);
         boxMin = pk_min_u16(boxMin, q);
