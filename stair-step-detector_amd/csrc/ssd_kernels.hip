@@ -28,26 +28,13 @@ namespace ssd
 
 struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
 
-/* CameraToWorld (transformation.h:59-64, 79-87): a*x + b, float promoted to double,
- * row sums left to right, then the translation; followed by the six strict range
- * compares of getPointsInRange (pointcloud.cpp:150-165). */
-__device__ __forceinline__ bool world_point(const PointParams &P, const F3 &v, double &wx, double &wy, double &wz)
-{
-  if(!(v.z > 0.0f))                                   /* pointcloud.cpp:143-146 */
-    return false;
-  const double x = v.x, y = v.y, z = v.z;
-  wx = (P.a[0] * x + P.a[1] * y) + P.a[2] * z;
-  wy = (P.a[3] * x + P.a[4] * y) + P.a[5] * z;
-  wz = (P.a[6] * x + P.a[7] * y) + P.a[8] * z;
-  wx = wx + P.b[0];
-  wy = wy + P.b[1];
-  wz = wz + P.b[2];
-  return wx > P.xMin && wx < P.xMax && wy > P.yMin && wy < P.yMax && wz > P.zMin && wz < P.zMax;
-}
-
-/* world_point as flat code for k_hist: all three rows, then the seven tests combined without short circuit.  Early exits
- * only pay when all 64 lanes of a wave take them, which a camera image next to never offers; as nested branches they cost
- * the default values of everything the point contributes, re-materialised at every level (9 moves per point in K1's ISA). */
+/* CameraToWorld (transformation.h:59-64, 79-87): a*x + b, float promoted to double, row sums left to right, then the
+ * translation; followed by the non-zero test (pointcloud.cpp:143-146) and the six strict range compares of
+ * getPointsInRange (pointcloud.cpp:150-165).  Flat code: all three rows, then the seven tests combined without short
+ * circuit.  Early exits only pay when all 64 lanes of a wave take them, which a camera image next to never offers; as nested
+ * branches they cost the default values of everything the point contributes, re-materialised at every level (9 moves per
+ * point in K1's ISA).  (The throughput of K1 / K2 on float3 input did not move with it — they sit on the memory roof
+ * of the GPU's current clock state — but the instruction count did: what 16-bit depth input, VALU-bound, runs on.) */
 __device__ __forceinline__ bool world_point_flat(const PointParams &P, const F3 &v, double &wx, double &wy, double &wz)
 {
   const double x = v.x, y = v.y, z = v.z;
@@ -62,7 +49,7 @@ __device__ __forceinline__ bool world_point_flat(const PointParams &P, const F3 
 
 /* The same decisions taken height first, for the passes that drop most points on their height bin: the z row
  * and the z tests, then (only for points whose bin matters) the x and y rows and their tests.  The
- * conjunction of tests and every operation are those of world_point. */
+ * conjunction of tests and every operation are those of world_point_flat. */
 __device__ __forceinline__ bool world_z(const PointParams &P, const F3 &v, double &wz)
 {
   if(!(v.z > 0.0f))
@@ -945,15 +932,12 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
       /* few, flat decisions per point (see k_inquad) */
       key[j] = kNoPixel;
       double wx, wy, wz;
-      const bool okz = world_z_flat(P, v[j], wz);
-      const int slot = lut[okz ? height_bin(P, wz) : 0];
-      if(!(okz && slot != 0xff))
+      const bool ok = world_point_flat(P, v[j], wx, wy, wz);
+      const int slot = lut[ok ? height_bin(P, wz) : 0];
+      if(!(ok & (slot != 0xff)))
         continue;
       int ix, iy;
-      const bool okxy = world_xy(P, v[j], wx, wy);
       const bool inside = image_pixel(P, X, wx, wy, ix, iy);
-      if(!okxy)
-        continue;
       if(slot != curT)
       {
         flushT();
