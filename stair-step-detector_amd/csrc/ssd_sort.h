@@ -8,6 +8,11 @@
  * lands on that rank is whatever this algorithm leaves there.  The kernels select by rank (no sort) and fall back to
  * this restatement only when the selected distance is duplicated and the duplicates would give different lines.
  * Compiled for host and device from this one definition; tests compare it with std::sort itself (oracle, host).
+ *
+ * Provenance: written from the algorithm's published description (Musser's introsort as libstdc++ configures it:
+ * threshold 16, depth limit 2 * floor(lg n), median of first + 1 / middle / last - 1 moved to the front, unguarded
+ * partition, heap-select + sort-heap fallback, final guarded / unguarded insertion sort).  It restates the ALGORITHM and
+ * its constants so that ties land where std::sort leaves them; it contains no text of libstdc++.
  */
 #ifndef SSD_SORT_H_
 #define SSD_SORT_H_
