@@ -140,7 +140,7 @@ SOURCE_EXPORTS = [
 ]
 # libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
 HOOK_EXPORTS = [
-    "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_quad_device", "ssd_test_sort_host",
+    "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_quad_device", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
     "ssd_test_sort_device", "ssd_testhooks_last_error",
 ]
 SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
@@ -247,6 +247,7 @@ def hooks_lib():
     L.ssd_test_sort_host.argtypes = [vp, i32, vp]
     L.ssd_test_sort_device.argtypes = [i32, vp, i32, vp]
     L.ssd_test_quad_device.argtypes = [i32, vp, vp, i32, vp, C.POINTER(C.c_int)]
+    L.ssd_test_grid_boxes_device.argtypes = [i32, vp, C.c_double, C.c_double, C.c_double, C.c_double, vp, i32, vp, C.POINTER(C.c_int)]
     _hooks_lib = L
     return L
 
@@ -527,6 +528,18 @@ def quad_test_device(quad, pts, device=0):
     _check(hooks_lib().ssd_test_quad_device(device, q.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), len(p),
                                             out.ctypes.data_as(C.c_void_p), C.byref(err)), "hooks")
     return err.value, out
+
+
+def grid_boxes_device(quad, x_min, y_min, box_x, box_y, boxes, device=0):
+    """test hook: k_inquad's "box of K1's grid wholly inside the quadrilateral" -> (usable, uint8 inside[n])"""
+    q = np.ascontiguousarray(quad, dtype=np.float64).reshape(8)
+    b = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 4)
+    out = np.zeros(len(b), dtype=np.uint8)
+    usable = C.c_int(0)
+    _check(hooks_lib().ssd_test_grid_boxes_device(device, q.ctypes.data_as(C.c_void_p), x_min, y_min, box_x, box_y,
+                                                  b.ctypes.data_as(C.c_void_p), len(b), out.ctypes.data_as(C.c_void_p),
+                                                  C.byref(usable)), "hooks")
+    return usable.value, out
 
 
 def make_scene(width, height, n_steps=3, seed=12345, cam_height=1.0, pitch_deg=50.0, roll_deg=0.0,

@@ -2002,20 +2002,9 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
                                           need = need || !(x1 <= b.x || x0 >= b.y || y1 <= b.z || y0 >= b.w);      /* not wholly outside */
                                         else
                                         {
-                                          bool in = x0 >= b.x && x1 <= b.y && y0 >= b.z && y1 <= b.w;   /* wholly inside the constant cell */
-                                          const QuadGridSegs &sg = segs[q];
-                                          if(!in && sg.ok)
-                                          {
-                                            /* wholly inside all four edges (the tread is turned against the axes) */
-                                            const double dx0 = x0, dx1 = x1 + 1, dy0 = y0, dy1 = y1 + 1;
-                                            in = true;
-#pragma unroll
-                                            for(int s = 0; s < 4; s++)
-                                            {
-                                              const double gx = sg.g[s][0], gy = sg.g[s][1];
-                                              in = in && (gx * (gx > 0 ? dx0 : dx1) + gy * (gy > 0 ? dy0 : dy1) + sg.g[s][2] > 0);
-                                            }
-                                          }
+                                          /* wholly inside the constant cell, or inside all four edges (the tread is turned
+                                           * against the axes) */
+                                          const bool in = (x0 >= b.x && x1 <= b.y && y0 >= b.z && y1 <= b.w) || grid_box_inside(segs[q], x0, x1, y0, y1);
                                           need = need || !in;
                                         }
                                       }

@@ -306,6 +306,20 @@ __device__ inline void build_grid_segs(const QuadTest &t, double xMin, double yM
   }
 }
 
+/* the boxes [x0, x1] x [y0, y1] of K1's grid cells that lie wholly inside all four edges (QuadGridSegs, ssd_device.h) */
+__device__ __forceinline__ bool grid_box_inside(const QuadGridSegs &sg, int x0, int x1, int y0, int y1)
+{
+  const double dx0 = x0, dx1 = x1 + 1, dy0 = y0, dy1 = y1 + 1;
+  bool in = sg.ok != 0;
+#pragma unroll
+  for(int s = 0; s < 4; s++)
+  {
+    const double gx = sg.g[s][0], gy = sg.g[s][1];
+    in = in && (gx * (gx > 0 ? dx0 : dx1) + gy * (gy > 0 ? dy0 : dy1) + sg.g[s][2] > 0);
+  }
+  return in;
+}
+
 } // namespace ssd
 
 #endif /* SSD_QUADTEST_H_ */

@@ -58,6 +58,29 @@ __global__ void k_sorttest(double *dist, int *idx, int n)
   }
 }
 
+/* test hook: k_inquad's "is this box of K1's grid wholly inside the quadrilateral?" (build_grid_segs + grid_box_inside) for one
+ * quadrilateral and n boxes (x0, x1, y0, y1 in grid cells); usable = QuadGridSegs::ok (0 also when the test would throw) */
+__global__ void k_gridboxes(const double *__restrict__ quad, double xMin, double yMin, double boxX, double boxY,
+                            const int *__restrict__ boxes, int n, unsigned char *__restrict__ inside, int *__restrict__ usable)
+{
+  __shared__ QuadTest t;
+  __shared__ QuadGridSegs sg;
+  if(threadIdx.x == 0)
+  {
+    double q[8];
+    for(int k = 0; k < 8; k++)
+      q[k] = quad[k];
+    QuadTest local;
+    build_quad_test(q, local);
+    t = local;
+    build_grid_segs(t, xMin, yMin, boxX, boxY, sg);
+    *usable = sg.ok;
+  }
+  __syncthreads();
+  for(int i = threadIdx.x; i < n; i += blockDim.x)
+    inside[i] = grid_box_inside(sg, boxes[4 * i], boxes[4 * i + 1], boxes[4 * i + 2], boxes[4 * i + 3]) ? 1 : 0;
+}
+
 /* test hook: QuadrilateralTest as the kernels build and evaluate it (build_quad_test + the constant cell + quad_test),
  * one quadrilateral, n points; err = the negative code of the reference's throw or 0 */
 __global__ void k_quadtest(const double *__restrict__ quad, const double *__restrict__ pts, int n, unsigned char *__restrict__ inside,
@@ -187,6 +210,32 @@ int ssd_test_quad_device(int device, const double quad[8], const double *pts_xy,
   HIP_TRY(hipMemcpy(inside, di, static_cast<size_t>(n), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(err, de, sizeof(int), hipMemcpyDeviceToHost));
   (void)hipFree(dq); (void)hipFree(dp); (void)hipFree(di); (void)hipFree(de);
+  return SSD_OK;
+}
+
+int ssd_test_grid_boxes_device(int device, const double quad[8], double x_min, double y_min, double box_x, double box_y,
+                               const int32_t *boxes, int n, uint8_t *inside, int *usable)
+{
+  if(!quad || !boxes || !inside || !usable || n < 1)
+    return fail(SSD_E_ARG, "ssd_test_grid_boxes_device: bad argument");
+  if(device_count() <= 0)
+    return fail(SSD_E_NODEVICE, "ssd_test_grid_boxes_device: no HIP device");
+  HIP_TRY(hipSetDevice(device));
+  double *dq = nullptr;
+  int *db = nullptr, *du = nullptr;
+  unsigned char *di = nullptr;
+  HIP_TRY(hipMalloc(&dq, 8 * sizeof(double)));
+  HIP_TRY(hipMalloc(&db, static_cast<size_t>(n) * 4 * sizeof(int)));
+  HIP_TRY(hipMalloc(&di, static_cast<size_t>(n)));
+  HIP_TRY(hipMalloc(&du, sizeof(int)));
+  HIP_TRY(hipMemcpy(dq, quad, 8 * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, boxes, static_cast<size_t>(n) * 4 * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(di, 0, static_cast<size_t>(n)));
+  hipLaunchKernelGGL(k_gridboxes, dim3(1), dim3(256), 0, nullptr, dq, x_min, y_min, box_x, box_y, db, n, di, du);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(inside, di, static_cast<size_t>(n), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(usable, du, sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(dq); (void)hipFree(db); (void)hipFree(di); (void)hipFree(du);
   return SSD_OK;
 }
 

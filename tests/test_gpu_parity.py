@@ -273,6 +273,59 @@ def test_hip_path_reproduces_the_surveys_observed_run(ssd, gpu_device, tmp_path)
     assert ssd.Stairs(fr).serialize() == sa.OBSERVED_LINE
 
 
+@pytest.mark.gpu
+def test_cells_classified_as_inside_hold_only_points_the_quadrilateral_test_accepts(ssd, gpu_device):
+    """k_inquad skips a tread cell whose box on K1's 256 x 256 grid lies inside all four edges of the quadrilateral
+    (build_grid_segs / grid_box_inside).  Property: every point of such a box — corners, edge midpoints, random interior
+    points, nudged 1e-9 m outwards as K1's truncation may — passes the kernels' QuadrilateralTest (itself pinned to the
+    reference's goldens above); and the shortcut is not vacuous: it accepts most boxes well inside an ordinary tread.
+    Quadrilaterals: the reference goldens' (incl. the degenerate ones that throw) + random turned / sheared treads."""
+    import json
+    import os
+    rng = np.random.default_rng(20260)
+    x_min, y_min, span = -0.6, 0.1, 1.2
+    box = 256.0 / span
+    quads = []
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_quadtest.json")))
+    for c in cases:
+        quads.append(np.array([float.fromhex(x) for x in c["quad"]]).reshape(4, 2))
+    for _ in range(60):
+        yaw = np.radians(rng.uniform(-45, 45))
+        w, d = rng.uniform(0.3, 1.0), rng.uniform(0.1, 0.4)
+        cx, cy = rng.uniform(-0.2, 0.2), rng.uniform(0.4, 1.0)
+        base = np.array([[-w / 2, -d / 2], [w / 2, -d / 2], [-w / 2, d / 2], [w / 2, d / 2]])     # fl, fr, bl, br
+        base += rng.normal(0, 0.02, base.shape)                                                    # sheared / trapezoid
+        rot = np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]])
+        quads.append(base @ rot.T + [cx, cy])
+    accepted = usable_quads = 0
+    for quad in quads:
+        n = 600
+        x0 = rng.integers(0, 250, n); y0 = rng.integers(0, 250, n)
+        x1 = np.minimum(255, x0 + rng.integers(0, 24, n)); y1 = np.minimum(255, y0 + rng.integers(0, 6, n))
+        boxes = np.stack([x0, x1, y0, y1], 1)
+        usable, inside = ssd.grid_boxes_device(quad, x_min, y_min, box, box, boxes, gpu_device)
+        if not usable:
+            assert not inside.any()
+            continue
+        usable_quads += 1
+        sel = boxes[inside != 0]
+        accepted += len(sel)
+        if len(sel) == 0:
+            continue
+        # the world rectangle a box stands for, widened as K1's truncation may have misplaced a point
+        e = 1.0e-9
+        X0, X1 = x_min + sel[:, 0] / box - e, x_min + (sel[:, 1] + 1) / box + e
+        Y0, Y1 = y_min + sel[:, 2] / box - e, y_min + (sel[:, 3] + 1) / box + e
+        u = rng.uniform(0, 1, (len(sel), 12, 2))
+        u[:, 0] = [0, 0]; u[:, 1] = [1, 0]; u[:, 2] = [0, 1]; u[:, 3] = [1, 1]
+        u[:, 4] = [0.5, 0]; u[:, 5] = [0.5, 1]; u[:, 6] = [0, 0.5]; u[:, 7] = [1, 0.5]
+        pts = np.stack([X0[:, None] + u[:, :, 0] * (X1 - X0)[:, None], Y0[:, None] + u[:, :, 1] * (Y1 - Y0)[:, None]], 2).reshape(-1, 2)
+        err, ok = ssd.quad_test_device(quad, pts, gpu_device)
+        assert err == 0
+        assert ok.all(), ("a point of a box classified as inside fails the quadrilateral test", quad.tolist(), pts[ok == 0][:3].tolist())
+    assert usable_quads >= 50 and accepted > 2000, (usable_quads, accepted)
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_riser_evidence_matches_the_cpu_statement(ssd, oracle, gpu_device, name):
     """Extension (no reference counterpart): the evidence of the vertical faces gathered by
