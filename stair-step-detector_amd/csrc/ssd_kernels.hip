@@ -2012,10 +2012,16 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
                                     }, cellList, listScratch);
   const int nGroups = (count + 3) >> 2;
   const int gEnd = ((tid >> 6) + 1) * nGroups / kWavesPerBlock;
-  for(int g = (tid >> 6) * nGroups / kWavesPerBlock; g < gEnd; g++)
-  {
-    F3 v[kPts];
+  /* the loads of the NEXT group issued before the current one is processed (as in k_raster): 0.89 -> 0.86 ms even though
+   * the second register buffer costs 7 VGPR spills at 8 waves per SIMD; with 7 / 6 waves and no spills: 0.90 / 0.98 ms */
+  int g = (tid >> 6) * nGroups / kWavesPerBlock;
+  F3 v[kPts], vn[kPts];
+  if(g < gEnd)
     load_cell<SRC>(base, cell0, cellList, 4 * g + (lane >> 4), count, lane, P.nPoints, v, D);
+  for( ; g < gEnd; g++)
+  {
+    if(g + 1 < gEnd)
+      load_cell<SRC>(base, cell0, cellList, 4 * (g + 1) + (lane >> 4), count, lane, P.nPoints, vn, D);
     unsigned int key[kPts];
     #pragma unroll
     for(int j = 0; j < kPts; j++)
@@ -2053,6 +2059,9 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
       }
     }
     wavewin_emit(ww, wm, win, gimg, imgWords, X.W64, X.winShiftGround, box, key, lane);
+#pragma unroll
+    for(int j = 0; j < kPts; j++)
+      v[j] = vn[j];
   }
   wavewin_flush(ww, win, gimg, imgWords, X.W64, X.winShiftGround, box, lane);
   wavemiss_flush(wm, box, lane);
