@@ -398,6 +398,8 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   HIP_TRY_H(hipMalloc(&h->dTileMasks, h->tileMaskStride * sizeof(uint2) * h->F));
   HIP_TRY_H(hipMalloc(&h->dResults, sizeof(ssd_frame_result) * h->F * 2));
   HIP_TRY_H(hipHostMalloc(&h->hResults, sizeof(ssd_frame_result) * h->F * 2, hipHostMallocDefault));
+  std::memset(h->hResults, 0, sizeof(ssd_frame_result) * h->F * 2);
+  HIP_TRY_H(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->hResultsDev), h->hResults, 0));
   HIP_TRY_H(hipEventCreateWithFlags(&h->resultsReady[0], hipEventDisableTiming));
   HIP_TRY_H(hipEventCreateWithFlags(&h->resultsReady[1], hipEventDisableTiming));
   HIP_TRY_H(hipEventCreateWithFlags(&h->lastDone, hipEventDisableTiming));
@@ -565,6 +567,8 @@ static int choose_chunk(int nPoints, int nframes)
   return chunk;
 }
 
+static constexpr int kDirectResultFrames = 64;
+
 static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_bytes, int nframes, void *stream, int stages, bool depthInput)
 {
   if(!h || !d_xyz)
@@ -660,19 +664,25 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   if(stages & SSD_STAGE_INQUAD)
     launch_inquad(xyz, strideFloats, P, h->dState, h->dGroundImg, h->dTileMasks, h->tileMaskStride, nframes, chunkInquad, depth, s);
   mark();
+  /* The results leave with the batch, into this enqueue's pinned slot (event for ssd_fetch / ssd_fetch_back).  A few frames:
+   * k_final stores them there itself — a kilobyte per frame of posted writes, visible to the host once the event has
+   * fired — instead of a device-to-host copy command behind the kernel (single frame: one command less in the chain).
+   * Batches go through device memory and one copy: a megabyte of scattered stores over PCIe would hold k_final's blocks. */
+  const int slot = static_cast<int>(h->finalCount & 1ull);
+  const bool direct = nframes <= kDirectResultFrames && h->hResultsDev != nullptr;
   if(stages & SSD_STAGE_FINAL)
   {
-    launch_final(P, h->dState, h->dGroundImg, h->dResults + static_cast<size_t>(h->finalCount & 1ull) * h->F, nframes, dbg, dbgImg, s);
+    ssd_frame_result *out = (direct ? h->hResultsDev : h->dResults) + static_cast<size_t>(slot) * h->F;
+    launch_final(P, h->dState, h->dGroundImg, out, nframes, dbg, dbgImg, s);
     if(P.risers)
       launch_risers(xyz, strideFloats, P, h->dState, h->dTileMasks, h->tileMaskStride, h->dRisers, nframes, chunk, depth, s);
   }
   mark();
   if(stages & SSD_STAGE_FINAL)
   {
-    /* the results leave with the batch: copy into this enqueue's pinned slot, event for ssd_fetch / ssd_fetch_back */
-    const int slot = static_cast<int>(h->finalCount & 1ull);
-    HIP_TRY(hipMemcpyAsync(h->hResults + static_cast<size_t>(slot) * h->F, h->dResults + static_cast<size_t>(slot) * h->F,
-                           sizeof(ssd_frame_result) * nframes, hipMemcpyDeviceToHost, s));
+    if(!direct)
+      HIP_TRY(hipMemcpyAsync(h->hResults + static_cast<size_t>(slot) * h->F, h->dResults + static_cast<size_t>(slot) * h->F,
+                             sizeof(ssd_frame_result) * nframes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(h->resultsReady[slot], s));
     h->resultsFrames[slot] = nframes;
     h->finalCount++;

@@ -27,6 +27,7 @@ struct ssd_handle
    * a batch's results is part of its enqueue, so that the next batch can be enqueued before the results are read */
   ssd_frame_result *dResults = nullptr;     /* 2 x F */
   ssd_frame_result *hResults = nullptr;     /* 2 x F, pinned */
+  ssd_frame_result *hResultsDev = nullptr;  /* the same memory as the kernels address it (small batches write it directly) */
   hipEvent_t resultsReady[2] = { nullptr, nullptr };
   int resultsFrames[2] = { 0, 0 };
   unsigned long long finalCount = 0;        /* enqueues that produced results */

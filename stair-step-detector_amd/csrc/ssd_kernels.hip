@@ -23,6 +23,16 @@
 namespace ssd
 {
 
+/* Phase clocks of the latency-bound kernels (tools/phases.py; a tools-only build: make EXTRA=-DSSD_PHASE_TIMING
+ * OUT=../lib_phase).  Block (0, 0) leaves wall_clock64() — 100 MHz — at the marked places. */
+#ifdef SSD_PHASE_TIMING
+__device__ unsigned long long g_phase[4][32];
+#define SSD_PHASE_IF(cond, k, i) do { if(blockIdx.x == 0 && blockIdx.y == 0 && (cond)) g_phase[k][i] = wall_clock64(); } while(0)
+#else
+#define SSD_PHASE_IF(cond, k, i) do { } while(0)
+#endif
+#define SSD_PHASE(k, i) SSD_PHASE_IF(threadIdx.x == 0, k, i)
+
 /* ========================================================================= */
 /* shared per-point arithmetic                                                */
 
@@ -1108,6 +1118,80 @@ __device__ __forceinline__ void closed_column(const BitImg &im, int c, int yA, i
   }
 }
 
+/* The closed image at ONE pixel column x, rows [yA, yB) top to bottom: hit(y) for every closed pixel (x, y).
+ * The scans of the outline want nothing else of the closed image than its first and last lit row in every 25th (50th)
+ * column, and the closing at (x, y) is a function of the raw 5 x 5 neighbourhood only: per row a 5-bit strip of the raw
+ * row (pixels x-2 .. x+2; two 32-bit loads and a funnel shift), its horizontal dilation at x-1, x, x+1 (3 bits), then the
+ * vertical dilation and the erosion on those 3-bit values — a dozen 32-bit operations per row, against some hundred 64-bit
+ * ones for a whole closed word.  Same definition as closed_from_rows: pixels outside the image never veto the erosion and
+ * never feed the dilation (cv::morphologyEx, default border; segmentation.cpp:888,928). */
+struct ColumnStrip
+{
+  const unsigned int *row0;      /* the image as 32-bit words */
+  long long stride;              /* 32-bit words per row */
+  int i0, i1, sh, H;             /* word indices of pixel x-2 and of the word after it (-1: outside), shift of pixel x-2 */
+  unsigned int ignore;           /* of x-1, x, x+1 the positions outside the image */
+};
+__device__ __forceinline__ ColumnStrip column_strip(const BitImg &im, int x)
+{
+  ColumnStrip c;
+  c.row0 = reinterpret_cast<const unsigned int *>(im.w);
+  c.stride = 2ll * im.W64;
+  const int xs = x - 2;
+  const int w = xs >> 5;                               /* arithmetic: -1 for xs < 0 */
+  c.sh = xs & 31;
+  c.i0 = (w >= 0 && w < 2 * im.W64) ? w : -1;
+  c.i1 = (w + 1 >= 0 && w + 1 < 2 * im.W64) ? w + 1 : -1;
+  c.H = im.H;
+  c.ignore = (x - 1 < 0 ? 1u : 0u) | (x + 1 >= im.W ? 4u : 0u);
+  return c;
+}
+/* horizontally dilated raw row yy at x-1, x, x+1 (3 bits); rows outside the image read as zero */
+__device__ __forceinline__ unsigned int strip_hdil(const ColumnStrip &c, int yy, int yEnd)
+{
+  const bool in = yy >= 0 && yy < c.H && yy < yEnd;
+  const unsigned int *r = c.row0 + static_cast<long long>(in ? yy : 0) * c.stride;
+  const unsigned int lo = (in && c.i0 >= 0) ? r[c.i0] : 0u;
+  const unsigned int hi = (in && c.i1 >= 0) ? r[c.i1] : 0u;
+  const unsigned int v = __funnelshift_r(lo, hi, c.sh) & 31u;
+  return (v | (v >> 1) | (v >> 2)) & 7u;
+}
+template<typename Hit>
+__device__ __forceinline__ void closed_scan_column(const BitImg &im, int x, int yA, int yB, Hit hit)
+{
+  constexpr int kRows = 16;                            /* rows per step: their loads are issued together */
+  const int yEnd = yB + 2;                             /* rows from here on feed no row of the band: not loaded */
+  const ColumnStrip c = column_strip(im, x);
+  /* h[i] = the dilated strip of row y0 - 2 + i.  The four rows above the band are loaded with the first step's rows:
+   * nothing is consumed before all of them are under way (a band is a chain of memory round trips and little else) */
+  unsigned int h[kRows + 4];
+#pragma unroll
+  for(int k = 0; k < 4; k++)
+    h[k] = strip_hdil(c, yA - 2 + k, yEnd);
+  for(int y0 = yA; y0 < yB; y0 += kRows)
+  {
+#pragma unroll
+    for(int k = 0; k < kRows; k++)
+      h[4 + k] = strip_hdil(c, y0 + 2 + k, yEnd);
+    /* f bit i: the dilated image is lit at every in-image pixel of x-1 .. x+1 in row y0 - 2 + i (rows outside: set) */
+    unsigned int f = 0u;
+#pragma unroll
+    for(int i = 1; i < kRows + 3; i++)
+    {
+      const int yy = y0 - 2 + i;
+      const bool full = yy < 0 || yy >= c.H || ((h[i - 1] | h[i] | h[i + 1] | c.ignore) & 7u) == 7u;
+      f |= full ? 1u << i : 0u;
+    }
+#pragma unroll
+    for(int k = 0; k < kRows; k++)
+      if(y0 + k < yB && ((f >> (k + 1)) & 7u) == 7u)
+        hit(y0 + k);
+#pragma unroll
+    for(int k = 0; k < 4; k++)
+      h[k] = h[kRows + k];
+  }
+}
+
 /* ========================================================================= */
 /* BestLine (segmentation.cpp:409-487), one wave per point list                */
 
@@ -1182,17 +1266,72 @@ __device__ double line_residual_keys(const int *px, const int *py, int m, int p,
   return static_cast<int>(sum) / (n * hypot_ref(static_cast<double>(line.a), static_cast<double>(line.b)));
 }
 
-/* all 64 lanes of the calling wave take part; result is returned in every lane */
-__device__ LineI wave_best_line(const int *px, const int *py, int m, int lane, bool smallImage)
+/* The same sum for lists of at most 64 points held one per lane (myX, myY of lane i = point i), in ONE walk over the
+ * points: the D >= n + 2 smallest distances are kept sorted in registers (insertion by a min / med3 network, D operations
+ * per point), so nothing has to tell a later pass which ones were taken already — plain distances, equal ones included,
+ * sum up to the same total whichever of them is counted.  The walk reads the points with v_readlane (a few cycles) instead
+ * of LDS (a round trip per point in a lone wave); the products are 24-bit multiplies (|a| <= H, |b| <= W, coordinates
+ * < 2^12: exact).  11 + D vector instructions per point against 15 per point and pass of four. */
+template<int D>
+__device__ __forceinline__ unsigned int smallest_sum_lanes(int myX, int myY, int m, const LineI &line, int need)
+{
+  unsigned int b[D];
+#pragma unroll
+  for(int j = 0; j < D; j++)
+    b[j] = 0xffffffffu;
+  for(int i = 0; i < m; i++)
+  {
+    const int x = __builtin_amdgcn_readlane(myX, i), y = __builtin_amdgcn_readlane(myY, i);
+    const unsigned int d = static_cast<unsigned int>(abs(__mul24(x, line.a) + __mul24(y, line.b) + line.c));
+#pragma unroll
+    for(int j = D - 1; j > 0; j--)
+      b[j] = umed3(b[j - 1], b[j], d);
+    b[0] = min(b[0], d);
+  }
+  unsigned int sum = 0;
+#pragma unroll
+  for(int j = 0; j < D; j++)
+    sum += j < need ? b[j] : 0u;
+  return sum;
+}
+
+__device__ __forceinline__ double line_residual_lanes(int myX, int myY, int m, int p, int q, LineI &line)
+{
+  line = line_through_i(__shfl(myX, p), __shfl(myY, p), __shfl(myX, q), __shfl(myY, q));
+  if(m <= 2)
+    return 0.0;
+  const int nd = m - 2;
+  const int n = nd > 4 ? (nd - 1) / 2 : 1;
+  const int need = n + 2;                      /* <= 32 for m <= 64; the pair's own two points are the two zeros */
+  unsigned int sum;
+  if(need <= 4) sum = smallest_sum_lanes<4>(myX, myY, m, line, need);
+  else if(need <= 8) sum = smallest_sum_lanes<8>(myX, myY, m, line, need);
+  else if(need <= 12) sum = smallest_sum_lanes<12>(myX, myY, m, line, need);
+  else if(need <= 16) sum = smallest_sum_lanes<16>(myX, myY, m, line, need);
+  else if(need <= 24) sum = smallest_sum_lanes<24>(myX, myY, m, line, need);
+  else sum = smallest_sum_lanes<32>(myX, myY, m, line, need);
+  return static_cast<int>(sum) / (n * hypot_ref(static_cast<double>(line.a), static_cast<double>(line.b)));
+}
+
+/* all 64 lanes of the calling wave take part, on the pairs tStart + lane, tStart + tStride + lane, ..: the best of them
+ * (residual, pair index, line; pair index 0x7fffffff = none) is returned in every lane */
+__device__ void wave_best_line_part(const int *px, const int *py, int m, int lane, bool smallImage, int tStart, int tStride,
+                                    double &bestRes, int &bestT, LineI &bestLine)
 {
   const int nPairs = m * (m - 1) / 2;
-  double bestRes = 1.0e300;
-  int bestT = 0x7fffffff;
-  LineI bestLine{ 0, 0, 0 };
-  for(int t = lane; t < nPairs; t += 64)
+  bestRes = 1.0e300;
+  bestT = 0x7fffffff;
+  bestLine = LineI{ 0, 0, 0 };
+  const bool inLanes = smallImage && m <= 64;
+  const int myX = inLanes && lane < m ? px[lane] : 0, myY = inLanes && lane < m ? py[lane] : 0;
+  /* every lane runs the same number of rounds (the lanes' points are exchanged by shuffles); a lane without a pair
+   * works on pair 0 and discards the result */
+  for(int t0 = tStart; t0 < nPairs; t0 += tStride)
   {
+    const int t = t0 + lane;
+    const bool real = t < nPairs;
     /* decode pair t in the order of the reference's double loop (p ascending, q > p ascending) */
-    int p = 0, rem = t;
+    int p = 0, rem = real ? t : 0;
     while(rem >= m - 1 - p)
     {
       rem -= m - 1 - p;
@@ -1200,8 +1339,12 @@ __device__ LineI wave_best_line(const int *px, const int *py, int m, int lane, b
     }
     const int q = p + 1 + rem;
     LineI l;
-    const double r = smallImage && m <= 128 ? line_residual_keys(px, py, m, p, q, l) : line_residual_generic(px, py, m, p, q, l);
-    if(bestT == 0x7fffffff || r < bestRes)     /* min_element: first of equal minima (t ascends per lane) */
+    double r;
+    if(inLanes)
+      r = line_residual_lanes(myX, myY, m, p, q, l);
+    else
+      r = smallImage && m <= 128 ? line_residual_keys(px, py, m, p, q, l) : line_residual_generic(px, py, m, p, q, l);
+    if(real && (bestT == 0x7fffffff || r < bestRes))     /* min_element: first of equal minima (t ascends per lane) */
     {
       bestRes = r;
       bestT = t;
@@ -1222,12 +1365,29 @@ __device__ LineI wave_best_line(const int *px, const int *py, int m, int lane, b
       bestRes = oRes; bestT = oT; bestLine.a = oa; bestLine.b = ob; bestLine.c = oc;
     }
   }
-  return bestLine;
+}
+
+/* one wave, all pairs */
+__device__ LineI wave_best_line(const int *px, const int *py, int m, int lane, bool smallImage)
+{
+  double res;
+  int t;
+  LineI l;
+  wave_best_line_part(px, py, m, lane, smallImage, 0, 64, res, t, l);
+  return l;
 }
 
 /* ========================================================================= */
 /* K3: outline of one step plateau image — one workgroup per (slot, frame)      */
 
+/* threads of the image kernels (K3, K5): one block per image, a chain of short phases.  More waves = fewer rows per
+ * thread in the closing (latency), but the arithmetic phases (BestLine) run at the CU's rate whatever the count, and every
+ * barrier and every per-wave preamble is paid per wave: measured on 1024 XGA frames, K3 takes 0.106 / 0.146 / 0.307 ms with
+ * 256 / 512 / 1024 threads, on a single frame 30 / 26.5 / 28 us.  Hence two instantiations: 256 for batches, 512 for a few
+ * frames. */
+constexpr int kImgThreadsBatch = 256, kImgThreadsFew = 512;   /* chosen per launch (launch_outline / launch_final) */
+constexpr int kMaxImgWaves = kImgThreadsFew / 64;
+constexpr int kImgFewFrames = 64;
 constexpr int kMaxCols = SSD_MAX_SCANS;      /* scan columns per image (W/25 + 1 <= 128) */
 constexpr int kMaxProbe = SSD_MAX_EDGE_PTS;  /* probe rows per vertical edge (H/10 + 1 <= 256) */
 
@@ -1246,11 +1406,16 @@ struct OutlineShared
   double vdist[2][kMaxProbe];
   int vBest[2];
   LineD baseLine;
+  LineD nline[4];                            /* the edges' lines normalised, left edges reversed (calcBaseLine) */
+  double partRes[kMaxImgWaves];                 /* BestLine: every wave's best over its share of its edge's pairs */
+  int partT[kMaxImgWaves];
+  LineI partLine[kMaxImgWaves];
   double bounds[4][2][2];
   unsigned int status;
 };
 
-__global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__restrict__ st,
+template<int T>
+__global__ __launch_bounds__(T) void k_outline(Params P, FrameState *__restrict__ st,
                                                       unsigned long long *__restrict__ stepImg,
                                                       DebugFrame *__restrict__ dbg,
                                                       unsigned long long *__restrict__ dbgImg)
@@ -1268,6 +1433,7 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
   const size_t imgWords = static_cast<size_t>(P.H) * P.W64;
   unsigned long long *img = stepImg + (static_cast<size_t>(frame) * P.maxStepImages + slot) * imgWords;
   const BitImg im{ img, P.W, P.H, P.W64 };
+  SSD_PHASE(0, 0);
 
   /* scan columns: x_j = xr0 + 25 j; the centre column xc = W/2 is j = jc */
   const int xStep = 25;
@@ -1276,7 +1442,7 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
   const int jc = xc / xStep;
   const int nCols = min(kMaxCols, (P.W - 1 - xr0) / xStep + 1);
 
-  for(int j = tid; j < kMaxCols; j += kThreads)
+  for(int j = tid; j < kMaxCols; j += T)
   {
     S.yFirst[j] = 0x7fffffff;
     S.ySecond[j] = -1;
@@ -1291,6 +1457,7 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
     S.vProbe[0] = S.vProbe[1] = 0;
   }
   __syncthreads();
+  SSD_PHASE(0, 1);
 
   /* ---- phase B: closed image, column extents (Scanner::probeVertical, segmentation.cpp:88-111) ---- */
   unsigned long long *dbgRaw = nullptr, *dbgClosed = nullptr;
@@ -1311,93 +1478,122 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
     by0 = 0; by1 = P.H - 1; bc0 = 0; bc1 = P.W64 - 1;
   }
   const int bw = emptyImg && !dbgImg ? 0 : bc1 - bc0 + 1, bh = emptyImg && !dbgImg ? 0 : by1 - by0 + 1;
-  /* thread -> (word column, band of rows): neighbouring threads read neighbouring words */
-  const int nBands = bw > 0 ? max(1, kThreads / bw) : 0;
-  const int bandRows = nBands > 0 ? (bh + nBands - 1) / nBands : 0;
-  for(int t = tid; t < bw * nBands; t += kThreads)
+  if(dbgImg)
   {
-    const int band = t / bw;
-    const int c = bc0 + (t - band * bw);
-    const int yA = by0 + band * bandRows, yB = min(yA + bandRows, by1 + 1);
-    closed_column(im, c, yA, yB, dbgImg != nullptr, [&](int y, unsigned long long cw)
+    /* debug capture: the raw and the closed image whole, word by word (thread -> word column, band of rows) */
+    const int nBands = bw > 0 ? max(1, T / bw) : 0;
+    const int bandRows = nBands > 0 ? (bh + nBands - 1) / nBands : 0;
+    for(int t = tid; t < bw * nBands; t += T)
     {
-      if(dbgImg)
+      const int band = t / bw;
+      const int c = bc0 + (t - band * bw);
+      const int yA = by0 + band * bandRows, yB = min(yA + bandRows, by1 + 1);
+      closed_column(im, c, yA, yB, true, [&](int y, unsigned long long cw)
       {
         dbgRaw[y * P.W64 + c] = img[y * P.W64 + c];
         dbgClosed[y * P.W64 + c] = cw;
+      });
+    }
+  }
+  /* the scan columns inside the box, each cut into bands of rows: thread -> (column, band); first and last closed row of
+   * the band in registers, one LDS atomic pair per thread */
+  if(bw > 0)
+  {
+    const int xLo = 64 * bc0, xHi = min(64 * bc1 + 63, P.W - 1);
+    const int jLo = xLo <= xr0 ? 0 : (xLo - xr0 + xStep - 1) / xStep;
+    const int jHi = xHi < xr0 ? -1 : min(nCols - 1, (xHi - xr0) / xStep);
+    const int nJ = jHi - jLo + 1;
+    const int nBands = nJ > 0 ? max(1, T / nJ) : 0;
+    const int bandRows = nBands > 0 ? (bh + nBands - 1) / nBands : 0;
+    for(int t = tid; t < nJ * nBands; t += T)
+    {
+      const int band = t / nJ;
+      const int j = jLo + (t - band * nJ);
+      const int yA = by0 + band * bandRows, yB = min(yA + bandRows, by1 + 1);
+      int yLo = 0x7fffffff, yHi = -1;
+      closed_scan_column(im, xr0 + xStep * j, yA, yB, [&](int y)
+      {
+        yLo = min(yLo, y);
+        yHi = y;
+      });
+      if(yHi >= 0)
+      {
+        atomicMin(&S.yFirst[j], yLo);
+        atomicMax(&S.ySecond[j], yHi);
       }
-      if(cw == 0ull)
-        return;
-      const int x0 = 64 * c;
-      int j = x0 <= xr0 ? 0 : (x0 - xr0 + xStep - 1) / xStep;
-      for(int x = xr0 + xStep * j; x < x0 + 64 && j < nCols; x += xStep, j++)
-        if((cw >> (x - x0)) & 1ull)
-        {
-          atomicMin(&S.yFirst[j], y);
-          atomicMax(&S.ySecond[j], y);
-        }
-    });
+    }
   }
   __syncthreads();
+  SSD_PHASE(0, 2);
 
   /* ---- phase C: scans (Scanner::scan :59-85, HorizontalEdgesDetector::detect :607-620),
    *      point lists (Scanner::obtainLinePoints :129-156) ---- */
-  if(tid == 0)
   {
+    /* every wave counts for itself (ballots over the columns' "long enough" bits, no serial walk through LDS) */
+    bool ok0 = false, ok1 = false;
+    if(lane < nCols)
+      ok0 = S.ySecond[lane] >= 0 && S.ySecond[lane] - S.yFirst[lane] >= P.minImgYExtent;
+    if(lane + 64 < nCols)
+      ok1 = S.ySecond[lane + 64] >= 0 && S.ySecond[lane + 64] - S.yFirst[lane + 64] >= P.minImgYExtent;
+    const unsigned long long okLo = __ballot(ok0), okHi = __ballot(ok1);
+    auto okAt = [&](int j) { return j >= 0 && j < nCols && (((j < 64 ? okLo : okHi) >> (j & 63)) & 1ull) != 0ull; };
     int nR = 0, nL = 0;
-    for(int j = jc; j < nCols; j++)
-    {
-      if(S.ySecond[j] < 0) break;
-      if(S.ySecond[j] - S.yFirst[j] < P.minImgYExtent) break;
+    while(okAt(jc + nR))
       nR++;
-    }
     if(nR > 0)
-      for(int j = jc - 1; j >= 0; j--)
-      {
-        if(S.ySecond[j] < 0) break;
-        if(S.ySecond[j] - S.yFirst[j] < P.minImgYExtent) break;
+      while(okAt(jc - 1 - nL))
         nL++;
-      }
-    S.nRight = nR;
-    S.nLeft = nL;
-    if(nR > 0 && nR + nL >= 3)
+    const bool found = nR > 0 && nR + nL >= 3;
+    /* The four point lists (Scanner::obtainLinePoints :129-156).  Its pushes come out as two runs of consecutive columns:
+     * the right lists take the columns cR0, cR0 + 1, .. (nRl of them), the left lists cL0, cL0 - 1, .. (nLl), with
+     * cR0 = cL0 = the column where the reference starts: as many columns of the longer side as put total/2 + 1 on it. */
+    const int total = nR + nL;
+    const int half = total / 2 + 1;
+    int c0, nRl, nLl;
+    if(nL >= half)
     {
-      S.found = 1;
-      /* scan s of the right list is column jc + s, of the left list column jc - 1 - s */
-      int n[4] = { 0, 0, 0, 0 };
-      auto push = [&](bool toRight, int j)
+      const int a = nL - half;
+      c0 = jc - 1 - a;
+      nRl = a + 1 + nR;
+      nLl = half;
+    }
+    else
+    {
+      const int b = nR > half ? nR - half : 0;
+      c0 = jc + b;
+      nRl = nR - b;
+      nLl = b + 1 + nL;
+    }
+    if(found)
+    {
+      for(int k = tid; k < nRl; k += T)
       {
-        const int x = xr0 + xStep * j;
-        const int f = toRight ? kFR : kFL, b = toRight ? kBR : kBL;
-        S.ex[f][n[f]] = x; S.ey[f][n[f]] = S.ySecond[j]; n[f]++;
-        S.ex[b][n[b]] = x; S.ey[b][n[b]] = S.yFirst[j]; n[b]++;
-      };
-      const int total = nR + nL;
-      const int half = total / 2 + 1;
-      int indLeft = 0, indRight = 0;
-      if(nL >= half)
-      {
-        indLeft = nL - half;
-        for(int i = indLeft; i >= 0; i--)
-          push(true, jc - 1 - i);
+        const int j = c0 + k, x = xr0 + xStep * j;
+        S.ex[kFR][k] = x; S.ey[kFR][k] = S.ySecond[j];
+        S.ex[kBR][k] = x; S.ey[kBR][k] = S.yFirst[j];
       }
-      else
+      for(int k = tid; k < nLl; k += T)
       {
-        if(nR > half)
-          indRight = nR - half;
-        for(int i = indRight; i >= 0; i--)
-          push(false, jc + i);
+        const int j = c0 - k, x = xr0 + xStep * j;
+        S.ex[kFL][k] = x; S.ey[kFL][k] = S.ySecond[j];
+        S.ex[kBL][k] = x; S.ey[kBL][k] = S.yFirst[j];
       }
-      for( ; indRight < nR; indRight++)
-        push(true, jc + indRight);
-      for( ; indLeft < nL; indLeft++)
-        push(false, jc - 1 - indLeft);
-      for(int e = 0; e < 4; e++)
-        S.en[e] = n[e];
+    }
+    if(tid == 0)
+    {
+      S.nRight = nR;
+      S.nLeft = nL;
+      if(found)
+      {
+        S.found = 1;
+        S.en[kFR] = S.en[kBR] = nRl;
+        S.en[kFL] = S.en[kBL] = nLl;
+      }
     }
   }
   __syncthreads();
 
+  SSD_PHASE(0, 3);
   if(dp && tid == 0)
   {
     dp->n_scans_right = S.nRight;
@@ -1410,52 +1606,76 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
 
   if(S.found)
   {
-    /* ---- BestLine per horizontal edge: wave w takes edge w (HorizontalEdges::Edge :570-583) ---- */
+    /* ---- BestLine per horizontal edge: wave w takes edge w (HorizontalEdges::Edge :570-583), then the edge's
+     *      BoundaryPoints (:521-552): the first and the last list point within 10 pixels of the line, by ballots ---- */
+    static_assert((T / 64) % 4 == 0, "the waves are dealt out over the four edges");
     {
-      const LineI l = wave_best_line(S.ex[wave], S.ey[wave], S.en[wave], lane, 3ll * P.W * P.H < (1ll << 25));
+      /* wave w works on edge w % 4, on every ((T / 64) / 4)-th round of 64 pairs */
+      constexpr int kParts = (T / 64) / 4;
+      double res;
+      int t;
+      LineI l;
+      wave_best_line_part(S.ex[wave & 3], S.ey[wave & 3], S.en[wave & 3], lane, 3ll * P.W * P.H < (1ll << 25), 64 * (wave >> 2), 64 * kParts, res, t, l);
       if(lane == 0)
-        S.line[wave] = l;
+      {
+        S.partRes[wave] = res;
+        S.partT[wave] = t;
+        S.partLine[wave] = l;
+      }
     }
     __syncthreads();
-
-    /* ---- BoundaryPoints (:521-552), base line (:672-679), detectEdge windows (:681-697) ---- */
-    if(tid == 0)
+    if(wave < 4)
     {
-      for(int e = 0; e < 4; e++)
+      const int e = wave, n = S.en[e];
+      /* the parts' bests combined: smallest residual, ties to the smaller pair index (min_element's first of equals) */
+      int best = -1;
+      for(int w = e; w < (T / 64); w += 4)
+        if(S.partT[w] != 0x7fffffff && (best < 0 || S.partRes[w] < S.partRes[best] || (S.partRes[w] == S.partRes[best] && S.partT[w] < S.partT[best])))
+          best = w;
+      const LineI l = best >= 0 ? S.partLine[best] : LineI{ 0, 0, 0 };
+      const double fm = static_cast<double>(-l.a) / l.b;       /* FlatLine :508-511 */
+      const double fn = static_cast<double>(-l.c) / l.b;
+      int first = -1, last = -1;
+      for(int i0 = 0; i0 < n; i0 += 64)
       {
-        const LineI l = S.line[e];
-        const double fm = static_cast<double>(-l.a) / l.b;       /* FlatLine :508-511 */
-        const double fn = static_cast<double>(-l.c) / l.b;
-        double in[2] = { -1.0, -1.0 }, out[2] = { -1.0, -1.0 };
-        for(int i = 0; i < S.en[e]; i++)
+        const int i = i0 + lane;
+        const bool near = i < n && fabs(S.ex[e][i < n ? i : 0] * fm + fn - S.ey[e][i < n ? i : 0]) < 10;
+        const unsigned long long m = __ballot(near);
+        if(m != 0ull)
         {
-          const double yy = S.ex[e][i] * fm + fn;
-          if(fabs(yy - S.ey[e][i]) < 10)
-          {
-            in[0] = S.ex[e][i]; in[1] = yy;
-            break;
-          }
+          if(first < 0)
+            first = i0 + __ffsll(static_cast<long long>(m)) - 1;
+          last = i0 + 63 - __clzll(static_cast<long long>(m));
         }
-        for(int i = S.en[e] - 1; i >= 0; i--)
+      }
+      if(lane == 0)
+      {
+        S.line[e] = l;
+        double in[2] = { -1.0, -1.0 }, out[2] = { -1.0, -1.0 };
+        if(first >= 0)
         {
-          const double yy = S.ex[e][i] * fm + fn;
-          if(fabs(yy - S.ey[e][i]) < 10)
-          {
-            out[0] = S.ex[e][i]; out[1] = yy;
-            break;
-          }
+          in[0] = S.ex[e][first]; in[1] = S.ex[e][first] * fm + fn;
+          out[0] = S.ex[e][last]; out[1] = S.ex[e][last] * fm + fn;
         }
         if((in[0] == -1.0 && in[1] == -1.0) || (out[0] == -1.0 && out[1] == -1.0))
-          S.status |= SSD_ST_ASSERT;
+          atomicOr(&S.status, static_cast<unsigned int>(SSD_ST_ASSERT));
         S.bounds[e][0][0] = in[0]; S.bounds[e][0][1] = in[1];
         S.bounds[e][1][0] = out[0]; S.bounds[e][1][1] = out[1];
+        /* calcBaseLine's first step, one edge per wave: left edges reversed */
+        const bool leftEdge = e == kFL || e == kBL;
+        S.nline[e] = leftEdge ? normalized_line(-l.a, -l.b, -l.c) : normalized_line(l.a, l.b, l.c);
       }
+    }
+    __syncthreads();
+    SSD_PHASE(0, 4);
+
+    /* ---- base line (:672-679), detectEdge windows (:681-697) ---- */
+    if(tid == 0)
+    {
       /* calcBaseLine: bisectors of (reversed left, right) front and back lines, then of those two;
        * slope-corrected by xyRatio^2, perpendicular through the first front-left point */
-      const LineI fl = S.line[kFL], frl = S.line[kFR], bl = S.line[kBL], brl = S.line[kBR];
-      const LineD nfl = normalized_line(-fl.a, -fl.b, -fl.c), nfr = normalized_line(frl.a, frl.b, frl.c);
+      const LineD nfl = S.nline[kFL], nfr = S.nline[kFR], nbl = S.nline[kBL], nbr = S.nline[kBR];
       const LineD front{ nfl.a + nfr.a, nfl.b + nfr.b, nfl.c + nfr.c };
-      const LineD nbl = normalized_line(-bl.a, -bl.b, -bl.c), nbr = normalized_line(brl.a, brl.b, brl.c);
       const LineD back{ nbl.a + nbr.a, nbl.b + nbr.b, nbl.c + nbr.c };
       const LineD nf = normalized_line(front.a, front.b, front.c), nb = normalized_line(back.a, back.b, back.c);
       const LineD center{ nf.a + nb.a, nf.b + nb.b, nf.c + nb.c };
@@ -1496,11 +1716,12 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
       }
     }
     __syncthreads();
+    SSD_PHASE(0, 5);
 
     /* ---- phase D: row probes (VerticalEdgePointsDetector :243-312) on freshly closed rows ---- */
     {
       const int np0 = S.vProbe[0], np1 = S.vProbe[1];
-      for(int t = tid; t < np0 + np1; t += kThreads)
+      for(int t = tid; t < np0 + np1; t += T)
       {
         const int side = t < np0 ? 0 : 1;
         const int k = side == 0 ? t : t - np0;
@@ -1536,28 +1757,40 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
       }
     }
     __syncthreads();
+    SSD_PHASE(0, 6);
 
-    /* compact the probe hits in scan order (y descending), distances to the base line (:708-721) */
-    if(tid < 2)
+    /* compact the probe hits in scan order (y descending), distances to the base line (:708-721): wave 0 the left
+     * edge's, wave 1 the right edge's; places by ballot and prefix count */
+    if(wave < 2)
     {
-      const int side = tid;
+      const int side = wave, np = S.vProbe[side];
       int n = 0;
-      for(int k = 0; k < S.vProbe[side]; k++)
-        if(S.vx[side][k] >= 0)
+      for(int k0 = 0; k0 < np; k0 += 64)
+      {
+        const int k = k0 + lane;
+        const int x = k < np ? S.vx[side][k] : -1;
+        const unsigned long long m = __ballot(x >= 0);
+        if(x >= 0)
         {
-          const int x = S.vx[side][k], y = S.vYStart[side] - 10 * k;
-          S.vpx[side][n] = x;
-          S.vpy[side][n] = y;
-          S.vdist[side][n] = fabs(x * S.baseLine.a + y * S.baseLine.b + S.baseLine.c);
-          n++;
+          const int at = n + __popcll(m & ((1ull << lane) - 1ull));
+          const int y = S.vYStart[side] - 10 * k;
+          S.vpx[side][at] = x;
+          S.vpy[side][at] = y;
+          S.vdist[side][at] = fabs(x * S.baseLine.a + y * S.baseLine.b + S.baseLine.c);
         }
-      S.vn[side] = n;
-      S.vBest[side] = -1;
+        n += __popcll(m);
+      }
+      if(lane == 0)
+      {
+        S.vn[side] = n;
+        S.vBest[side] = -1;
+      }
     }
     __syncthreads();
+    SSD_PHASE(0, 7);
 
     /* findBestPoint (segmentation.cpp:708-728): the element of rank 2n/3 by distance, by counting; ties see below */
-    for(int t = tid; t < S.vn[0] + S.vn[1]; t += kThreads)
+    for(int t = tid; t < S.vn[0] + S.vn[1]; t += T)
     {
       const int side = t < S.vn[0] ? 0 : 1;
       const int i = side == 0 ? t : t - S.vn[0];
@@ -1573,21 +1806,23 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
         S.vBest[side] = i;
     }
     __syncthreads();
+    SSD_PHASE(0, 8);
 
     /* The reference sorts with std::ranges::sort (segmentation.cpp:724), which is not stable: among points at exactly
      * the same distance, the one on rank 2n/3 is whatever libstdc++'s introsort leaves there.  Only when that can
      * matter — the selected distance is duplicated AND a duplicate would give another line — the keys are sorted the
      * way the library does it (ssd_sort.h; vdist in place, vx as the payload: neither is needed afterwards). */
-    if(tid < 2 && S.vn[tid] > 0 && S.vBest[tid] >= 0)
+    if(wave < 2 && S.vn[wave] > 0 && S.vBest[wave] >= 0)
     {
-      const int side = tid, n = S.vn[side], best = S.vBest[side];
+      const int side = wave, n = S.vn[side], best = S.vBest[side];
       const double D = S.vdist[side][best];
       const double cBest = -S.baseLine.a * S.vpx[side][best] - S.baseLine.b * S.vpy[side][best];
-      bool ambiguous = false;
-      for(int k = 0; k < n; k++)
+      bool mine = false;
+      for(int k = lane; k < n; k += 64)
         if(k != best && S.vdist[side][k] == D && (-S.baseLine.a * S.vpx[side][k] - S.baseLine.b * S.vpy[side][k]) != cBest)
-          ambiguous = true;
-      if(ambiguous)
+          mine = true;
+      const bool ambiguous = __ballot(mine) != 0ull;
+      if(ambiguous && lane == 0)
       {
         for(int k = 0; k < n; k++)
           S.vx[side][k] = k;
@@ -1597,6 +1832,7 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
     }
     __syncthreads();
   }
+  SSD_PHASE(0, 9);
 
   /* ---- Corners (:731-751), quadrilateral, isConvex (:758-772), imgPointsToWorld (pointcloud.cpp:476-487) ---- */
   if(tid == 0)
@@ -1681,19 +1917,21 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
     }
   }
   __syncthreads();
+  SSD_PHASE(0, 10);
 
   /* leave the raw image zeroed for the next batch (all its bits lie inside the bounding box) */
   if(!emptyImg)
   {
     const int cy0 = fs.imgYMin[slot], cc0 = fs.imgXMin[slot];
     const int cw = fs.imgXMax[slot] - cc0 + 1, ch = fs.imgYMax[slot] - cy0 + 1;
-    for(int idx = tid; idx < cw * ch; idx += kThreads)
+    for(int idx = tid; idx < cw * ch; idx += T)
     {
       const int ry = idx / cw;
       const size_t o = static_cast<size_t>(cy0 + ry) * P.W64 + cc0 + (idx - ry * cw);
       img[o] = 0ull;                                 /* unconditionally: a load first would make every word a round trip */
     }
   }
+  SSD_PHASE(0, 11);
 }
 
 /* ========================================================================= */
@@ -1703,13 +1941,11 @@ __global__ __launch_bounds__(kThreads) void k_outline(Params P, FrameState *__re
 __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__ st, int nframes, DebugFrame *__restrict__ dbg)
 {
   static_assert(kMaxPlateaus + 1 <= 64, "one lane per accumulator");
-  __shared__ QuadBuildScratch sScratch[kMaxPlateaus + 1];
-  __shared__ QuadTest sTest[kMaxPlateaus + 1];
-  __shared__ double sQuad[kMaxPlateaus + 1][8];
   const int frame = blockIdx.x, lane = threadIdx.x;
   if(frame >= nframes)
     return;
   FrameState &fs = st[frame];
+  SSD_PHASE(1, 0);
   if(lane <= kMaxPlateaus)
   {
     fs.sumZ[lane] = 0;
@@ -1717,43 +1953,54 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
   }
   const int first = fs.firstStep, last = fs.firstStep + fs.nStepImages;
   const int groundInd = fs.groundInd;
-  const bool valid = lane >= first && lane < last && lane < kMaxPlateaus && fs.pl[lane].valid;
+  const bool mine = lane >= first && lane < last && lane < kMaxPlateaus;
+  /* every lane with an image fetches its quadrilateral before anyone knows whether it is valid: one round trip for both */
+  double quad[8];
+#pragma unroll
+  for(int k = 0; k < 8; k++)
+    quad[k] = mine ? fs.pl[lane].quadWorld[k] : 0.0;
+  const bool valid = mine && fs.pl[lane].valid;
   const unsigned long long validMask = __ballot(valid);
   const int firstValid = validMask ? __ffsll(static_cast<long long>(validMask)) - 1 : -1;
   const bool groundLane = lane == kGroundAcc && firstValid >= 0 && groundInd >= 0;
   int err = 0;
-  if(groundLane)
+  SSD_PHASE_IF(lane == firstValid, 1, 1);
   {
-    /* calcGroundQuadrilateral (pointcloud.cpp:489-512) */
+    /* calcGroundQuadrilateral (pointcloud.cpp:489-512) from the front edge of the first valid step */
+    const int srcLane = firstValid >= 0 ? firstValid : 0;
     double q[4];
+#pragma unroll
     for(int k = 0; k < 4; k++)
-      q[k] = fs.pl[firstValid].quadWorld[k];
-    const double yMin = P.yMin;
-    double *g = fs.groundQuadWorld;
-    if(q[1] < q[3])
+      q[k] = __shfl(quad[k], srcLane);
+    if(groundLane)
     {
-      g[0] = q[0]; g[1] = yMin;
-      g[2] = q[2] + (q[3] - yMin) * (q[3] - q[1]) / (q[2] - q[0]); g[3] = yMin;
+      const double yMin = P.yMin;
+      if(q[1] < q[3])
+      {
+        quad[0] = q[0]; quad[1] = yMin;
+        quad[2] = q[2] + (q[3] - yMin) * (q[3] - q[1]) / (q[2] - q[0]); quad[3] = yMin;
+      }
+      else
+      {
+        quad[0] = q[0] + (q[1] - yMin) * (q[1] - q[3]) / (q[0] - q[2]); quad[1] = yMin;
+        quad[2] = q[2]; quad[3] = yMin;
+      }
+      quad[4] = q[0]; quad[5] = q[1];
+      quad[6] = q[2]; quad[7] = q[3];
+#pragma unroll
+      for(int k = 0; k < 8; k++)
+        fs.groundQuadWorld[k] = quad[k];
     }
-    else
-    {
-      g[0] = q[0] + (q[1] - yMin) * (q[1] - q[3]) / (q[0] - q[2]); g[1] = yMin;
-      g[2] = q[2]; g[3] = yMin;
-    }
-    g[4] = q[0]; g[5] = q[1];
-    g[6] = q[2]; g[7] = q[3];
   }
+  SSD_PHASE_IF(lane == firstValid, 1, 2);
   if(groundLane || valid)
   {
-    /* built in LDS (the builder indexes its arrays at run time and re-reads what it writes: as locals they were scratch
-     * memory, 24 us per frame), stored to the frame's table once */
-    double (&quad)[8] = sQuad[lane];
-    QuadTest &t = sTest[lane];
-    const double *src = groundLane ? fs.groundQuadWorld : fs.pl[lane].quadWorld;
-    for(int k = 0; k < 8; k++)
-      quad[k] = src[k];
-    build_quad_test(quad, t, sScratch[lane]);
+    /* built in registers (ssd_quadtest.h), stored to the frame's table once */
+    QuadTest t;
+    SSD_PHASE_IF(lane == firstValid, 1, 3);
+    build_quad_test(quad, t);
     err = t.err;
+    SSD_PHASE_IF(lane == firstValid, 1, 4);
     /* one quadrilateral the reference would throw on ends the frame (quadrilateralTest.cpp:283-372) */
     const bool threwHere = __ballot(err != 0) != 0ull;
     /* The live quadrilaterals go into a compact table (at most one per image slot + the ground): k_inquad copies it
@@ -1765,17 +2012,21 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
       if(slot < kMaxLive)
       {
         fs.qtLive[slot] = t;
-        build_grid_segs(t, P.pt.xMin, P.pt.yMin, P.pt.boxX, P.pt.boxY, fs.segLive[slot]);
+        QuadGridSegs sg;
+        build_grid_segs(t, P.pt.xMin, P.pt.yMin, P.pt.boxX, P.pt.boxY, sg);
+        fs.segLive[slot] = sg;
         fs.liveAcc[slot] = static_cast<unsigned char>(lane);
         /* the groups of 4 height bins this accumulator's plateau occupies (matched against the cells' masks) */
-        unsigned int groups = 0u;
         const PlateauState &pl = fs.pl[groundLane ? groundInd : lane];
-        for(int b = pl.effLo; b <= pl.effHi; b++)
+        unsigned int groups = 0u;
+        const int effLo = pl.effLo, effHi = pl.effHi;
+        for(int b = effLo; b <= effHi; b++)
           groups |= 1u << (b / kBinsPerGroup);
         fs.liveGroups[slot] = groups;
       }
     }
   }
+  SSD_PHASE_IF(lane == firstValid, 1, 5);
   const bool threw = __ballot(err != 0) != 0ull;
   const bool active = (groundLane || valid) && !threw;
   if(lane <= kMaxPlateaus)
@@ -1790,6 +2041,7 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
     fs.lutLive[b] = live ? static_cast<unsigned char>(__popcll(activeMask & ((1ull << acc) - 1ull))) : static_cast<unsigned char>(0xff);
   }
 
+  SSD_PHASE_IF(lane == firstValid, 1, 6);
   unsigned int wanted = 0u;
   for(int b = lane; b < P.nBins; b += 64)
   {
@@ -1809,6 +2061,7 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
     fs.anyActive = activeMask != 0ull ? 1u : 0u;
     fs.nLive = min(__popcll(activeMask), kMaxLive);
   }
+  SSD_PHASE_IF(lane == firstValid, 1, 7);
   if(dbg)
   {
     ssd_debug_frame &d = dbg[frame].d;
@@ -2119,11 +2372,15 @@ struct FinalShared
   int px[kMaxCols], py[kMaxCols];
   int n;
   LineI line;
+  double partRes[kMaxImgWaves];             /* BestLine: every wave's best over its share of the pairs */
+  int partT[kMaxImgWaves];
+  LineI partLine[kMaxImgWaves];
   double stepsWorld[SSD_MAX_STEPS][9];       /* z, 4 x (x,y) in camera-dependent world coordinates; thread 0 only:
                                                 in LDS because a private array would live in scratch memory */
 };
 
-__global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__restrict__ st,
+template<int T>
+__global__ __launch_bounds__(T) void k_final(Params P, FrameState *__restrict__ st,
                                                     unsigned long long *__restrict__ groundImg,
                                                     ssd_frame_result *__restrict__ results,
                                                     DebugFrame *__restrict__ dbg,
@@ -2147,8 +2404,9 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
   const int xr0 = xc % xStep;
   const int jc = xc / xStep;
   const int nCols = min(kMaxCols, (P.W - 1 - xr0) / xStep + 1);
+  SSD_PHASE(2, 0);
 
-  for(int j = tid; j < kMaxCols; j += kThreads)
+  for(int j = tid; j < kMaxCols; j += T)
     S.yEdge[j] = -1;
   if(tid == 0)
     S.n = 0;
@@ -2175,173 +2433,238 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
     else if(by0 <= yStop)
       by0 = yStop + 1;                               /* only rows below the image centre are probed */
     const int bw = (emptyImg && !dbgImg) || by1 < by0 ? 0 : bc1 - bc0 + 1, bh = by1 - by0 + 1;
-    const int nBands = bw > 0 ? max(1, kThreads / bw) : 0;
-    const int bandRows = nBands > 0 ? (bh + nBands - 1) / nBands : 0;
-    for(int t = tid; t < bw * nBands; t += kThreads)
+    if(dbgImg)
     {
-      const int band = t / bw;
-      const int c = bc0 + (t - band * bw);
-      const int yA = by0 + band * bandRows, yB = min(yA + bandRows, by1 + 1);
-      closed_column(im, c, yA, yB, dbgImg != nullptr, [&](int y, unsigned long long cw)
+      /* debug capture: the raw and the closed image whole, word by word */
+      const int nBands = bw > 0 ? max(1, T / bw) : 0;
+      const int bandRows = nBands > 0 ? (bh + nBands - 1) / nBands : 0;
+      for(int t = tid; t < bw * nBands; t += T)
       {
-        if(dbgImg)
+        const int band = t / bw;
+        const int c = bc0 + (t - band * bw);
+        const int yA = by0 + band * bandRows, yB = min(yA + bandRows, by1 + 1);
+        closed_column(im, c, yA, yB, true, [&](int y, unsigned long long cw)
         {
           dbgRaw[y * P.W64 + c] = img[y * P.W64 + c];
           dbgClosed[y * P.W64 + c] = cw;
-        }
-        if(cw == 0ull || y <= yStop)
-          return;
-        const int x0 = 64 * c;
-        int j = x0 <= xr0 ? 0 : (x0 - xr0 + xStep - 1) / xStep;
-        for(int x = xr0 + xStep * j; x < x0 + 64 && j < nCols; x += xStep, j++)
-          if((cw >> (x - x0)) & 1ull)
-            atomicMax(&S.yEdge[j], y);
-      });
+        });
+      }
+    }
+    /* the scan columns inside the box in bands of rows, as in k_outline: the last closed row below the image centre */
+    if(bw > 0)
+    {
+      const int yTop = max(by0, yStop + 1);
+      const int nRowsBelow = by1 - yTop + 1;
+      const int xLo = 64 * bc0, xHi = min(64 * bc1 + 63, P.W - 1);
+      const int jLo = xLo <= xr0 ? 0 : (xLo - xr0 + xStep - 1) / xStep;
+      const int jHi = xHi < xr0 ? -1 : min(nCols - 1, (xHi - xr0) / xStep);
+      const int nJ = nRowsBelow > 0 ? jHi - jLo + 1 : 0;
+      const int nBands = nJ > 0 ? max(1, T / nJ) : 0;
+      const int bandRows = nBands > 0 ? (nRowsBelow + nBands - 1) / nBands : 0;
+      for(int t = tid; t < nJ * nBands; t += T)
+      {
+        const int band = t / nJ;
+        const int j = jLo + (t - band * nJ);
+        const int yA = yTop + band * bandRows, yB = min(yA + bandRows, by1 + 1);
+        int yHi = -1;
+        closed_scan_column(im, xr0 + xStep * j, yA, yB, [&](int y) { yHi = y; });
+        if(yHi >= 0)
+          atomicMax(&S.yEdge[j], yHi);
+      }
     }
     __syncthreads();
+    SSD_PHASE(2, 1);
 
     /* BottomScanner::scan (:170-222): first hit rightwards from the centre (else leftwards), then
      * contiguous hits to the right of it, then to the left of it */
-    if(tid == 0)
     {
-      int n = 0, j = jc;
-      bool got = false;
-      for( ; j < nCols; j++)
-        if(S.yEdge[j] >= 0) { got = true; break; }
-      if(!got)
-        for(j = jc - 1; j >= 0; j--)
-          if(S.yEdge[j] >= 0) { got = true; break; }
-      if(got)
+      /* every wave for itself: the columns' hit bits by ballot, the run around the first hit by bit scans */
+      const bool h0 = lane < nCols && S.yEdge[lane] >= 0, h1 = lane + 64 < nCols && S.yEdge[lane + 64] >= 0;
+      const unsigned long long hLo = __ballot(h0), hHi = __ballot(h1);
+      auto hitAt = [&](int j) { return j >= 0 && j < nCols && (((j < 64 ? hLo : hHi) >> (j & 63)) & 1ull) != 0ull; };
+      int jStart = jc;
+      while(jStart < nCols && !hitAt(jStart))
+        jStart++;
+      if(jStart >= nCols)
       {
-        const int jStart = j;
-        S.px[n] = xr0 + xStep * j; S.py[n] = S.yEdge[j]; n++;
-        for(j = jStart + 1; j < nCols && S.yEdge[j] >= 0; j++)
-        { S.px[n] = xr0 + xStep * j; S.py[n] = S.yEdge[j]; n++; }
-        for(j = jStart - 1; j >= 0 && S.yEdge[j] >= 0; j--)
-        { S.px[n] = xr0 + xStep * j; S.py[n] = S.yEdge[j]; n++; }
+        jStart = jc - 1;
+        while(jStart >= 0 && !hitAt(jStart))
+          jStart--;
       }
-      S.n = n;
+      int nRight = 0, nLeft = 0;                 /* hits to the right of the start column, to the left of it */
+      if(jStart >= 0)
+      {
+        while(hitAt(jStart + 1 + nRight))
+          nRight++;
+        while(hitAt(jStart - 1 - nLeft))
+          nLeft++;
+      }
+      const int n = jStart >= 0 ? 1 + nRight + nLeft : 0;
+      /* point k: the start column, then rightwards, then leftwards */
+      for(int k = tid; k < n; k += T)
+      {
+        const int j = k <= nRight ? jStart + k : jStart - (k - nRight);
+        S.px[k] = xr0 + xStep * j;
+        S.py[k] = S.yEdge[j];
+      }
+      if(tid == 0)
+        S.n = n;
     }
     __syncthreads();
-    if(S.n >= 2 && wave == 0)
+    SSD_PHASE(2, 2);
+    if(S.n >= 2)
     {
-      const LineI l = wave_best_line(S.px, S.py, S.n, lane, 3ll * P.W * P.H < (1ll << 25));
+      /* BestLine: the pairs dealt out over the block's waves, the waves' bests combined in pair order */
+      double res;
+      int t;
+      LineI l;
+      wave_best_line_part(S.px, S.py, S.n, lane, 3ll * P.W * P.H < (1ll << 25), 64 * wave, T, res, t, l);
       if(lane == 0)
-        S.line = l;
+      {
+        S.partRes[wave] = res;
+        S.partT[wave] = t;
+        S.partLine[wave] = l;
+      }
+    }
+    __syncthreads();
+    if(S.n >= 2 && tid == 0)
+    {
+      int best = -1;
+      for(int w = 0; w < T / 64; w++)
+        if(S.partT[w] != 0x7fffffff && (best < 0 || S.partRes[w] < S.partRes[best] || (S.partRes[w] == S.partRes[best] && S.partT[w] < S.partT[best])))
+          best = w;
+      S.line = best >= 0 ? S.partLine[best] : LineI{ 0, 0, 0 };
     }
     __syncthreads();
   }
+  SSD_PHASE(2, 3);
 
-  if(tid == 0)
+  /* ---- the emitted surfaces, one lane each (wave 0): lane 0 the ground (calcGround, pointcloud.cpp:528-547), lane 1 + i the
+   *      plateau firstValidInd + i (calcStairStep :549-558); every lane fetches its own sums and corners (one round trip
+   *      for all), its place in the result is the count of emitted surfaces before it; then the detectStairs tail
+   *      (:370-383): ToExternalWorld (transformation.cpp:190-194), straight from the lane's registers ---- */
+  static_assert(kMaxPlateaus + 1 <= 64 && SSD_MAX_STEPS <= 64, "one lane per surface");
+  if(wave == 0)
   {
-    int n = 0;
-    double (&stepsWorld)[SSD_MAX_STEPS][9] = S.stepsWorld;
-    if(!threw && fs.firstValidInd >= 0)
+    const bool any = !threw && fs.firstValidInd >= 0;
+    const int firstValidInd = fs.firstValidInd, firstStep = fs.firstStep, last = fs.firstStep + fs.nStepImages;
+    const bool groundLane = any && lane == 0 && fs.groundInd >= 0;
+    const int k = firstValidInd + lane - 1;
+    const bool stepLane = any && lane >= 1 && k < last && fs.pl[k < last ? max(k, 0) : 0].valid;
+    double sW[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };         /* z, 4 x (x, y): camera-dependent world coordinates */
+    if(groundLane)
     {
-      if(fs.groundInd >= 0)
+      /* "return {}" when no front edge is found (quirk Q6): the ground stays all zero */
+      const bool valid = S.n >= 2;
+      fs.groundFrontValid = valid ? 1 : 0;
+      const double meanZ = (static_cast<double>(fs.sumZ[kGroundAcc]) / static_cast<double>(1ll << kZFixShift)) / fs.cnt[kGroundAcc];
+      double fimg[4] = { 0, 0, 0, 0 };
+      if(valid)
       {
-        /* calcGround (pointcloud.cpp:528-547) */
-        double *s = stepsWorld[n];
-        for(int k = 0; k < 9; k++) s[k] = 0.0;       /* "return {}" when no front edge is found (quirk Q6) */
-        const bool valid = S.n >= 2;
-        fs.groundFrontValid = valid ? 1 : 0;
-        const double meanZ = (static_cast<double>(fs.sumZ[kGroundAcc]) / static_cast<double>(1ll << kZFixShift)) / fs.cnt[kGroundAcc];
-        double fimg[4] = { 0, 0, 0, 0 };
+        /* detectFrontEdge tail (segmentation.cpp:896-906) */
+        const LineI l = S.line;
+        const double fm = static_cast<double>(-l.a) / l.b, fn = static_cast<double>(-l.c) / l.b;
+        int xl = S.px[0], xr = S.px[0];
+        for(int i = 1; i < S.n; i++) { xl = min(xl, S.px[i]); xr = max(xr, S.px[i]); }
+        fimg[0] = xl; fimg[1] = xl * fm + fn;
+        fimg[2] = xr; fimg[3] = xr * fm + fn;
+        const double flx = P.xMin + fimg[0] * P.xToWorld, fly = P.yMax - fimg[1] * P.yToWorld;
+        const double frx = P.xMin + fimg[2] * P.xToWorld, fry = P.yMax - fimg[3] * P.yToWorld;
+        const LineD frontLine = line_through_d(flx, fly, frx, fry);
+        const double *g = fs.groundQuadWorld;
+        const LineD leftSide = line_through_d(g[0], g[1], g[4], g[5]);
+        const LineD rightSide = line_through_d(g[2], g[3], g[6], g[7]);
+        /* StairsDetector::Line::intersection (pointcloud.cpp:520-525) */
+        const double dl = frontLine.a * leftSide.b - leftSide.a * frontLine.b;
+        const double dr = frontLine.a * rightSide.b - rightSide.a * frontLine.b;
+        sW[0] = meanZ;
+        sW[1] = (frontLine.b * leftSide.c - leftSide.b * frontLine.c) / dl;
+        sW[2] = (leftSide.a * frontLine.c - frontLine.a * leftSide.c) / dl;
+        sW[3] = (frontLine.b * rightSide.c - rightSide.b * frontLine.c) / dr;
+        sW[4] = (rightSide.a * frontLine.c - frontLine.a * rightSide.c) / dr;
+        sW[5] = g[4]; sW[6] = g[5];
+        sW[7] = g[6]; sW[8] = g[7];
+      }
+      if(dbg)
+      {
+        ssd_debug_frame &d = dbg[frame].d;
+        d.ground_front_valid = valid ? 1 : 0;
+        d.ground_n_in_quad = static_cast<int>(fs.cnt[kGroundAcc]);
+        d.ground_mean_z = meanZ;
+        d.ground_n_pts = S.n;
+        for(int i = 0; i < S.n; i++) { d.ground_pts[i][0] = S.px[i]; d.ground_pts[i][1] = S.py[i]; }
         if(valid)
         {
-          /* detectFrontEdge tail (segmentation.cpp:896-906) */
-          const LineI l = S.line;
-          const double fm = static_cast<double>(-l.a) / l.b, fn = static_cast<double>(-l.c) / l.b;
-          int xl = S.px[0], xr = S.px[0];
-          for(int k = 1; k < S.n; k++) { xl = min(xl, S.px[k]); xr = max(xr, S.px[k]); }
-          fimg[0] = xl; fimg[1] = xl * fm + fn;
-          fimg[2] = xr; fimg[3] = xr * fm + fn;
-          const double flx = P.xMin + fimg[0] * P.xToWorld, fly = P.yMax - fimg[1] * P.yToWorld;
-          const double frx = P.xMin + fimg[2] * P.xToWorld, fry = P.yMax - fimg[3] * P.yToWorld;
-          const LineD frontLine = line_through_d(flx, fly, frx, fry);
-          const double *g = fs.groundQuadWorld;
-          const LineD leftSide = line_through_d(g[0], g[1], g[4], g[5]);
-          const LineD rightSide = line_through_d(g[2], g[3], g[6], g[7]);
-          /* StairsDetector::Line::intersection (pointcloud.cpp:520-525) */
-          const double dl = frontLine.a * leftSide.b - leftSide.a * frontLine.b;
-          const double dr = frontLine.a * rightSide.b - rightSide.a * frontLine.b;
-          s[0] = meanZ;
-          s[1] = (frontLine.b * leftSide.c - leftSide.b * frontLine.c) / dl;
-          s[2] = (leftSide.a * frontLine.c - frontLine.a * leftSide.c) / dl;
-          s[3] = (frontLine.b * rightSide.c - rightSide.b * frontLine.c) / dr;
-          s[4] = (rightSide.a * frontLine.c - frontLine.a * rightSide.c) / dr;
-          s[5] = g[4]; s[6] = g[5];
-          s[7] = g[6]; s[8] = g[7];
-        }
-        n++;
-        if(dbg)
-        {
-          ssd_debug_frame &d = dbg[frame].d;
-          d.ground_front_valid = valid ? 1 : 0;
-          d.ground_n_in_quad = static_cast<int>(fs.cnt[kGroundAcc]);
-          d.ground_mean_z = meanZ;
-          d.ground_n_pts = S.n;
-          for(int k = 0; k < S.n; k++) { d.ground_pts[k][0] = S.px[k]; d.ground_pts[k][1] = S.py[k]; }
-          if(valid)
-          {
-            d.ground_line[0] = S.line.a; d.ground_line[1] = S.line.b; d.ground_line[2] = S.line.c;
-            for(int k = 0; k < 4; k++) d.ground_front_img[k] = fimg[k];
-          }
+          d.ground_line[0] = S.line.a; d.ground_line[1] = S.line.b; d.ground_line[2] = S.line.c;
+          for(int i = 0; i < 4; i++) d.ground_front_img[i] = fimg[i];
         }
       }
-      /* calcStairStep (pointcloud.cpp:549-558) */
-      const int last = fs.firstStep + fs.nStepImages;
-      for(int k = fs.firstValidInd; k < last && n < SSD_MAX_STEPS; k++)
+    }
+    if(stepLane)
+    {
+      /* calcAverageZ over the plateau's points inside its quadrilateral = all of them (k_raster's sum, the histogram's
+       * count) minus the ones outside (k_inquad's sum and count) */
+      const long long inZ = fs.totZ[k - firstStep] - fs.sumZ[k];
+      const unsigned int inN = static_cast<unsigned int>(fs.pl[k].nPoints) - fs.cnt[k];
+      const double meanZ = (static_cast<double>(inZ) / static_cast<double>(1ll << kZFixShift)) / inN;
+      sW[0] = meanZ;
+#pragma unroll
+      for(int c = 0; c < 8; c++)
+        sW[1 + c] = fs.pl[k].quadWorld[c];
+      if(dbg)
       {
-        if(!fs.pl[k].valid)
-          continue;
-        /* calcAverageZ over the plateau's points inside its quadrilateral = all of them (k_raster's sum, the histogram's
-         * count) minus the ones outside (k_inquad's sum and count) */
-        const long long inZ = fs.totZ[k - fs.firstStep] - fs.sumZ[k];
-        const unsigned int inN = static_cast<unsigned int>(fs.pl[k].nPoints) - fs.cnt[k];
-        const double meanZ = (static_cast<double>(inZ) / static_cast<double>(1ll << kZFixShift)) / inN;
-        double *s = stepsWorld[n];
-        s[0] = meanZ;
-        for(int c = 0; c < 8; c++) s[1 + c] = fs.pl[k].quadWorld[c];
-        n++;
-        if(dbg)
-        {
-          ssd_debug_plateau &p = dbg[frame].d.plateaus[k];
-          p.n_in_quad = static_cast<int>(inN);
-          p.sum_z_fix = inZ;
-          p.mean_z = meanZ;
-        }
+        ssd_debug_plateau &p = dbg[frame].d.plateaus[k];
+        p.n_in_quad = static_cast<int>(inN);
+        p.sum_z_fix = inZ;
+        p.mean_z = meanZ;
       }
     }
-    /* detectStairs tail (pointcloud.cpp:370-383): ToExternalWorld (transformation.cpp:190-194) */
-    res.n_steps = n;
-    res.status = static_cast<int>(fs.status);
-    for(int i = n; i < SSD_MAX_STEPS; i++)        /* unused slots are zero, so results compare bytewise */
+    const unsigned long long emitted = __ballot(groundLane || stepLane);
+    const int place = __popcll(emitted & ((1ull << lane) - 1ull));
+    const int n = min(__popcll(emitted), SSD_MAX_STEPS);
+    if((groundLane || stepLane) && place < SSD_MAX_STEPS)
     {
-      res.steps[i].height = 0.0;
-      for(int c = 0; c < 8; c++) res.steps[i].quad[c] = 0.0;
-    }
-    for(int i = 0; i < n; i++)
-    {
-      const double *s = stepsWorld[i];
-      res.steps[i].height = P.worldZ + s[0];
+      res.steps[place].height = P.worldZ + sW[0];
+#pragma unroll
       for(int c = 0; c < 4; c++)
       {
-        const double x = s[1 + 2 * c], y = s[2 + 2 * c];
+        const double x = sW[1 + 2 * c], y = sW[2 + 2 * c];
         double ex = P.r2[0] * x + P.r2[1] * y;
         double ey = P.r2[2] * x + P.r2[3] * y;
         ex = ex + P.t2[0];
         ey = ey + P.t2[1];
-        res.steps[i].quad[2 * c] = ex;
-        res.steps[i].quad[2 * c + 1] = ey;
+        res.steps[place].quad[2 * c] = ex;
+        res.steps[place].quad[2 * c + 1] = ey;
+      }
+#pragma unroll
+      for(int c = 0; c < 9; c++)
+        S.stepsWorld[place][c] = sW[c];              /* for the risers below */
+    }
+    if(lane >= n && lane < SSD_MAX_STEPS)            /* unused slots are zero, so results compare bytewise */
+    {
+      res.steps[lane].height = 0.0;
+#pragma unroll
+      for(int c = 0; c < 8; c++)
+        res.steps[lane].quad[c] = 0.0;
+    }
+    if(lane == 0)
+    {
+      S.n = n;                                       /* from here on: the number of emitted surfaces */
+      res.n_steps = n;
+      res.status = static_cast<int>(fs.status);
+      if(dbg)
+      {
+        dbg[frame].d.status = static_cast<int>(fs.status);
+        dbg[frame].d.n_oob = static_cast<int>(fs.nOob);
       }
     }
-    if(dbg)
-    {
-      dbg[frame].d.status = static_cast<int>(fs.status);
-      dbg[frame].d.n_oob = static_cast<int>(fs.nOob);
-    }
-    if(P.risers)
+  }
+  SSD_PHASE(2, 4);
+  __syncthreads();
+  if(P.risers && tid == 0)
+  {
+    const int n = S.n;
+    double (&stepsWorld)[SSD_MAX_STEPS][9] = S.stepsWorld;
     {
       /* vertical faces (extension, include/ssd_hip.h): one riser under the front edge of every emitted surface but
        * the lowest; its evidence is gathered by k_risers from the bins of no plateau between the two heights */
@@ -2387,19 +2710,21 @@ __global__ __launch_bounds__(kThreads) void k_final(Params P, FrameState *__rest
     }
   }
   __syncthreads();
+  SSD_PHASE(2, 5);
 
   /* leave the ground image zeroed for the next batch (all its bits lie inside the bounding box) */
   if(fs.imgYMax[kMaxStepImages] >= fs.imgYMin[kMaxStepImages])
   {
     const int cy0 = fs.imgYMin[kMaxStepImages], cc0 = fs.imgXMin[kMaxStepImages];
     const int cw = fs.imgXMax[kMaxStepImages] - cc0 + 1, ch = fs.imgYMax[kMaxStepImages] - cy0 + 1;
-    for(int idx = tid; idx < cw * ch; idx += kThreads)
+    for(int idx = tid; idx < cw * ch; idx += T)
     {
       const int ry = idx / cw;
       const size_t o = static_cast<size_t>(cy0 + ry) * P.W64 + cc0 + (idx - ry * cw);
       img[o] = 0ull;                                 /* unconditionally: a load first would make every word a round trip */
     }
   }
+  SSD_PHASE(2, 6);
 }
 
 /* ========================================================================= */
@@ -2603,7 +2928,11 @@ void launch_raster(const float *xyz, size_t strideFloats, const Params &P, Frame
 void launch_outline(const Params &P, FrameState *st, unsigned long long *stepImg, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
 {
   dim3 grid(nframes, P.maxStepImages);
-  hipLaunchKernelGGL(k_outline, grid, dim3(kThreads), 0, s, P, st, stepImg, dbg, dbgImg);
+  /* while every image has a CU of its own, the block that gets through its phases soonest; beyond that the cheapest */
+  if(nframes <= kImgFewFrames)
+    hipLaunchKernelGGL(k_outline<kImgThreadsFew>, grid, dim3(kImgThreadsFew), 0, s, P, st, stepImg, dbg, dbgImg);
+  else
+    hipLaunchKernelGGL(k_outline<kImgThreadsBatch>, grid, dim3(kImgThreadsBatch), 0, s, P, st, stepImg, dbg, dbgImg);
 }
 void launch_quads(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s)
 {
@@ -2622,7 +2951,10 @@ void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, Frame
 }
 void launch_final(const Params &P, FrameState *st, unsigned long long *groundImg, ssd_frame_result *results, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_final, dim3(nframes), dim3(kThreads), 0, s, P, st, groundImg, results, dbg, dbgImg);
+  if(nframes <= kImgFewFrames)
+    hipLaunchKernelGGL(k_final<kImgThreadsFew>, dim3(nframes), dim3(kImgThreadsFew), 0, s, P, st, groundImg, results, dbg, dbgImg);
+  else
+    hipLaunchKernelGGL(k_final<kImgThreadsBatch>, dim3(nframes), dim3(kImgThreadsBatch), 0, s, P, st, groundImg, results, dbg, dbgImg);
 }
 void launch_risers(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, const uint2 *tileMasks, size_t tileMaskStride,
                    ssd_frame_risers *out, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
@@ -2638,3 +2970,10 @@ void launch_risers(const float *xyz, size_t strideFloats, const Params &P, Frame
 }
 
 } // namespace ssd
+
+#ifdef SSD_PHASE_TIMING
+extern "C" __attribute__((visibility("default"))) int ssd_phase_read(unsigned long long *out)
+{
+  return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(ssd::g_phase), sizeof(ssd::g_phase)));
+}
+#endif

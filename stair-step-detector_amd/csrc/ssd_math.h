@@ -69,7 +69,7 @@ __device__ __forceinline__ LineI line_through_i(int x1, int y1, int x2, int y2)
 {
   return { y2 - y1, x1 - x2, x2 * y1 - x1 * y2 };
 }
-__device__ __forceinline__ LineD line_through_d(double x1, double y1, double x2, double y2)
+__host__ __device__ __forceinline__ LineD line_through_d(double x1, double y1, double x2, double y2)
 {
   return { y2 - y1, x1 - x2, x2 * y1 - x1 * y2 };
 }

@@ -12,223 +12,268 @@
 namespace ssd
 {
 
-struct SegTmp { double bxLo, bxUp, byLo, byUp; };
-
-__device__ __forceinline__ void sector_init(double a, double b, double &lo, double &up)
+/* (selects, not conditional stores: the compiler turned "if(lo > b) lo = b; else if(up < b) up = b;" into ONE store through
+ * a selected address, which put every sector into scratch memory) */
+__host__ __device__ __forceinline__ void sector_init(double a, double b, double &lo, double &up)
 {
-  lo = a; up = a;                       /* Sector(a, b): quadrilateralTest.cpp:28-40 */
-  if(lo > b) lo = b;
-  else if(up < b) up = b;
+  const bool below = a > b;             /* Sector(a, b): quadrilateralTest.cpp:28-40 */
+  const bool above = !below && a < b;
+  lo = below ? b : a;
+  up = above ? b : a;
 }
-__device__ __forceinline__ void sector_expand(double c, double &lo, double &up)
+__host__ __device__ __forceinline__ void sector_expand(double c, double &lo, double &up)
 {
-  if(lo > c) lo = c;
-  else if(up < c) up = c;
+  const double l = lo, u = up;
+  const bool below = l > c;
+  const bool above = !below && u < c;
+  lo = below ? c : l;
+  up = above ? c : u;
 }
-__device__ __forceinline__ bool sector_overlaps(double lo, double up, double olo, double oup)
+__host__ __device__ __forceinline__ bool sector_overlaps(double lo, double up, double olo, double oup)
 {
   return lo < oup && up > olo;
 }
 
-/* the builder's working arrays: indexed at run time, so as locals they would live in scratch (global) memory — k_quads
- * passes a slice of LDS instead (a frame's quadrilaterals are built by one lane each, one wave per frame: latency) */
-struct QuadBuildScratch
+/* i-th of three values, i in 0..2 (selects, no indexed memory) */
+template<typename T>
+__host__ __device__ __forceinline__ T pick3(T a0, T a1, T a2, int i)
 {
-  SegTmp box[4];
-  double xs[4], ys[4], rowUpper[3], cellUpper[3][3];
-  int nCells[3];
-  unsigned char cellMask[3][3], cellCnt[3][3], cellConst[3][3];
-};
+  return i == 0 ? a0 : (i == 1 ? a1 : a2);
+}
 
-/* QuadrilateralTest::QuadrilateralTest (quadrilateralTest.cpp:275-443) flattened into tables */
-__device__ inline void build_quad_test(const double *q /* 4 x (x,y) */, QuadTest &t, QuadBuildScratch &w)
+/* one step of the merge loop (:377-394) at the static position C of a row held in scalars: cells C and C + 1 are compared;
+ * equal masks -> the cells from C + 1 on move down one place.  Returns true when merged (the loop then stays at C). */
+template<int C>
+__host__ __device__ __forceinline__ bool quad_merge_step(unsigned int &p0, unsigned int &p1, unsigned int &p2,
+                                                         double &u0, double &u1, double &u2, int &n, int &err)
 {
-  t.err = 0;
+  const unsigned int cur = C == 0 ? p0 : p1, nxt = C == 0 ? p1 : p2;
+  if((cur & 0xffu) == 0u && (nxt & 0xffu) == 0u) { err = -5; return false; }
+  if(((cur >> 8) & 0xffu) > 1u && ((nxt >> 8) & 0xffu) > 1u) { err = -6; return false; }
+  if((cur & 0xffu) != (nxt & 0xffu))
+    return false;
+  if(C == 0) { p0 = p1; u0 = u1; }
+  p1 = p2; u1 = u2;
+  n--;
+  return true;
+}
+
+/* QuadrilateralTest::QuadrilateralTest (quadrilateralTest.cpp:275-443) flattened into tables.
+ * Every array here is indexed by compile-time constants only (loops unrolled, run-time positions taken by selects), so the
+ * whole construction lives in registers: k_quads builds a frame's quadrilaterals one lane each, one wave per frame — pure
+ * latency.  As run-time-indexed arrays the working set sat in scratch memory (24 us per frame), then in LDS (15 us: a
+ * chain of some hundred dependent LDS round trips); this form: see DESIGN.md, single-frame latency.
+ * On an error (t.err != 0: the reference throws) nothing but t.err is meaningful. */
+__host__ __device__ inline void build_quad_test(const double *qin /* 4 x (x,y) */, QuadTest &t)
+{
+  double q[8];
+#pragma unroll
+  for(int k = 0; k < 8; k++)
+    q[k] = qin[k];
+  int err = 0;
   t.fx0 = 1.0; t.fx1 = 0.0; t.fy0 = 1.0; t.fy1 = 0.0;
-  sector_init(q[0], q[2], t.bxLo, t.bxUp);
-  sector_init(q[1], q[3], t.byLo, t.byUp);
-  sector_expand(q[4], t.bxLo, t.bxUp); sector_expand(q[5], t.byLo, t.byUp);
-  sector_expand(q[6], t.bxLo, t.bxUp); sector_expand(q[7], t.byLo, t.byUp);
+  double bxLo, bxUp, byLo, byUp;
+  sector_init(q[0], q[2], bxLo, bxUp);
+  sector_init(q[1], q[3], byLo, byUp);
+  sector_expand(q[4], bxLo, bxUp); sector_expand(q[5], byLo, byUp);
+  sector_expand(q[6], bxLo, bxUp); sector_expand(q[7], byLo, byUp);
+  t.bxLo = bxLo; t.bxUp = bxUp; t.byLo = byLo; t.byUp = byUp;
 
   /* segments counterclockwise: 0->1, 1->3, 3->2, 2->0 */
-  const int sp[4] = { 0, 1, 3, 2 }, sq[4] = { 1, 3, 2, 0 };
-  SegTmp (&box)[4] = w.box;
+  constexpr int sp[4] = { 0, 1, 3, 2 }, sq[4] = { 1, 3, 2, 0 };
+  double sxLo[4], sxUp[4], syLo[4], syUp[4], segK[4], segC[4];
+  bool steep[4], leftIfPositive[4];
+#pragma unroll
   for(int s = 0; s < 4; s++)
   {
     const double px = q[2 * sp[s]], py = q[2 * sp[s] + 1], qx = q[2 * sq[s]], qy = q[2 * sq[s] + 1];
-    sector_init(px, qx, box[s].bxLo, box[s].bxUp);
-    sector_init(py, qy, box[s].byLo, box[s].byUp);
+    sector_init(px, qx, sxLo[s], sxUp[s]);
+    sector_init(py, qy, syLo[s], syUp[s]);
     const double dx = qx - px, dy = qy - py;
     const LineD l = line_through_d(px, py, qx, qy);
-    if(fabs(dx) < fabs(dy))
-    {
-      t.segSteep[s] = 1;                      /* SteepLine :145-166 */
-      t.segK[s] = l.b / l.a;
-      t.segC[s] = l.c / l.a;
-      t.segLeftIfPositive[s] = dy > 0 ? 0 : 1;
-    }
-    else
-    {
-      t.segSteep[s] = 0;                      /* FlatLine :124-143 */
-      t.segK[s] = l.a / l.b;
-      t.segC[s] = l.c / l.b;
-      t.segLeftIfPositive[s] = dx > 0 ? 1 : 0;
-    }
+    steep[s] = fabs(dx) < fabs(dy);
+    const double den = steep[s] ? l.a : l.b;      /* SteepLine :145-166 / FlatLine :124-143 */
+    segK[s] = (steep[s] ? l.b : l.a) / den;
+    segC[s] = l.c / den;
+    leftIfPositive[s] = steep[s] ? !(dy > 0) : (dx > 0);
+    t.segSteep[s] = steep[s] ? 1 : 0;
+    t.segLeftIfPositive[s] = leftIfPositive[s] ? 1 : 0;
+    t.segK[s] = segK[s];
+    t.segC[s] = segC[s];
   }
-  auto isLeft = [&](int s, double x, double y)
-  {
-    const bool positive = t.segSteep[s] ? (x + y * t.segK[s] + t.segC[s] > 0) : (x * t.segK[s] + y + t.segC[s] > 0);
-    return t.segLeftIfPositive[s] ? positive : !positive;
-  };
-  const bool inside = isLeft(0, q[6], q[7]);
+#define SSD_QUAD_IS_LEFT(s, x, y) \
+  ((steep[s] ? ((x) + (y) * segK[s] + segC[s] > 0) : ((x) * segK[s] + (y) + segC[s] > 0)) == leftIfPositive[s])
+  const bool inside = SSD_QUAD_IS_LEFT(0, q[6], q[7]);
   t.insideIsLeft = inside ? 1 : 0;
-  if(inside != isLeft(1, q[4], q[5]) || inside != isLeft(2, q[0], q[1]) || inside != isLeft(3, q[2], q[3]))
-  {
-    t.err = -1;
-    return;
-  }
+  if(inside != SSD_QUAD_IS_LEFT(1, q[4], q[5]) || inside != SSD_QUAD_IS_LEFT(2, q[0], q[1]) || inside != SSD_QUAD_IS_LEFT(3, q[2], q[3]))
+    err = -1;
+#undef SSD_QUAD_IS_LEFT
 
-  double (&xs)[4] = w.xs, (&ys)[4] = w.ys;
-  xs[0] = q[0]; xs[1] = q[2]; xs[2] = q[4]; xs[3] = q[6];
-  ys[0] = q[1]; ys[1] = q[3]; ys[2] = q[5]; ys[3] = q[7];
-  for(int i = 1; i < 4; i++)                 /* insertion sort of 4 */
+  /* insertion sort of the four x and the four y (the reference sorts them; written as its compare-and-shift steps so that
+   * unordered values (NaN) end up where a run-time loop would leave them) */
+  double xs[4] = { q[0], q[2], q[4], q[6] }, ys[4] = { q[1], q[3], q[5], q[7] };
+#pragma unroll
+  for(int i = 1; i < 4; i++)
   {
     const double vx = xs[i], vy = ys[i];
-    int k = i - 1;
-    while(k >= 0 && xs[k] > vx) { xs[k + 1] = xs[k]; k--; }
-    xs[k + 1] = vx;
-    k = i - 1;
-    while(k >= 0 && ys[k] > vy) { ys[k + 1] = ys[k]; k--; }
-    ys[k + 1] = vy;
+    bool gx = true, gy = true;
+#pragma unroll
+    for(int k = i - 1; k >= 0; k--)
+    {
+      const bool mx = gx && xs[k] > vx;
+      xs[k + 1] = mx ? xs[k] : (gx ? vx : xs[k + 1]);
+      gx = mx;
+      const bool my = gy && ys[k] > vy;
+      ys[k + 1] = my ? ys[k] : (gy ? vy : ys[k + 1]);
+      gy = my;
+    }
+    if(gx) xs[0] = vx;
+    if(gy) ys[0] = vy;
   }
 
-  int nRows = 0;
-  double (&rowUpper)[3] = w.rowUpper;
-  int (&nCells)[3] = w.nCells;
-  double (&cellUpper)[3][3] = w.cellUpper;
-  unsigned char (&cellMask)[3][3] = w.cellMask, (&cellCnt)[3][3] = w.cellCnt, (&cellConst)[3][3] = w.cellConst;
-  double lowerY = ys[0];
-  for(int yi = 1; yi < 4; yi++)
+  /* rows and columns of the map: a new one wherever the sorted coordinate rises (:300-309); a row's columns do not depend
+   * on the row before the merge */
+  bool colLive[3], rowLive[3];
+  double colLo[3], rowLo[3];
   {
-    if(!(lowerY < ys[yi]))
-      continue;
-    const int r = nRows++;
-    rowUpper[r] = ys[yi];
-    nCells[r] = 0;
-    double lowerX = xs[0];
-    for(int xi = 1; xi < 4; xi++)
+    double lowerX = xs[0], lowerY = ys[0];
+#pragma unroll
+    for(int i = 0; i < 3; i++)
     {
-      if(!(lowerX < xs[xi]))
-        continue;
-      const int c = nCells[r]++;
-      cellUpper[r][c] = xs[xi];
+      colLive[i] = lowerX < xs[i + 1];
+      colLo[i] = lowerX;
+      if(colLive[i]) lowerX = xs[i + 1];
+      rowLive[i] = lowerY < ys[i + 1];
+      rowLo[i] = lowerY;
+      if(rowLive[i]) lowerY = ys[i + 1];
+    }
+  }
+  /* cell (ri, ci) = [colLo, xs[ci + 1]] x [rowLo, ys[ri + 1]], packed: mask | count << 8 | constant << 16 */
+  unsigned int cell[3][3];
+#pragma unroll
+  for(int ri = 0; ri < 3; ri++)
+#pragma unroll
+    for(int ci = 0; ci < 3; ci++)
+    {
       double cxLo, cxUp, cyLo, cyUp;
-      sector_init(lowerX, xs[xi], cxLo, cxUp);
-      sector_init(lowerY, ys[yi], cyLo, cyUp);
-      unsigned char mask = 0, cnt = 0;
-      bool nb[5] = { false, false, false, false, false };
+      sector_init(colLo[ci], xs[ci + 1], cxLo, cxUp);
+      sector_init(rowLo[ri], ys[ri + 1], cyLo, cyUp);
+      const double mx = (cxLo + cxUp) / 2, my = (cyLo + cyUp) / 2;
+      unsigned int mask = 0, cnt = 0, nb = 0;
+#pragma unroll
       for(int s = 0; s < 4; s++)
       {
-        const bool xo = sector_overlaps(cxLo, cxUp, box[s].bxLo, box[s].bxUp);
-        const bool yo = sector_overlaps(cyLo, cyUp, box[s].byLo, box[s].byUp);
-        if(xo && yo)
-        {
-          mask |= static_cast<unsigned char>(1u << s);
-          cnt++;
-        }
-        if(cnt == 0)
-        {
-          /* BBox::getRelativePosition :93-110 */
-          int rel = 0;
-          const double mx = (cxLo + cxUp) / 2, my = (cyLo + cyUp) / 2;
-          if(yo && mx < box[s].bxLo) rel = 1;
-          else if(yo && mx > box[s].bxUp) rel = 2;
-          else if(xo && my < box[s].byLo) rel = 3;
-          else if(xo && my > box[s].byUp) rel = 4;
-          nb[rel] = true;
-        }
+        /* (bitwise on purpose: selects and mask arithmetic instead of 36 x 6 branches) */
+        const bool xo = (cxLo < sxUp[s]) & (cxUp > sxLo[s]);
+        const bool yo = (cyLo < syUp[s]) & (cyUp > syLo[s]);
+        const bool both = xo & yo;
+        mask |= both ? 1u << s : 0u;
+        cnt += both ? 1u : 0u;
+        /* BBox::getRelativePosition :93-110, asked only while no segment has met the cell */
+        const bool r1 = yo & (mx < sxLo[s]);
+        const bool r2 = yo & (mx > sxUp[s]);
+        const bool r3 = xo & (my < syLo[s]);
+        const bool r4 = xo & (my > syUp[s]);
+        const unsigned int rel = r1 ? 2u : (r2 ? 4u : (r3 ? 8u : (r4 ? 16u : 1u)));
+        nb |= cnt == 0u ? rel : 0u;
       }
-      cellMask[r][c] = mask;
-      cellCnt[r][c] = cnt;
-      cellConst[r][c] = (nb[1] && nb[2] && nb[3] && nb[4]) ? 1 : 0;
-      lowerX = xs[xi];
+      cell[ri][ci] = mask | (cnt << 8) | ((nb & 0x1eu) == 0x1eu ? 0x10000u : 0u);
     }
-    lowerY = ys[yi];
-  }
-  if(nRows == 0) { t.err = -2; return; }
-  for(int r = 0; r < nRows; r++)
+  /* the live rows / columns move to the front: source of place 0 / 1 / 2 */
+  const int nRows = (rowLive[0] ? 1 : 0) + (rowLive[1] ? 1 : 0) + (rowLive[2] ? 1 : 0);
+  const int nCols = (colLive[0] ? 1 : 0) + (colLive[1] ? 1 : 0) + (colLive[2] ? 1 : 0);
+  const int srcR[3] = { rowLive[0] ? 0 : (rowLive[1] ? 1 : 2), (rowLive[0] && rowLive[1]) ? 1 : 2, 2 };
+  const int srcC[3] = { colLive[0] ? 0 : (colLive[1] ? 1 : 2), (colLive[0] && colLive[1]) ? 1 : 2, 2 };
+  double rowUpper[3], colUpper[3];
+  unsigned int p[3][3];
+#pragma unroll
+  for(int r = 0; r < 3; r++)
   {
-    if(nCells[r] == 0) { t.err = -3; return; }
-    for(int c = 0; c < nCells[r]; c++)
-      if(cellCnt[r][c] > 2) { t.err = -4; return; }
+    rowUpper[r] = pick3(ys[1], ys[2], ys[3], srcR[r]);
+    colUpper[r] = pick3(xs[1], xs[2], xs[3], srcC[r]);
+    unsigned int rowCells[3];
+#pragma unroll
+    for(int ci = 0; ci < 3; ci++)
+      rowCells[ci] = pick3(cell[0][ci], cell[1][ci], cell[2][ci], srcR[r]);
+#pragma unroll
+    for(int c = 0; c < 3; c++)
+      p[r][c] = pick3(rowCells[0], rowCells[1], rowCells[2], srcC[c]);
   }
-  /* merge equal neighbours (:377-394) */
-  for(int r = 0; r < nRows; r++)
+  if(err == 0 && nRows == 0) err = -2;
+  if(err == 0 && nCols == 0) err = -3;
+#pragma unroll
+  for(int r = 0; r < 3; r++)
+#pragma unroll
+    for(int c = 0; c < 3; c++)
+      if(err == 0 && r < nRows && c < nCols && ((p[r][c] >> 8) & 0xffu) > 2u)
+        err = -4;
+  /* merge equal neighbours (:377-394): at most two steps per row of three cells */
+  int nCells[3];
+  double u[3][3];
+#pragma unroll
+  for(int r = 0; r < 3; r++)
   {
-    int c = 0;
-    while(c + 1 < nCells[r])
+    nCells[r] = nCols;
+    u[r][0] = colUpper[0]; u[r][1] = colUpper[1]; u[r][2] = colUpper[2];
+    if(err == 0 && r < nRows && nCells[r] > 1)
     {
-      const unsigned char cur = cellMask[r][c], nxt = cellMask[r][c + 1];
-      if(cur == 0 && nxt == 0) { t.err = -5; return; }
-      if(cellCnt[r][c] > 1 && cellCnt[r][c + 1] > 1) { t.err = -6; return; }
-      if(cur == nxt)
+      const bool merged = quad_merge_step<0>(p[r][0], p[r][1], p[r][2], u[r][0], u[r][1], u[r][2], nCells[r], err);
+      if(err == 0)
       {
-        for(int k = c; k + 1 < nCells[r]; k++)
+        if(merged)
         {
-          cellUpper[r][k] = cellUpper[r][k + 1];
-          cellMask[r][k] = cellMask[r][k + 1];
-          cellCnt[r][k] = cellCnt[r][k + 1];
-          cellConst[r][k] = cellConst[r][k + 1];
+          if(nCells[r] > 1)
+            quad_merge_step<0>(p[r][0], p[r][1], p[r][2], u[r][0], u[r][1], u[r][2], nCells[r], err);
         }
-        nCells[r]--;
+        else if(nCells[r] > 2)
+          quad_merge_step<1>(p[r][0], p[r][1], p[r][2], u[r][0], u[r][1], u[r][2], nCells[r], err);
       }
-      else
-        c++;
     }
   }
+  t.err = err;
   t.nRows = static_cast<unsigned char>(nRows);
+#pragma unroll
   for(int r = 0; r < 3; r++)
   {
     t.nCells[r] = r < nRows ? static_cast<unsigned char>(nCells[r]) : 0;
+#pragma unroll
     for(int c = 0; c < 3; c++)
     {
       const bool live = r < nRows && c < nCells[r];
-      t.cellMask[r][c] = live ? cellMask[r][c] : 0;
-      t.cellConst[r][c] = live ? cellConst[r][c] : 0;
+      t.cellMask[r][c] = live ? static_cast<unsigned char>(p[r][c] & 0xffu) : 0;
+      t.cellConst[r][c] = live ? static_cast<unsigned char>((p[r][c] >> 16) & 1u) : 0;
     }
-    t.xTrans[r][0] = r < nRows && nCells[r] > 1 ? cellUpper[r][0] : 0.0;
-    t.xTrans[r][1] = r < nRows && nCells[r] > 2 ? cellUpper[r][1] : 0.0;
+    t.xTrans[r][0] = r < nRows && nCells[r] > 1 ? u[r][0] : 0.0;
+    t.xTrans[r][1] = r < nRows && nCells[r] > 2 ? u[r][1] : 0.0;
   }
   t.yTrans[0] = nRows > 1 ? rowUpper[0] : 0.0;
   t.yTrans[1] = nRows > 2 ? rowUpper[1] : 0.0;
 
   /* fast cell: the selectors put (x, y) into row r / cell c exactly when lower <= coordinate < upper
    * (quadrilateralTest.cpp:487-571), first and last cells being bounded by the strict bounding box */
+  const double xAfterLo = nextafter(bxLo, 1e300), yAfterLo = nextafter(byLo, 1e300);
   double bestArea = -1.0;
-  for(int r = 0; r < nRows; r++)
+  double fx0 = 1.0, fx1 = 0.0, fy0 = 1.0, fy1 = 0.0;
+#pragma unroll
+  for(int r = 0; r < 3; r++)
   {
-    const double y0 = r == 0 ? nextafter(t.byLo, 1e300) : rowUpper[r - 1];
-    const double y1 = r == nRows - 1 ? t.byUp : rowUpper[r];
-    for(int c = 0; c < nCells[r]; c++)
+    const double y0 = r == 0 ? yAfterLo : rowUpper[r > 0 ? r - 1 : 0];
+    const double y1 = r == nRows - 1 ? byUp : rowUpper[r];
+#pragma unroll
+    for(int c = 0; c < 3; c++)
     {
-      if(cellMask[r][c] != 0 || cellConst[r][c] == 0)
-        continue;
-      const double x0 = c == 0 ? nextafter(t.bxLo, 1e300) : cellUpper[r][c - 1];
-      const double x1 = c == nCells[r] - 1 ? t.bxUp : cellUpper[r][c];
+      const bool candidate = err == 0 && r < nRows && c < nCells[r] && (p[r][c] & 0xffu) == 0u && ((p[r][c] >> 16) & 1u) != 0u;
+      const double x0 = c == 0 ? xAfterLo : u[r][c > 0 ? c - 1 : 0];
+      const double x1 = c == nCells[r] - 1 ? bxUp : u[r][c];
       const double area = (x1 - x0) * (y1 - y0);
-      if(area > bestArea)
+      if(candidate && area > bestArea)
       {
         bestArea = area;
-        t.fx0 = x0; t.fx1 = x1; t.fy0 = y0; t.fy1 = y1;
+        fx0 = x0; fx1 = x1; fy0 = y0; fy1 = y1;
       }
     }
   }
-}
-
-__device__ inline void build_quad_test(const double *q, QuadTest &t)
-{
-  QuadBuildScratch w;
-  build_quad_test(q, t, w);
+  t.fx0 = fx0; t.fx1 = fx1; t.fy0 = fy0; t.fy1 = fy1;
 }
 
 /* QuadrilateralTest::isPointWithin (quadrilateralTest.cpp:445-451 and the selector lambdas :487-571) */
@@ -266,12 +311,13 @@ __device__ __forceinline__ bool quad_test(const QuadTest &t, double x, double y)
  * into, PROVIDED the map itself agrees with the geometry: a cell that holds segments tests only those (all pass), a cell
  * without segments answers with its constant.  Such a cell is crossed by no edge, so it lies wholly inside or wholly
  * outside the quadrilateral; ok = 0 when one that lies inside (tested at its centre) carries the constant "outside". */
-__device__ inline void build_grid_segs(const QuadTest &t, double xMin, double yMin, double boxX, double boxY, QuadGridSegs &o)
+__host__ __device__ inline void build_grid_segs(const QuadTest &t, double xMin, double yMin, double boxX, double boxY, QuadGridSegs &o)
 {
   const double margin = 4.0e-9;
-  o.ok = t.err == 0 ? 1 : 0;
+  int ok = t.err == 0 ? 1 : 0;
   o.pad = 0;
   double cx[4], cy[4], cc[4];                       /* sign-adjusted: inside <=> cx * x + cy * y + cc > 0 */
+#pragma unroll
   for(int s = 0; s < 4; s++)
   {
     const bool positiveInside = (t.segLeftIfPositive[s] != 0) == (t.insideIsLeft != 0);
@@ -280,30 +326,36 @@ __device__ inline void build_grid_segs(const QuadTest &t, double xMin, double yM
     cx[s] = sgn * (t.segSteep[s] ? 1.0 : k);
     cy[s] = sgn * (t.segSteep[s] ? k : 1.0);
     cc[s] = sgn * t.segC[s];
-    o.g[s][0] = cx[s] / boxX;
-    o.g[s][1] = cy[s] / boxY;
-    o.g[s][2] = (cc[s] + cx[s] * xMin + cy[s] * yMin) - margin * (fabs(cx[s]) + fabs(cy[s]));
-    if(!(fabs(o.g[s][0]) < 1.0e6 && fabs(o.g[s][1]) < 1.0e6 && fabs(o.g[s][2]) < 1.0e6))
-      o.ok = 0;                                     /* degenerate edge (infinite or NaN slope) */
+    const double g0 = cx[s] / boxX, g1 = cy[s] / boxY;
+    const double g2 = (cc[s] + cx[s] * xMin + cy[s] * yMin) - margin * (fabs(cx[s]) + fabs(cy[s]));
+    o.g[s][0] = g0;
+    o.g[s][1] = g1;
+    o.g[s][2] = g2;
+    if(!(fabs(g0) < 1.0e6 && fabs(g1) < 1.0e6 && fabs(g2) < 1.0e6))
+      ok = 0;                                       /* degenerate edge (infinite or NaN slope) */
   }
-  for(int r = 0; r < t.nRows && r < 3; r++)
+  /* (the loops are unrolled over the whole 3 x 3 map and predicated: compile-time indices, registers) */
+#pragma unroll
+  for(int r = 0; r < 3; r++)
   {
-    const double y0 = r == 0 ? t.byLo : t.yTrans[r - 1];
-    const double y1 = r == t.nRows - 1 ? t.byUp : t.yTrans[r];
-    for(int c = 0; c < t.nCells[r] && c < 3; c++)
+    const double y0 = r == 0 ? t.byLo : t.yTrans[r > 0 ? r - 1 : 0];
+    const double y1 = r == t.nRows - 1 ? t.byUp : t.yTrans[r < 2 ? r : 1];
+#pragma unroll
+    for(int c = 0; c < 3; c++)
     {
-      if(t.cellMask[r][c] != 0 || t.cellConst[r][c] != 0)
-        continue;
-      const double x0 = c == 0 ? t.bxLo : t.xTrans[r][c - 1];
-      const double x1 = c == t.nCells[r] - 1 ? t.bxUp : t.xTrans[r][c];
+      const bool live = r < t.nRows && c < t.nCells[r] && t.cellMask[r][c] == 0 && t.cellConst[r][c] == 0;
+      const double x0 = c == 0 ? t.bxLo : t.xTrans[r][c > 0 ? c - 1 : 0];
+      const double x1 = c == t.nCells[r] - 1 ? t.bxUp : t.xTrans[r][c < 2 ? c : 1];
       const double mx = (x0 + x1) / 2, my = (y0 + y1) / 2;
       bool inside = true;
+#pragma unroll
       for(int s = 0; s < 4; s++)
         inside = inside && (cx[s] * mx + cy[s] * my + cc[s] > 0);
-      if(inside)
-        o.ok = 0;
+      if(live && inside)
+        ok = 0;
     }
   }
+  o.ok = ok;
 }
 
 /* the boxes [x0, x1] x [y0, y1] of K1's grid cells that lie wholly inside all four edges (QuadGridSegs, ssd_device.h) */
