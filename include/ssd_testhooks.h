@@ -23,6 +23,8 @@ int ssd_test_sort_device(int device, const double *dist, int n, int32_t *perm);
  * quadrilateral (front-left, front-right, back-left, back-right as x,y) and n points; *err = 0 or the code of the
  * reference's throw (-1..-6), in which case `inside` is left zero */
 int ssd_test_quad_device(int device, const double quad[8], const double *pts_xy, int n, uint8_t *inside, int *err);
+/* the same code (csrc/ssd_quadtest.h: build_quad_test, the constant cell, quad_test) compiled for the host: runs without a GPU */
+int ssd_test_quad_host(const double quad[8], const double *pts_xy, int n, uint8_t *inside, int *err);
 /* test hook: k_inquad's cell classification "this box of K1's grid (x0, x1, y0, y1 in cells of 1 / box_x by 1 / box_y metres
  * from (x_min, y_min); boxes = n x 4 int32) lies wholly inside the quadrilateral" (csrc/ssd_quadtest.h: build_grid_segs,
  * grid_box_inside); *usable = 0 when the shortcut switches itself off for this quadrilateral (all boxes then answer 0) */

@@ -140,7 +140,7 @@ SOURCE_EXPORTS = [
 ]
 # libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
 HOOK_EXPORTS = [
-    "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_quad_device", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
+    "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
     "ssd_test_sort_device", "ssd_testhooks_last_error",
 ]
 SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
@@ -242,6 +242,8 @@ def hooks_lib():
     L.ssd_test_hypot_host.restype = C.c_double
     L.ssd_test_hypot_host.argtypes = [C.c_double, C.c_double]
     L.ssd_test_hypot_device.argtypes = [i32, vp, vp, vp, i32]
+    L.ssd_test_quad_host.argtypes = [vp, vp, i32, vp, vp]
+    L.ssd_test_quad_host.restype = i32
     L.ssd_test_frame_state.argtypes = [vp, i32, vp, C.c_size_t, vp]
     L.ssd_test_frame_state.restype = C.c_longlong
     L.ssd_test_sort_host.argtypes = [vp, i32, vp]
@@ -527,6 +529,17 @@ def quad_test_device(quad, pts, device=0):
     err = C.c_int(0)
     _check(hooks_lib().ssd_test_quad_device(device, q.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), len(p),
                                             out.ctypes.data_as(C.c_void_p), C.byref(err)), "hooks")
+    return err.value, out
+
+
+def quad_test_host(quad, pts):
+    """test hook: the same QuadrilateralTest code compiled for the host (no GPU) -> (err code, uint8 inside[n])"""
+    q = np.ascontiguousarray(quad, dtype=np.float64).reshape(8)
+    p = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros(len(p), dtype=np.uint8)
+    err = C.c_int(0)
+    _check(hooks_lib().ssd_test_quad_host(q.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), len(p),
+                                          out.ctypes.data_as(C.c_void_p), C.byref(err)), "hooks")
     return err.value, out
 
 

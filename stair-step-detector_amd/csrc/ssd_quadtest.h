@@ -277,7 +277,7 @@ __host__ __device__ inline void build_quad_test(const double *qin /* 4 x (x,y) *
 }
 
 /* QuadrilateralTest::isPointWithin (quadrilateralTest.cpp:445-451 and the selector lambdas :487-571) */
-__device__ __forceinline__ bool quad_test(const QuadTest &t, double x, double y)
+__host__ __device__ __forceinline__ bool quad_test(const QuadTest &t, double x, double y)
 {
   if(!(t.bxLo < x && x < t.bxUp && t.byLo < y && y < t.byUp))
     return false;
@@ -295,7 +295,7 @@ __device__ __forceinline__ bool quad_test(const QuadTest &t, double x, double y)
   bool ok = true;
   while(mask)                                          /* at most two segments per cell (:370-372) */
   {
-    const int s = __ffs(static_cast<int>(mask)) - 1;
+    const int s = __builtin_ffs(static_cast<int>(mask)) - 1;
     mask &= mask - 1;
     const double k = t.segK[s], cc = t.segC[s];
     const bool positive = t.segSteep[s] ? (x + y * k + cc > 0) : (x * k + y + cc > 0);
@@ -359,7 +359,7 @@ __host__ __device__ inline void build_grid_segs(const QuadTest &t, double xMin, 
 }
 
 /* the boxes [x0, x1] x [y0, y1] of K1's grid cells that lie wholly inside all four edges (QuadGridSegs, ssd_device.h) */
-__device__ __forceinline__ bool grid_box_inside(const QuadGridSegs &sg, int x0, int x1, int y0, int y1)
+__host__ __device__ __forceinline__ bool grid_box_inside(const QuadGridSegs &sg, int x0, int x1, int y0, int y1)
 {
   const double dx0 = x0, dx1 = x1 + 1, dy0 = y0, dy1 = y1 + 1;
   bool in = sg.ok != 0;

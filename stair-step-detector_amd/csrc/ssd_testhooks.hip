@@ -213,6 +213,23 @@ int ssd_test_quad_device(int device, const double quad[8], const double *pts_xy,
   return SSD_OK;
 }
 
+/* the same builder and evaluator compiled for the host (ssd_quadtest.h is host + device code): no GPU needed */
+int ssd_test_quad_host(const double quad[8], const double *pts_xy, int n, uint8_t *inside, int *err)
+{
+  if(!quad || !pts_xy || !inside || !err || n < 1)
+    return fail(SSD_E_ARG, "ssd_test_quad_host: bad argument");
+  ssd::QuadTest t;
+  ssd::build_quad_test(quad, t);
+  *err = t.err;
+  for(int i = 0; i < n; i++)
+  {
+    const double x = pts_xy[2 * i], y = pts_xy[2 * i + 1];
+    const bool fast = x >= t.fx0 && x < t.fx1 && y >= t.fy0 && y < t.fy1;
+    inside[i] = (t.err == 0 && (fast || ssd::quad_test(t, x, y))) ? 1 : 0;
+  }
+  return SSD_OK;
+}
+
 int ssd_test_grid_boxes_device(int device, const double quad[8], double x_min, double y_min, double box_x, double box_y,
                                const int32_t *boxes, int n, uint8_t *inside, int *usable)
 {

@@ -354,3 +354,49 @@ def test_deprojection_matches_oracle_bitwise(ssd, oracle):
     cfg = ssd.default_config(640, 480)
     res, *_ = oracle.process(ob.to_oracle_config(cfg), ob.to_oracle_calibration(t.constants), a)
     assert res.n_steps == 4
+
+
+def test_host_build_of_the_kernels_quadrilateral_test_against_the_reference_goldens(ssd):
+    """PINNED, and without a GPU: csrc/ssd_quadtest.h (the register-resident builder k_quads runs, the constant cell, the
+    evaluator k_inquad runs) is host + device code; compiled for the host (ssd_test_quad_host) it must reproduce the
+    vectors the reference's own quadrilateralTest.cpp produced (tests/golden/ref_quadtest.json, generator
+    make_ref_goldens.py) — every throw code and every point.  The -m gpu twin runs the device build of the same code."""
+    import json
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_quadtest.json")))
+    seen = set()
+    for c in cases:
+        quad = np.array([float.fromhex(x) for x in c["quad"]]).reshape(4, 2)
+        pts = np.array([float.fromhex(x) for x in c["pts"]]).reshape(-1, 2)
+        err, inside = ssd.quad_test_host(quad, pts)
+        assert err == c["rc"], (err, c["rc"])
+        seen.add(err)
+        if err == 0:
+            assert "".join(str(int(v)) for v in inside) == c["inside"]
+    assert 0 in seen and -1 in seen
+
+
+def test_host_build_of_the_quadrilateral_test_against_the_oracle_on_random_quadrilaterals(ssd, oracle):
+    """The same host build against the oracle's restatement (itself checked against the real reference in test_oracle.py) on
+    random treads: turned, sheared, with equal coordinates (merged cells) — throw code and every point."""
+    rng = np.random.default_rng(977)
+    codes = set()
+    for it in range(400):
+        yaw = np.radians(rng.uniform(-50, 50)) if it % 3 else 0.0
+        w, d = rng.uniform(0.2, 1.0), rng.uniform(0.08, 0.4)
+        base = np.array([[-w / 2, -d / 2], [w / 2, -d / 2], [-w / 2, d / 2], [w / 2, d / 2]])
+        if it % 4 != 1:
+            base += rng.normal(0, 0.03 if it % 4 else 0.15, base.shape)
+        rot = np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]])
+        quad = base @ rot.T + [rng.uniform(-0.2, 0.2), rng.uniform(0.4, 1.0)]
+        if it % 7 == 0:
+            quad = np.round(quad * 8) / 8
+        lo, hi = quad.min(axis=0) - 0.05, quad.max(axis=0) + 0.05
+        pts = rng.uniform(lo, hi, (300, 2))
+        pts[:8] = np.vstack([quad, quad + 1e-12])            # the corners themselves and just beside them
+        err, inside = ssd.quad_test_host(quad, pts)
+        want_err, want = oracle.quad_test(quad, pts)
+        codes.add(err)
+        assert err == want_err, (it, err, want_err)
+        if err == 0:
+            assert np.array_equal(inside.astype(bool), np.asarray(want).astype(bool)), it
+    assert 0 in codes and len(codes) > 1
