@@ -371,20 +371,26 @@ def main():
         if world == 1 and not depth_in and not args.no_latency:
             # BASELINE configs[1]: ONE frame resident in HBM through the whole path (enqueue + fetch); GPU-latency-bound
             one = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=1), trans, device)
-            one.set_timing(True)
             lat, st1 = [], {k: 0.0 for k in ssd.STAGE_NAMES}
-            for i in range(8 + 48):
+            for i in range(8 + 48):                       # the latency: no timing events between the launches
                 c0 = time.perf_counter()
                 one.enqueue(frames.data_ptr(), 1, stream=stream)
                 one.fetch(1)
                 if i >= 8:
                     lat.append(time.perf_counter() - c0)
+            one.set_timing(True)
+            for i in range(4 + 16):                       # the stages: events between the launches (they add ~20 us per call)
+                one.enqueue(frames.data_ptr(), 1, stream=stream)
+                one.fetch(1)
+                if i >= 4:
                     for k, v in one.stage_times_ms().items():
-                        st1[k] += v / 48
+                        st1[k] += v / 16
             one.close()
             out["single_frame"] = {"latency_ms_device_resident": sorted(lat)[len(lat) // 2] * 1e3, "stage_ms": st1,
-                                   "note": "one %dx%d frame already in HBM, ssd_enqueue + ssd_fetch (7 launches, state memset, result copy); "
-                                           "median of 48; bounded by the GPU-side latency of the launches' serial sections, not by HBM" % (W, H)}
+                                   "note": "one %dx%d frame already in HBM, ssd_enqueue + ssd_fetch (state memset + 7 dependent launches, the last "
+                                           "one storing the result into pinned host memory); median of 48 calls without timing events; stage_ms "
+                                           "from 16 further calls with events between the launches; bounded by the GPU-side latency of the "
+                                           "kernels' short phases (DESIGN.md section 3), not by HBM" % (W, H)}
         if world == 1 and not depth_in and not args.no_latency:
             # Two handles (each with its own workspace) on two streams, fed alternately, no timing events: the launches of one
             # batch fill the gaps the other's small, latency-bound kernels leave.  Reported beside `value`, which stays the
