@@ -601,10 +601,7 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   const DepthSrc depthSrc{ h->dDepthMaps, h->dDepthMaps ? h->dDepthMaps + P.W : nullptr, h->intr.depth_units, P.W, P.H };
   const DepthSrc *depth = depthInput ? &depthSrc : nullptr;
   const int chunk = choose_chunk(P.nPoints, nframes);
-  /* K2 and K4 walk cell columns: the taller a block's chunk, the fewer window flushes and block starts per cell — worth more
-   * than block count as long as the launch keeps a few hundred blocks (measured, XGA, tools/exp_frames.sh: 16 frames
-   * 39.8 k -> 52.1 k frames/s, 64 frames 112 k -> 126 k; from 256 frames on the general chunk is as tall already).
-   * K2: up to 32 tiles; K4 (a third of the cells, more state per block): up to 16. */
+  /* K2 and K4 walk cell columns: the taller a block's chunk, the fewer window flushes and block starts per cell (below) */
   /* K1 ends every block with up to 121 global atomics into the frame's histogram: with one-tile chunks (single frames) 768
    * blocks queue up on the same addresses; at most SSD_K1_BLOCKS_PER_FRAME blocks per frame keeps that short */
   int chunkHist = chunk;
@@ -617,13 +614,24 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   }
   int chunkRaster = chunk, chunkInquad = chunk;
   {
+    /* Blocks of K2 / K4 by batch size (XGA, tools/exp_frames.sh, 1-128 frames swept): what a block pays per start (state,
+     * LDS, cell list, window flush, final atomics) wants tall chunks, the 2048 block slots of the chip want >= ~1536 blocks,
+     * and a grid of one to two rounds of slots wants more, smaller blocks for its tail.  Rule: chunks of more than 8 tiles
+     * only while they leave >= 6144 blocks (three rounds); else as tall as leaves >= 1536 blocks, K2 never below 2 tiles.
+     * Against the former ">= 600 blocks": 8 / 16 / 32 / 64 frames 46 -> 49 k, 73 -> 82 k, 113 -> 124 k, 159 -> 172 k frames/s. */
     const long long totalTiles = (static_cast<long long>(P.nPoints) + kTileHost - 1) / kTileHost * nframes;
-    const int minBlocks = env_int("SSD_K24_MIN_BLOCKS", 600);
+    const int minBlocks = env_int("SSD_K24_MIN_BLOCKS", 1536), tallBlocks = env_int("SSD_K24_TALL_BLOCKS", 6144);
     int t2 = env_int("SSD_K2_CHUNK_TILES", 32), t4 = env_int("SSD_K4_CHUNK_TILES", 16);
     if(t2 > kMaxTilesPerBlockRasterHost) t2 = kMaxTilesPerBlockRasterHost;
     if(t4 > kMaxTilesPerBlockInquadHost) t4 = kMaxTilesPerBlockInquadHost;
-    while(t2 > 1 && totalTiles / t2 < minBlocks) t2 /= 2;
-    while(t4 > 1 && totalTiles / t4 < minBlocks) t4 /= 2;
+    auto pick = [&](int t, int tMin)
+    {
+      while(t > 8 && totalTiles / t < tallBlocks) t /= 2;
+      while(t > tMin && totalTiles / t < minBlocks) t /= 2;
+      return t;
+    };
+    t2 = pick(t2, 2);
+    t4 = pick(t4, 1);
     if(t2 * kTileHost > chunkRaster) chunkRaster = t2 * kTileHost;
     if(t4 * kTileHost > chunkInquad) chunkInquad = t4 * kTileHost;
   }
