@@ -649,7 +649,12 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   }
   if(stages & SSD_STAGE_HIST)
   {
-    HIP_TRY(hipMemsetAsync(h->dState, 0, sizeof(FrameState) * nframes, s));
+    /* No memset of the state in front of a call: K1 only needs its accumulators zero, and k_peaks — their one reader —
+     * clears them as it takes them (everything else in FrameState is written before it is read).  Only after a call that
+     * ran K1 without k_peaks (ssd_enqueue_stages), or one that failed half way, the state is zeroed here. */
+    if(h->dirtyFrames > 0)
+      HIP_TRY(hipMemsetAsync(h->dState, 0, sizeof(FrameState) * h->dirtyFrames, s));
+    h->dirtyFrames = nframes;
     if(dbg)
       HIP_TRY(hipMemsetAsync(dbg, 0, sizeof(DebugFrame) * nframes, s));
   }
@@ -697,6 +702,8 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->lastDone, s));
+  if((stages & SSD_STAGE_PEAKS) && nframes >= h->dirtyFrames)
+    h->dirtyFrames = 0;
   h->lastStream = s;
   h->haveLast = true;
   /* a raster without its consumer leaves bits behind */

@@ -128,7 +128,11 @@ struct RiserState
 
 struct FrameState
 {
-  unsigned int hist[kMaxBins];
+  /* K1's accumulators.  Zero between calls: k_peaks takes them over into hist / nNonZero below and clears them, so a call
+   * needs no memset of the state in front of it (ssd_capi.hip, stateClean) */
+  unsigned int histAcc[kMaxBins];
+  unsigned int nNonZeroAcc;
+  unsigned int hist[kMaxBins];     /* the frame's height histogram (as k_peaks took it) */
   unsigned int nNonZero, nInRange, nOob, status;
   int nPlateaus, firstStep, nStepImages, groundInd, firstValidInd;
   int groundFrontValid;

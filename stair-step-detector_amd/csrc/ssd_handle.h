@@ -47,6 +47,7 @@ struct ssd_handle
   unsigned long long *dDebugImg = nullptr;
   bool debug = false;
   bool imagesDirty = false;
+  int dirtyFrames = 0;                      /* leading FrameStates whose K1 accumulators may be non-zero (k_peaks clears them) */
   int lastFrames = 0;
   size_t bytes = 0;
   /* per-stage timing: a ring of event sets, one per enqueue, so that a timed loop never has to synchronise */

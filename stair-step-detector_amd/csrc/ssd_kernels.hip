@@ -401,10 +401,10 @@ __device__ __forceinline__ void hist_block(HistLds &L, const float *__restrict__
     for(int k = 0; k < kHistCopies; k++)
       s += lh[b * kHistCopies + ((k + tid) & (kHistCopies - 1))];      /* rotated: conflict-free */
     if(s)
-      atomicAdd(&fs.hist[b], s);
+      atomicAdd(&fs.histAcc[b], s);
   }
   if(tid == 0 && lNonZero)
-    atomicAdd(&fs.nNonZero, lNonZero);
+    atomicAdd(&fs.nNonZeroAcc, lNonZero);
   /* the block's cell records, in one burst */
   {
     uint2 *dst = tileMasks + static_cast<size_t>(frame) * tileMaskStride + static_cast<size_t>(begin / kCell);
@@ -444,11 +444,17 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
   unsigned int total = 0;
   for(int b = lane; b <= kMaxBins; b += 64)
   {
-    const unsigned int v = b < nb ? fs.hist[b] : 0u;
+    /* K1's accumulator is taken over and left zero for the next call (FrameState::histAcc) */
+    const unsigned int v = b < nb ? fs.histAcc[b] : 0u;
     hist[b] = v;
     total += v;
     if(b < kMaxBins)
+    {
       lut[b] = 0xff;
+      fs.hist[b] = v;
+      if(b < nb)
+        fs.histAcc[b] = 0u;
+    }
   }
 #pragma unroll
   for(int o = 32; o > 0; o >>= 1)
@@ -597,8 +603,14 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
     fs.imgYMin[lane] = 0x7fffffff; fs.imgYMax[lane] = -1;
     fs.imgXMin[lane] = 0x7fffffff; fs.imgXMax[lane] = -1;
   }
+  if(lane < kMaxStepImages)
+    fs.totZ[lane] = 0;                                 /* k_raster's sums start from zero */
   if(lane == 0)
   {
+    fs.nNonZero = fs.nNonZeroAcc;
+    fs.nNonZeroAcc = 0u;
+    fs.nOob = 0u;
+    fs.status = sOverflow ? static_cast<unsigned int>(SSD_ST_OVERFLOW) : 0u;     /* the frame's status starts here */
     fs.nInRange = total;
     fs.nPlateaus = nPl;
     fs.groundInd = sGround;
@@ -608,8 +620,6 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
     fs.wantedSteps = wanted;
     fs.wantedQuads = 0u;
     fs.anyActive = 0u;
-    if(sOverflow)
-      fs.status |= SSD_ST_OVERFLOW;
   }
 
   if(dbg)
