@@ -464,3 +464,50 @@ def test_randomised_sweep_small(ssd, gpu_device):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     summary = json.loads(p.stdout.strip().splitlines()[-1])
     assert summary["mismatches"] == 0 and summary["frames"] >= 8 * 32 // 2
+
+
+def test_one_handle_through_changing_calls_leaves_nothing_behind(ssd, oracle, gpu_device):
+    """The per-frame device state is not zeroed in front of a call (k_peaks clears K1's accumulators as it takes them, every
+    other field is written before it is read): one handle is driven through calls that differ in everything the state holds —
+    8 steps with outliers, then empty frames, no stairs, throwing quadrilaterals, fewer frames than before, more than before,
+    a K1-only call in between (which must trigger the zeroing), risers switched on and off — and every result must be, byte for
+    byte, what a fresh handle gives for the same frames, and the oracle's."""
+    W, H = 640, 480
+    groups = [["vga_8steps_outliers", "vga_yaw_outliers", "vga_3steps_clean", "vga_8steps_outliers", "vga_3steps_noise2mm", "vga_yaw30_narrow"],
+              ["vga_empty", "vga_empty"],
+              ["vga_yaw40_wide_throws", "vga_yaw50_throws", "vga_3steps_clean"],
+              ["vga_3steps_noise2mm"],
+              ["vga_yaw_outliers", "vga_8steps_outliers", "vga_empty", "vga_yaw50_throws", "vga_3steps_clean", "vga_yaw30_narrow", "vga_8steps_outliers", "vga_3steps_noise2mm"],
+              ["fuzz_border_closing_0", "vga_3steps_clean"]]
+    first = scenes.make(ssd, groups[0][0])
+    trans = ssd.transformation_for_scene(first)
+    cfg = ssd.default_config(W, H, max_frames_per_batch=8)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    buf = ssd.DeviceBuffer(8 * W * H * 12, gpu_device)
+    for round_ in range(2):
+        for gi, names in enumerate(groups):
+            sc_list = [scenes.make(ssd, n) for n in names]
+            xyz = ssd.synth_host(sc_list)
+            n = len(names)
+            risers = (gi + round_) % 3 == 1
+            det.set_risers(risers, 0.03, 200)
+            if gi == 3:
+                # K1 alone on more frames than the next call takes: its accumulators stay dirty, the next call has to zero them
+                buf.upload(ssd.synth_host([scenes.make(ssd, "vga_8steps_outliers")] * 5))
+                det.enqueue(buf.ptr, 5, stages=ssd.STAGE_HIST)
+            buf.upload(xyz)
+            det.enqueue(buf.ptr, n)
+            got = det.fetch_list(n)
+            fresh_det = ssd.Detector(cfg, trans, gpu_device)
+            fresh_det.set_risers(risers, 0.03, 200)
+            fresh = fresh_det.process_host(xyz)
+            for i in range(n):
+                assert bytes(got[i]) == bytes(fresh[i]), "round %d, call %d, frame %d (%s): differs from a fresh handle" % (round_, gi, i, names[i])
+                parity.check_results_only(ssd, oracle, cfg, trans.constants, xyz[i], got[i])
+            if risers:
+                a, b = det.fetch_risers(n), fresh_det.fetch_risers(n)
+                for i in range(n):
+                    assert bytes(a[i]) == bytes(b[i]), "round %d, call %d, frame %d: riser evidence differs from a fresh handle" % (round_, gi, i)
+            fresh_det.close()
+    det.close()
+    buf.free()
