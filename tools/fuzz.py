@@ -77,6 +77,12 @@ def main():
         else:
             buf = ssd.DeviceBuffer(F * W * H * 12, 0)
             ssd.synth_device(scenes, buf.ptr, device=0)
+            if F > 1:
+                # a call on other frames first (the batch shifted by k): whatever it leaves in the handle's per-frame state
+                # (nothing is zeroed in front of a call) must not reach the call that is checked
+                k = int(rng.integers(1, F))
+                det.enqueue(buf.ptr + k * W * H * 12, F - k)
+                det.fetch_list(F - k)
             det.enqueue(buf.ptr, F)
             res = det.fetch_list(F)
             host = ssd.synth_host(scenes)            # bit-identical to the device generator (tested)
