@@ -397,7 +397,7 @@ def main():
             # single-handle rate the roofline's live per-kernel durations belong to (timing events keep launches from overlapping).
             out["pipelined"] = {"note": "same batch, same K steps through ssd_pipeline_* (depth handles on depth HIP streams fed "
                                          "round-robin, per-stage timing events off; INTEGRATION.md section 4)", "unit": "frames/s"}
-            for depth in (2, 4):
+            for depth in (2, 3, 4):
                 pipe = ssd.Pipeline(cfg, trans, device, depth=depth)
                 torch.cuda.synchronize()
 
