@@ -25,6 +25,11 @@ int ssd_test_sort_device(int device, const double *dist, int n, int32_t *perm);
 int ssd_test_quad_device(int device, const double quad[8], const double *pts_xy, int n, uint8_t *inside, int *err);
 /* the same code (csrc/ssd_quadtest.h: build_quad_test, the constant cell, quad_test) compiled for the host: runs without a GPU */
 int ssd_test_quad_host(const double quad[8], const double *pts_xy, int n, uint8_t *inside, int *err);
+/* test hook: the kernels' 3x3 closing on bit images (csrc/ssd_closing.h) compiled for the host: closed_out (width x height bytes,
+ * may be null) = the closed image computed word by word; first / last [n_cols] = first and last closed row of the pixel columns
+ * x0, x0 + x_step, .. by the column-wise form the scans use, over rows [y_from, height) cut into bands of band_rows rows */
+int ssd_test_closing_host(const uint8_t *img, int width, int height, int x0, int x_step, int y_from, int band_rows, uint8_t *closed_out,
+                          int32_t *first, int32_t *last, int n_cols);
 /* test hook: k_inquad's cell classification "this box of K1's grid (x0, x1, y0, y1 in cells of 1 / box_x by 1 / box_y metres
  * from (x_min, y_min); boxes = n x 4 int32) lies wholly inside the quadrilateral" (csrc/ssd_quadtest.h: build_grid_segs,
  * grid_box_inside); *usable = 0 when the shortcut switches itself off for this quadrilateral (all boxes then answer 0) */

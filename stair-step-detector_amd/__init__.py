@@ -140,7 +140,7 @@ SOURCE_EXPORTS = [
 ]
 # libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
 HOOK_EXPORTS = [
-    "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
+    "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
     "ssd_test_sort_device", "ssd_testhooks_last_error",
 ]
 SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
@@ -242,6 +242,8 @@ def hooks_lib():
     L.ssd_test_hypot_host.restype = C.c_double
     L.ssd_test_hypot_host.argtypes = [C.c_double, C.c_double]
     L.ssd_test_hypot_device.argtypes = [i32, vp, vp, vp, i32]
+    L.ssd_test_closing_host.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32]
+    L.ssd_test_closing_host.restype = i32
     L.ssd_test_quad_host.argtypes = [vp, vp, i32, vp, vp]
     L.ssd_test_quad_host.restype = i32
     L.ssd_test_frame_state.argtypes = [vp, i32, vp, C.c_size_t, vp]
@@ -530,6 +532,21 @@ def quad_test_device(quad, pts, device=0):
     _check(hooks_lib().ssd_test_quad_device(device, q.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), len(p),
                                             out.ctypes.data_as(C.c_void_p), C.byref(err)), "hooks")
     return err.value, out
+
+
+def closing_host(img, x0, x_step, y_from=0, band_rows=16, want_closed=True):
+    """test hook: the kernels' closing compiled for the host -> (closed uint8 image or None, first[], last[]) for the pixel
+    columns x0, x0 + x_step, .. (rows y_from..)"""
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = a.shape
+    n = (w - 1 - x0) // x_step + 1 if w > x0 else 0
+    closed = np.zeros_like(a) if want_closed else None
+    first = np.zeros(max(n, 1), dtype=np.int32)
+    last = np.zeros(max(n, 1), dtype=np.int32)
+    _check(hooks_lib().ssd_test_closing_host(a.ctypes.data_as(C.c_void_p), w, h, x0, x_step, y_from, band_rows,
+                                             closed.ctypes.data_as(C.c_void_p) if want_closed else None,
+                                             first.ctypes.data_as(C.c_void_p), last.ctypes.data_as(C.c_void_p), n), "hooks")
+    return closed, first[:n], last[:n]
 
 
 def quad_test_host(quad, pts):

@@ -1,0 +1,214 @@
+/*
+ * ssd_closing.h — cv::morphologyEx(MORPH_CLOSE, 3x3 rect, 1 iteration, default border; segmentation.cpp:888,928) on the bit
+ * images of the kernels: whole 64-bit words on the fly (closed_word / closed_column: the probe rows of k_outline, the debug
+ * capture) and single pixel columns (closed_scan_column: the scans of k_outline and k_final).  Host + device code: the
+ * kernels run the device build, the CPU test suite the host build (ssd_test_closing_host, ssd_testhooks.hip) against the
+ * oracle's closing, which is itself checked against scipy.ndimage.
+ */
+#ifndef SSD_CLOSING_H_
+#define SSD_CLOSING_H_
+
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+namespace ssd
+{
+
+struct BitImg
+{
+  const unsigned long long *w;   /* H rows of W64 words; bit i of word c is pixel x = 64c + i */
+  int W, H, W64;
+};
+
+__host__ __device__ __forceinline__ unsigned long long raw_word(const BitImg &im, int y, int c)
+{
+  return (y >= 0 && y < im.H && c >= 0 && c < im.W64) ? im.w[static_cast<size_t>(y) * im.W64 + c] : 0ull;
+}
+
+/* word c of row y of the image after cv::morphologyEx(MORPH_CLOSE, 3x3 rect, 1 iteration, default
+ * border): dilation = OR over the in-image 3x3 neighbours, erosion = AND over them (pixels outside
+ * the image never win; segmentation.cpp:888,928).  Needs raw rows y-2..y+2, words c-1..c+1. */
+struct HRow
+{
+  unsigned long long c;          /* word c of a row, dilated horizontally */
+  unsigned int l, r;             /* the dilated pixels x = 64c-1 and x = 64c+64 */
+};
+
+__host__ __device__ __forceinline__ HRow hdilated_row(const BitImg &im, int yy, int c)
+{
+  const unsigned long long L = raw_word(im, yy, c - 1), w = raw_word(im, yy, c), R = raw_word(im, yy, c + 1);
+  HRow h;
+  h.c = w | (w << 1) | (w >> 1) | (L >> 63) | (R << 63);
+  h.l = static_cast<unsigned int>(((L >> 63) | (L >> 62) | w) & 1ull);
+  h.r = static_cast<unsigned int>((R | (R >> 1) | (w >> 63)) & 1ull);
+  return h;
+}
+
+/* h[r] = hdilated_row(y - 2 + r) */
+__host__ __device__ __forceinline__ unsigned long long closed_from_rows(const BitImg &im, int y, int c, const HRow h[5])
+{
+  const int rem = im.W - 64 * c;
+  const unsigned long long vm = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);        /* pixels of this word inside the image */
+  unsigned long long res = vm;
+#pragma unroll
+  for(int r = 0; r < 3; r++)
+  {
+    const int yy = y - 1 + r;
+    if(yy < 0 || yy >= im.H)
+      continue;                                   /* row outside the image: ignored by the erosion */
+    unsigned long long dc = h[r].c | h[r + 1].c | h[r + 2].c;
+    unsigned int dl = h[r].l | h[r + 1].l | h[r + 2].l;
+    unsigned int dr = h[r].r | h[r + 1].r | h[r + 2].r;
+    dc |= ~vm;
+    if(c == 0) dl = 1u;
+    if(rem <= 64) dr = 1u;
+    res &= dc & ((dc << 1) | dl) & ((dc >> 1) | (static_cast<unsigned long long>(dr) << 63));
+  }
+  return res;
+}
+
+/* a bounding box of raw bits (rows by0..by1, word columns ..bc1; word column 0 holds x = 0 and x = 1 alike) ->
+ * the box its closing can reach: one more row / the last word column when the bits come within one pixel of
+ * the image border, where the erosion has no out-of-image neighbour to veto it */
+__host__ __device__ __forceinline__ void grow_box_to_border(int W, int H, int W64, int &by0, int &by1, int &bc1)
+{
+  if(by1 < by0)
+    return;
+  if(by0 == 1)
+    by0 = 0;
+  if(by1 == H - 2)
+    by1 = H - 1;
+  if(bc1 == W64 - 2 && ((W - 1) & 63) == 0)
+    bc1 = W64 - 1;
+}
+
+__host__ __device__ inline unsigned long long closed_word(const BitImg &im, int y, int c)
+{
+  HRow h[5];
+#pragma unroll
+  for(int r = 0; r < 5; r++)
+    h[r] = hdilated_row(im, y - 2 + r, c);
+  return closed_from_rows(im, y, c, h);
+}
+
+/* closed words of column c, rows [yA, yB), top to bottom with a rolling window of five dilated rows
+ * (3 word loads per row instead of 15); calls visit(y, closedWord) for the non-zero ones (all with `all`) */
+template<typename Visit>
+__host__ __device__ __forceinline__ void closed_column(const BitImg &im, int c, int yA, int yB, bool all, Visit visit)
+{
+  HRow h[5];
+#pragma unroll
+  for(int r = 1; r < 5; r++)
+    h[r] = hdilated_row(im, yA - 3 + r, c);
+  /* four rows per step: their twelve word loads are issued together (one memory round trip instead of four — the
+   * walk is a chain of dependent latencies, and with outliers the box is the whole image) */
+  for(int y0 = yA; y0 < yB; y0 += 4)
+  {
+    HRow next[4];
+#pragma unroll
+    for(int k = 0; k < 4; k++)
+      next[k] = hdilated_row(im, y0 + k + 2, c);          /* rows beyond the image read as zero */
+#pragma unroll
+    for(int k = 0; k < 4; k++)
+    {
+      const int y = y0 + k;
+#pragma unroll
+      for(int r = 0; r < 4; r++)
+        h[r] = h[r + 1];
+      h[4] = next[k];
+      if(y >= yB)
+        continue;
+      if(!all && (h[0].c | h[1].c | h[2].c | h[3].c | h[4].c) == 0ull)
+        continue;                                 /* nothing lit within two rows: the closing has nothing either */
+      visit(y, closed_from_rows(im, y, c, h));
+    }
+  }
+}
+
+/* The closed image at ONE pixel column x, rows [yA, yB) top to bottom: hit(y) for every closed pixel (x, y).
+ * The scans of the outline want nothing else of the closed image than its first and last lit row in every 25th (50th)
+ * column, and the closing at (x, y) is a function of the raw 5 x 5 neighbourhood only: per row a 5-bit strip of the raw
+ * row (pixels x-2 .. x+2; two 32-bit loads and a funnel shift), its horizontal dilation at x-1, x, x+1 (3 bits), then the
+ * vertical dilation and the erosion on those 3-bit values — a dozen 32-bit operations per row, against some hundred 64-bit
+ * ones for a whole closed word.  Same definition as closed_from_rows: pixels outside the image never veto the erosion and
+ * never feed the dilation (cv::morphologyEx, default border; segmentation.cpp:888,928). */
+/* bits sh .. sh + 31 of hi:lo (v_alignbit_b32 on the device) */
+__host__ __device__ __forceinline__ unsigned int funnel_right(unsigned int lo, unsigned int hi, int sh)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __funnelshift_r(lo, hi, sh);
+#else
+  return sh == 0 ? lo : (lo >> sh) | (hi << (32 - sh));
+#endif
+}
+
+struct ColumnStrip
+{
+  const unsigned int *row0;      /* the image as 32-bit words */
+  long long stride;              /* 32-bit words per row */
+  int i0, i1, sh, H;             /* word indices of pixel x-2 and of the word after it (-1: outside), shift of pixel x-2 */
+  unsigned int ignore;           /* of x-1, x, x+1 the positions outside the image */
+};
+__host__ __device__ __forceinline__ ColumnStrip column_strip(const BitImg &im, int x)
+{
+  ColumnStrip c;
+  c.row0 = reinterpret_cast<const unsigned int *>(im.w);
+  c.stride = 2ll * im.W64;
+  const int xs = x - 2;
+  const int w = xs >> 5;                               /* arithmetic: -1 for xs < 0 */
+  c.sh = xs & 31;
+  c.i0 = (w >= 0 && w < 2 * im.W64) ? w : -1;
+  c.i1 = (w + 1 >= 0 && w + 1 < 2 * im.W64) ? w + 1 : -1;
+  c.H = im.H;
+  c.ignore = (x - 1 < 0 ? 1u : 0u) | (x + 1 >= im.W ? 4u : 0u);
+  return c;
+}
+/* horizontally dilated raw row yy at x-1, x, x+1 (3 bits); rows outside the image read as zero */
+__host__ __device__ __forceinline__ unsigned int strip_hdil(const ColumnStrip &c, int yy, int yEnd)
+{
+  const bool in = yy >= 0 && yy < c.H && yy < yEnd;
+  const unsigned int *r = c.row0 + static_cast<long long>(in ? yy : 0) * c.stride;
+  const unsigned int lo = (in && c.i0 >= 0) ? r[c.i0] : 0u;
+  const unsigned int hi = (in && c.i1 >= 0) ? r[c.i1] : 0u;
+  const unsigned int v = funnel_right(lo, hi, c.sh) & 31u;
+  return (v | (v >> 1) | (v >> 2)) & 7u;
+}
+template<typename Hit>
+__host__ __device__ __forceinline__ void closed_scan_column(const BitImg &im, int x, int yA, int yB, Hit hit)
+{
+  constexpr int kRows = 16;                            /* rows per step: their loads are issued together */
+  const int yEnd = yB + 2;                             /* rows from here on feed no row of the band: not loaded */
+  const ColumnStrip c = column_strip(im, x);
+  /* h[i] = the dilated strip of row y0 - 2 + i.  The four rows above the band are loaded with the first step's rows:
+   * nothing is consumed before all of them are under way (a band is a chain of memory round trips and little else) */
+  unsigned int h[kRows + 4];
+#pragma unroll
+  for(int k = 0; k < 4; k++)
+    h[k] = strip_hdil(c, yA - 2 + k, yEnd);
+  for(int y0 = yA; y0 < yB; y0 += kRows)
+  {
+#pragma unroll
+    for(int k = 0; k < kRows; k++)
+      h[4 + k] = strip_hdil(c, y0 + 2 + k, yEnd);
+    /* f bit i: the dilated image is lit at every in-image pixel of x-1 .. x+1 in row y0 - 2 + i (rows outside: set) */
+    unsigned int f = 0u;
+#pragma unroll
+    for(int i = 1; i < kRows + 3; i++)
+    {
+      const int yy = y0 - 2 + i;
+      const bool full = yy < 0 || yy >= c.H || ((h[i - 1] | h[i] | h[i + 1] | c.ignore) & 7u) == 7u;
+      f |= full ? 1u << i : 0u;
+    }
+#pragma unroll
+    for(int k = 0; k < kRows; k++)
+      if(y0 + k < yB && ((f >> (k + 1)) & 7u) == 7u)
+        hit(y0 + k);
+#pragma unroll
+    for(int k = 0; k < 4; k++)
+      h[k] = h[kRows + k];
+  }
+}
+
+} // namespace ssd
+
+#endif /* SSD_CLOSING_H_ */

@@ -6,6 +6,7 @@
 #include "ssd_handle.h"
 #include "ssd_math.h"
 #include "ssd_quadtest.h"
+#include "ssd_closing.h"
 #include "ssd_sort.h"
 #include "../../include/ssd_testhooks.h"
 
@@ -210,6 +211,47 @@ int ssd_test_quad_device(int device, const double quad[8], const double *pts_xy,
   HIP_TRY(hipMemcpy(inside, di, static_cast<size_t>(n), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(err, de, sizeof(int), hipMemcpyDeviceToHost));
   (void)hipFree(dq); (void)hipFree(dp); (void)hipFree(di); (void)hipFree(de);
+  return SSD_OK;
+}
+
+/* the kernels' closing compiled for the host (ssd_closing.h is host + device code): a W x H byte image (non-zero = lit) is
+ * packed into the kernels' bit image; closed_out (W x H bytes, may be null) = the closed image word by word (closed_word);
+ * first / last [n_cols] = the first and last closed row of the pixel columns x0, x0 + x_step, .. (closed_scan_column over
+ * rows [y_from, H), in bands of band_rows rows as the kernels cut them), -1 where none */
+int ssd_test_closing_host(const uint8_t *img, int width, int height, int x0, int x_step, int y_from, int band_rows, uint8_t *closed_out,
+                          int32_t *first, int32_t *last, int n_cols)
+{
+  if(!img || width < 1 || height < 1 || x_step < 1 || x0 < 0 || y_from < 0 || band_rows < 1 || (n_cols > 0 && (!first || !last)))
+    return fail(SSD_E_ARG, "ssd_test_closing_host: bad argument");
+  const int W64 = (width + 63) / 64;
+  std::vector<unsigned long long> bits(static_cast<size_t>(W64) * height, 0ull);
+  for(int y = 0; y < height; y++)
+    for(int x = 0; x < width; x++)
+      if(img[static_cast<size_t>(y) * width + x])
+        bits[static_cast<size_t>(y) * W64 + (x >> 6)] |= 1ull << (x & 63);
+  const ssd::BitImg im{ bits.data(), width, height, W64 };
+  if(closed_out)
+    for(int y = 0; y < height; y++)
+      for(int c = 0; c < W64; c++)
+      {
+        const unsigned long long w = ssd::closed_word(im, y, c);
+        for(int b = 0; b < 64 && 64 * c + b < width; b++)
+          closed_out[static_cast<size_t>(y) * width + 64 * c + b] = ((w >> b) & 1ull) ? 255 : 0;
+      }
+  for(int j = 0; j < n_cols; j++)
+  {
+    const int x = x0 + x_step * j;
+    first[j] = last[j] = -1;
+    if(x >= width)
+      continue;
+    for(int yA = y_from; yA < height; yA += band_rows)
+      ssd::closed_scan_column(im, x, yA, yA + band_rows < height ? yA + band_rows : height, [&](int y)
+      {
+        if(first[j] < 0)
+          first[j] = y;
+        last[j] = y;
+      });
+  }
   return SSD_OK;
 }
 

@@ -400,3 +400,36 @@ def test_host_build_of_the_quadrilateral_test_against_the_oracle_on_random_quadr
         if err == 0:
             assert np.array_equal(inside.astype(bool), np.asarray(want).astype(bool)), it
     assert 0 in codes and len(codes) > 1
+
+
+def test_host_build_of_the_kernels_closing_against_the_oracle(ssd, oracle):
+    """csrc/ssd_closing.h — the 3x3 closing on bit images as k_outline / k_final compute it, word by word (closed_word: probe
+    rows, debug capture) and by pixel column from the raw 5 x 5 neighbourhood (closed_scan_column: the scans) — is host + device
+    code.  Its host build against the oracle's closing (checked against scipy.ndimage and the border behaviour of
+    cv::morphologyEx in test_oracle.py): blobs, noise, lit borders, widths that are no multiple of 64 or 32, every band
+    height the kernels use; the first and last closed row of every 25th column must be those of the closed image."""
+    rng = np.random.default_rng(4711)
+    for case in range(40):
+        w = int(rng.choice([64, 65, 97, 128, 200, 427, 600]))
+        h = int(rng.integers(12, 90))
+        img = np.zeros((h, w), np.uint8)
+        for _ in range(int(rng.integers(1, 6))):                      # rectangles, some touching the borders
+            x0, y0 = int(rng.integers(-5, w - 3)), int(rng.integers(-5, h - 3))
+            x1, y1 = x0 + int(rng.integers(2, w // 2 + 3)), y0 + int(rng.integers(2, h // 2 + 3))
+            img[max(y0, 0):max(y1, 0), max(x0, 0):max(x1, 0)] = 255
+        img[rng.random((h, w)) < rng.choice([0.0, 0.02, 0.2, 0.5])] = 255    # salt
+        img[rng.random((h, w)) < rng.choice([0.0, 0.05, 0.3])] = 0           # pepper: holes for the closing to fill (or not)
+        if case % 5 == 0:
+            img[0, :] = 255; img[:, 0] = 255
+        if case % 7 == 0:
+            img[-1, :] = 255; img[:, -1] = 255
+        want = oracle.close3x3(img.copy())
+        xs0 = int(rng.integers(0, 25))
+        y_from = int(rng.integers(0, h // 2))
+        band = int(rng.choice([1, 3, 7, 16, 64]))
+        closed, first, last = ssd.closing_host(img, xs0, 25, y_from, band)
+        assert np.array_equal(closed, want), "case %d: word-wise closing differs (%dx%d)" % (case, w, h)
+        for j, x in enumerate(range(xs0, w, 25)):
+            rows = np.nonzero(want[y_from:, x])[0] + y_from
+            assert first[j] == (rows[0] if len(rows) else -1) and last[j] == (rows[-1] if len(rows) else -1), \
+                "case %d: column x = %d (%dx%d, rows from %d, bands of %d)" % (case, x, w, h, y_from, band)
