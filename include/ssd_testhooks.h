@@ -25,6 +25,9 @@ int ssd_test_sort_device(int device, const double *dist, int n, int32_t *perm);
 int ssd_test_quad_device(int device, const double quad[8], const double *pts_xy, int n, uint8_t *inside, int *err);
 /* the same code (csrc/ssd_quadtest.h: build_quad_test, the constant cell, quad_test) compiled for the host: runs without a GPU */
 int ssd_test_quad_host(const double quad[8], const double *pts_xy, int n, uint8_t *inside, int *err);
+/* test hook: BestLine (segmentation.cpp:409-487) over n points (x, y int32 pairs) with the kernels' residual code
+ * (csrc/ssd_bestline.h) compiled for the host; form 0 = any list, 1 = keys in passes of four (n <= 128), 2 = one pass (n <= 64) */
+int ssd_test_best_line_host(const int32_t *pts_xy, int n, int form, int32_t line[3]);
 /* test hook: the kernels' 3x3 closing on bit images (csrc/ssd_closing.h) compiled for the host: closed_out (width x height bytes,
  * may be null) = the closed image computed word by word; first / last [n_cols] = first and last closed row of the pixel columns
  * x0, x0 + x_step, .. by the column-wise form the scans use, over rows [y_from, height) cut into bands of band_rows rows */

@@ -140,7 +140,7 @@ SOURCE_EXPORTS = [
 ]
 # libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
 HOOK_EXPORTS = [
-    "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
+    "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_best_line_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
     "ssd_test_sort_device", "ssd_testhooks_last_error",
 ]
 SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
@@ -244,6 +244,8 @@ def hooks_lib():
     L.ssd_test_hypot_device.argtypes = [i32, vp, vp, vp, i32]
     L.ssd_test_closing_host.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32]
     L.ssd_test_closing_host.restype = i32
+    L.ssd_test_best_line_host.argtypes = [vp, i32, i32, vp]
+    L.ssd_test_best_line_host.restype = i32
     L.ssd_test_quad_host.argtypes = [vp, vp, i32, vp, vp]
     L.ssd_test_quad_host.restype = i32
     L.ssd_test_frame_state.argtypes = [vp, i32, vp, C.c_size_t, vp]
@@ -547,6 +549,14 @@ def closing_host(img, x0, x_step, y_from=0, band_rows=16, want_closed=True):
                                              closed.ctypes.data_as(C.c_void_p) if want_closed else None,
                                              first.ctypes.data_as(C.c_void_p), last.ctypes.data_as(C.c_void_p), n), "hooks")
     return closed, first[:n], last[:n]
+
+
+def best_line_host(pts, form):
+    """test hook: BestLine with the kernels' residual code compiled for the host -> (a, b, c)"""
+    p = np.ascontiguousarray(pts, dtype=np.int32).reshape(-1, 2)
+    out = np.zeros(3, dtype=np.int32)
+    _check(hooks_lib().ssd_test_best_line_host(p.ctypes.data_as(C.c_void_p), len(p), form, out.ctypes.data_as(C.c_void_p)), "hooks")
+    return tuple(int(v) for v in out)
 
 
 def quad_test_host(quad, pts):

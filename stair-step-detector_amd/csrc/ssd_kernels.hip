@@ -19,6 +19,7 @@
 #include "ssd_math.h"
 #include "ssd_quadtest.h"
 #include "ssd_closing.h"
+#include "ssd_bestline.h"
 #include "ssd_sort.h"
 
 namespace ssd
@@ -1018,122 +1019,14 @@ __global__ __launch_bounds__(kThreads, SSD_K2_WAVES) void k_raster(const float *
 /* ========================================================================= */
 /* BestLine (segmentation.cpp:409-487), one wave per point list                */
 
-/* residual of the line through points p and q: sum of the n smallest |a x + b y + c| of the other
- * points, over n * hypot(a, b) */
-__device__ double line_residual_generic(const int *px, const int *py, int m, int p, int q, LineI &line)
-{
-  line = line_through_i(px[p], py[p], px[q], py[q]);
-  if(m <= 2)
-    return 0.0;
-  const int nd = m - 2;
-  const int n = nd > 4 ? (nd - 1) / 2 : 1;
-  /* n rounds of "next smallest (distance, index)" — no per-lane storage */
-  int sum = 0;
-  int lastD = -1, lastI = -1;
-  for(int r = 0; r < n; r++)
-  {
-    int bestD = 0x7fffffff, bestI = 0x7fffffff;
-    for(int i = 0; i < m; i++)
-    {
-      if(i == p || i == q)
-        continue;
-      const int d = abs(px[i] * line.a + py[i] * line.b + line.c);
-      const bool after = d > lastD || (d == lastD && i > lastI);
-      const bool better = d < bestD || (d == bestD && i < bestI);
-      if(after && better) { bestD = d; bestI = i; }
-    }
-    sum += bestD;
-    lastD = bestD;
-    lastI = bestI;
-  }
-  return sum / (n * hypot_ref(static_cast<double>(line.a), static_cast<double>(line.b)));
-}
+/* (the residual of a pair's line, three forms: ssd_bestline.h — host + device code, the CPU suite runs its host build) */
 
-__device__ __forceinline__ unsigned int umed3(unsigned int a, unsigned int b, unsigned int c)
-{
-  return max(min(a, b), min(max(a, b), c));       /* v_med3_u32 */
-}
-
-/* The same sum for images with 3 W H < 2^25 and m <= 128 (every distance fits 25 bits: |a| <= H, |b| <= W,
- * |c| <= W H).  The two points of the pair lie on their line exactly (integer arithmetic), so the n smallest
- * distances of the others are the n + 2 smallest of all m, minus two zeros: no exclusion tests.  Distances
- * become distinct keys (d << 7 | i) + 1 and every pass over the points extracts the next FOUR smallest keys
- * with a min / med3 insertion network, in registers. */
-__device__ double line_residual_keys(const int *px, const int *py, int m, int p, int q, LineI &line)
-{
-  line = line_through_i(px[p], py[p], px[q], py[q]);
-  if(m <= 2)
-    return 0.0;
-  const int nd = m - 2;
-  const int n = nd > 4 ? (nd - 1) / 2 : 1;
-  int need = n + 2;
-  unsigned int sum = 0, last = 0;
-  while(need > 0)
-  {
-    unsigned int b1 = 0xffffffffu, b2 = 0xffffffffu, b3 = 0xffffffffu, b4 = 0xffffffffu;
-    for(int i = 0; i < m; i++)
-    {
-      const unsigned int d = static_cast<unsigned int>(abs(px[i] * line.a + py[i] * line.b + line.c));
-      unsigned int k = ((d << 7) | static_cast<unsigned int>(i)) + 1u;
-      k = k > last ? k : 0xffffffffu;
-      const unsigned int n4 = umed3(b3, b4, k), n3 = umed3(b2, b3, k), n2 = umed3(b1, b2, k);
-      b1 = min(b1, k); b2 = n2; b3 = n3; b4 = n4;
-    }
-    /* need <= number of keys above `last`, so the ones taken are real */
-    sum += (b1 - 1u) >> 7; last = b1;
-    if(need > 1) { sum += (b2 - 1u) >> 7; last = b2; }
-    if(need > 2) { sum += (b3 - 1u) >> 7; last = b3; }
-    if(need > 3) { sum += (b4 - 1u) >> 7; last = b4; }
-    need -= 4;
-  }
-  return static_cast<int>(sum) / (n * hypot_ref(static_cast<double>(line.a), static_cast<double>(line.b)));
-}
-
-/* The same sum for lists of at most 64 points held one per lane (myX, myY of lane i = point i), in ONE walk over the
- * points: the D >= n + 2 smallest distances are kept sorted in registers (insertion by a min / med3 network, D operations
- * per point), so nothing has to tell a later pass which ones were taken already — plain distances, equal ones included,
- * sum up to the same total whichever of them is counted.  The walk reads the points with v_readlane (a few cycles) instead
- * of LDS (a round trip per point in a lone wave); the products are 24-bit multiplies (|a| <= H, |b| <= W, coordinates
- * < 2^12: exact).  11 + D vector instructions per point against 15 per point and pass of four. */
-template<int D>
-__device__ __forceinline__ unsigned int smallest_sum_lanes(int myX, int myY, int m, const LineI &line, int need)
-{
-  unsigned int b[D];
-#pragma unroll
-  for(int j = 0; j < D; j++)
-    b[j] = 0xffffffffu;
-  for(int i = 0; i < m; i++)
-  {
-    const int x = __builtin_amdgcn_readlane(myX, i), y = __builtin_amdgcn_readlane(myY, i);
-    const unsigned int d = static_cast<unsigned int>(abs(__mul24(x, line.a) + __mul24(y, line.b) + line.c));
-#pragma unroll
-    for(int j = D - 1; j > 0; j--)
-      b[j] = umed3(b[j - 1], b[j], d);
-    b[0] = min(b[0], d);
-  }
-  unsigned int sum = 0;
-#pragma unroll
-  for(int j = 0; j < D; j++)
-    sum += j < need ? b[j] : 0u;
-  return sum;
-}
-
+/* line_residual_onepass for lists of at most 64 points held one per lane (myX, myY of lane i = point i): the walk over the
+ * points reads them with v_readlane (a few cycles) instead of LDS (a round trip per point in a lone wave) */
 __device__ __forceinline__ double line_residual_lanes(int myX, int myY, int m, int p, int q, LineI &line)
 {
   line = line_through_i(__shfl(myX, p), __shfl(myY, p), __shfl(myX, q), __shfl(myY, q));
-  if(m <= 2)
-    return 0.0;
-  const int nd = m - 2;
-  const int n = nd > 4 ? (nd - 1) / 2 : 1;
-  const int need = n + 2;                      /* <= 32 for m <= 64; the pair's own two points are the two zeros */
-  unsigned int sum;
-  if(need <= 4) sum = smallest_sum_lanes<4>(myX, myY, m, line, need);
-  else if(need <= 8) sum = smallest_sum_lanes<8>(myX, myY, m, line, need);
-  else if(need <= 12) sum = smallest_sum_lanes<12>(myX, myY, m, line, need);
-  else if(need <= 16) sum = smallest_sum_lanes<16>(myX, myY, m, line, need);
-  else if(need <= 24) sum = smallest_sum_lanes<24>(myX, myY, m, line, need);
-  else sum = smallest_sum_lanes<32>(myX, myY, m, line, need);
-  return static_cast<int>(sum) / (n * hypot_ref(static_cast<double>(line.a), static_cast<double>(line.b)));
+  return line_residual_onepass([&](int i, int &x, int &y) { x = __builtin_amdgcn_readlane(myX, i); y = __builtin_amdgcn_readlane(myY, i); }, m, line);
 }
 
 /* all 64 lanes of the calling wave take part, on the pairs tStart + lane, tStart + tStride + lane, ..: the best of them

@@ -65,7 +65,7 @@ struct LineD { double a, b, c; };
 struct LineI { int a, b, c; };
 
 /* LineCoordinates(p, q), types.h:140-158 */
-__device__ __forceinline__ LineI line_through_i(int x1, int y1, int x2, int y2)
+__host__ __device__ __forceinline__ LineI line_through_i(int x1, int y1, int x2, int y2)
 {
   return { y2 - y1, x1 - x2, x2 * y1 - x1 * y2 };
 }

@@ -7,6 +7,7 @@
 #include "ssd_math.h"
 #include "ssd_quadtest.h"
 #include "ssd_closing.h"
+#include "ssd_bestline.h"
 #include "ssd_sort.h"
 #include "../../include/ssd_testhooks.h"
 
@@ -252,6 +253,47 @@ int ssd_test_closing_host(const uint8_t *img, int width, int height, int x0, int
         last[j] = y;
       });
   }
+  return SSD_OK;
+}
+
+/* BestLine (segmentation.cpp:409-487) over a point list with the kernels' residual code compiled for the host
+ * (ssd_bestline.h): every pair in the reference's order, the first of the smallest residuals wins.
+ * form 0: line_residual_generic, 1: line_residual_keys (n <= 128), 2: line_residual_onepass (n <= 64) */
+int ssd_test_best_line_host(const int32_t *pts_xy, int n, int form, int32_t line[3])
+{
+  if(!pts_xy || !line || n < 2 || form < 0 || form > 2 || (form == 1 && n > 128) || (form == 2 && n > 64))
+    return fail(SSD_E_ARG, "ssd_test_best_line_host: bad argument");
+  std::vector<int> px(n), py(n);
+  for(int i = 0; i < n; i++)
+  {
+    px[i] = pts_xy[2 * i];
+    py[i] = pts_xy[2 * i + 1];
+  }
+  double bestRes = 0.0;
+  bool have = false;
+  ssd::LineI best{ 0, 0, 0 };
+  for(int p = 0; p < n; p++)
+    for(int q = p + 1; q < n; q++)
+    {
+      ssd::LineI l;
+      double r;
+      if(form == 0)
+        r = ssd::line_residual_generic(px.data(), py.data(), n, p, q, l);
+      else if(form == 1)
+        r = ssd::line_residual_keys(px.data(), py.data(), n, p, q, l);
+      else
+      {
+        l = ssd::line_through_i(px[p], py[p], px[q], py[q]);
+        r = ssd::line_residual_onepass([&](int i, int &x, int &y) { x = px[i]; y = py[i]; }, n, l);
+      }
+      if(!have || r < bestRes)
+      {
+        have = true;
+        bestRes = r;
+        best = l;
+      }
+    }
+  line[0] = best.a; line[1] = best.b; line[2] = best.c;
   return SSD_OK;
 }
 

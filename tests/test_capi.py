@@ -433,3 +433,35 @@ def test_host_build_of_the_kernels_closing_against_the_oracle(ssd, oracle):
             rows = np.nonzero(want[y_from:, x])[0] + y_from
             assert first[j] == (rows[0] if len(rows) else -1) and last[j] == (rows[-1] if len(rows) else -1), \
                 "case %d: column x = %d (%dx%d, rows from %d, bands of %d)" % (case, x, w, h, y_from, band)
+
+
+def test_host_build_of_the_kernels_best_line_against_the_oracle(ssd, oracle):
+    """csrc/ssd_bestline.h — the residual of a pair's line in the three forms k_outline / k_final use (any list; distinct keys
+    taken four per pass; ONE pass that keeps the n + 2 smallest distances sorted, equal distances included) — is host + device
+    code.  BestLine over its host build against the oracle's (itself checked against a brute-force statement in
+    test_oracle.py): scan-like lists of 2..64 points, outliers, collinear lists (every pair ties: the first must win), many
+    equal distances (rows of equal y), duplicated points' distances."""
+    rng = np.random.default_rng(20261)
+    checked = 0
+    for m in (2, 3, 4, 5, 6, 7, 8, 9, 11, 14, 21, 30, 42, 64):
+        for trial in range(6):
+            xs = 12 + 25 * np.arange(m)
+            if trial % 2:
+                xs = xs[::-1].copy()
+            ys = (300 + 0.07 * (xs - 500) + rng.integers(-3, 4, m)).astype(int)
+            if trial == 2:
+                ys[rng.integers(0, m)] += 40                      # an outlier scan
+            if trial == 3:
+                ys[:] = 300                                       # collinear
+            if trial == 4:
+                ys = 300 + (np.arange(m) % 2) * 2                 # two rows: distances repeat massively
+            if trial == 5:
+                ys = rng.integers(0, 768, m)                      # no line at all
+            pts = [(int(x), int(y)) for x, y in zip(xs, ys)]
+            rc, want = oracle.best_line(pts)
+            assert rc == 0
+            for form in (0, 1, 2):
+                got = ssd.best_line_host(pts, form)
+                assert got == tuple(int(v) for v in want), "m = %d, trial %d, form %d: %s vs %s" % (m, trial, form, got, tuple(want))
+                checked += 1
+    assert checked == 14 * 6 * 3
