@@ -1,7 +1,7 @@
 /*
  * ssd_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the per-frame point-cloud path.
  *
- * Pipeline over a batch of F frames resident in HBM (grid.y = frame everywhere):
+ * Pipeline over a batch of F frames resident in HBM (grid.x = frame everywhere: see the launch note on XCD balance):
  *   K1 k_hist      transform + crop + 1 cm height bin + histogram      (pointcloud.cpp:122-204)
  *   K1b k_peaks    peaks, filter, plateau pairs, bin->plateau LUT      (pointcloud.cpp:214-343, 399-418)
  *   K2 k_raster    top-down bit images of the step plateaus            (pointcloud.cpp:458-471)
@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(kThreads, SSD_K2_WAVES) void k_raster(const float *
 }
 
 /* ========================================================================= */
-/* BestLine (segmentation.cpp:409-487), one wave per point list                */
+/* BestLine (segmentation.cpp:409-487): a pair of points per lane, the waves dealt out over the lists */
 
 /* (the residual of a pair's line, three forms: ssd_bestline.h — host + device code, the CPU suite runs its host build) */
 
@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(T) void k_outline(Params P, FrameState *__restrict_
 
   if(S.found)
   {
-    /* ---- BestLine per horizontal edge: wave w takes edge w (HorizontalEdges::Edge :570-583), then the edge's
+    /* ---- BestLine per horizontal edge (HorizontalEdges::Edge :570-583): wave w works on edge w % 4; then the edge's
      *      BoundaryPoints (:521-552): the first and the last list point within 10 pixels of the line, by ballots ---- */
     static_assert((T / 64) % 4 == 0, "the waves are dealt out over the four edges");
     {
