@@ -13,7 +13,7 @@
  * All floating-point work is fp64 with contraction off (the file is compiled with
  * -ffp-contract=off): the reference is built without FMA (CMakeLists.txt:23-28) and one
  * flipped bin or pixel moves a corner by more than the parity bar.
- * K1/K2/K4 are HBM-read bound (12 B per raw point); no MFMA anywhere.
+ * K1 is HBM-read bound (12 B per raw point), K2 / K4 re-read a third of the points and are VALU-issue bound; no MFMA anywhere.
  */
 #include "ssd_device.h"
 #include "ssd_math.h"
