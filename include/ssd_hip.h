@@ -146,7 +146,7 @@ int ssd_fetch_back(ssd_handle *h, ssd_frame_result *results, int nframes, int ba
  * deals the submitted batches out round-robin; results come back in submission order.  At most `depth` batches are
  * unfetched at any time (ssd_pipeline_submit returns SSD_E_CAP otherwise); the frames of a submitted batch must stay
  * untouched until its results were fetched.  XGA, frames/s at depth 1 / 2 / 3 / 4: 64 frames per
- * batch 130 k / 207 k / 235 k / 199 k, 256: 191 k / 238 k / 250 k / 245 k, 1024: 246 k / 258 k / 262 k / 271 k. */
+ * batch 181 k / 235 k / 248 k / 232 k, 256: 230 k / 272 k / 282 k / 274 k, 1024: 257 k / 284 k / 304 k / 295 k. */
 typedef struct ssd_pipeline ssd_pipeline;
 int ssd_pipeline_create(const ssd_config *cfg, const ssd_calibration *cal, int device, int depth, ssd_pipeline **out);
 int ssd_pipeline_destroy(ssd_pipeline *p);
@@ -158,6 +158,12 @@ int ssd_pipeline_submit_after(ssd_pipeline *p, const void *d_xyz, size_t frame_s
 /* results of the OLDEST unfetched batch (waits for it); *nframes = its frame count; capacity = length of `results` */
 int ssd_pipeline_next(ssd_pipeline *p, ssd_frame_result *results, int capacity, int *nframes);
 int ssd_pipeline_pending(const ssd_pipeline *p);        /* batches submitted and not yet fetched */
+/* per-stage device times for the pipeline's batches (ssd_set_timing on every handle; events between the launches of a batch do
+ * not keep the batches of different handles from overlapping: measured, depth 3 at 1024 frames 302 k frames/s with, 297 k
+ * without).  ssd_pipeline_stage_times: the 7 stages (ssd_get_stage_times) of the batch ssd_pipeline_next returned last —
+ * valid until that batch's handle is given another one, i.e. call it right after ssd_pipeline_next */
+int ssd_pipeline_set_timing(ssd_pipeline *p, int enable);
+int ssd_pipeline_stage_times(ssd_pipeline *p, float ms[7]);
 const char *ssd_pipeline_last_error(void);
 
 /* ---- 16-bit depth input ---------------------------------------------

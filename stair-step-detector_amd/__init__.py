@@ -130,7 +130,7 @@ EXPORTS = [
     "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
     "ssd_device_count", "ssd_device_alloc", "ssd_device_free", "ssd_device_upload", "ssd_device_download",
     "ssd_device_sync", "ssd_host_alloc", "ssd_host_free",
-    "ssd_pipeline_create", "ssd_pipeline_destroy", "ssd_pipeline_submit", "ssd_pipeline_submit_after", "ssd_pipeline_next", "ssd_pipeline_pending",
+    "ssd_pipeline_create", "ssd_pipeline_destroy", "ssd_pipeline_submit", "ssd_pipeline_submit_after", "ssd_pipeline_next", "ssd_pipeline_pending", "ssd_pipeline_set_timing", "ssd_pipeline_stage_times",
     "ssd_pipeline_last_error",
 ]
 # libssd_source.so — the frame source standing in for the camera (include/ssd_source.h)
@@ -202,6 +202,8 @@ def lib():
     L.ssd_pipeline_submit_after.argtypes = [vp, vp, sz, i32, vp, i32]
     L.ssd_pipeline_next.argtypes = [vp, C.POINTER(FrameResult), i32, C.POINTER(i32)]
     L.ssd_pipeline_pending.argtypes = [vp]
+    L.ssd_pipeline_set_timing.argtypes = [vp, i32]
+    L.ssd_pipeline_stage_times.argtypes = [vp, vp]
     L.ssd_pipeline_last_error.restype = C.c_char_p
     _lib = L
     return L
@@ -479,6 +481,19 @@ class Pipeline:
     @property
     def results(self):
         return self._res
+
+    def set_timing(self, on=True):
+        rc = lib().ssd_pipeline_set_timing(self._p, 1 if on else 0)
+        if rc < 0:
+            raise SsdError("ssd_pipeline_set_timing: %d: %s" % (rc, lib().ssd_pipeline_last_error().decode()))
+
+    def stage_times_ms(self):
+        """Device time per stage of the batch next() returned last (call right after next())."""
+        ms = (C.c_float * 7)()
+        rc = lib().ssd_pipeline_stage_times(self._p, ms)
+        if rc < 0:
+            raise SsdError("ssd_pipeline_stage_times: %d: %s" % (rc, lib().ssd_pipeline_last_error().decode()))
+        return dict(zip(STAGE_NAMES, [float(v) for v in ms]))
 
     def close(self):
         if self._p:

@@ -21,6 +21,7 @@ struct ssd_pipeline
   std::vector<hipEvent_t> produced;       /* ssd_pipeline_submit_after: recorded on the producer's stream */
   std::vector<int> frames;                /* frames of the batch each handle holds, 0 = idle */
   unsigned long long submitted = 0, fetched = 0;
+  int lastFetched = -1;                   /* handle of the batch ssd_pipeline_next returned last */
 };
 
 namespace
@@ -145,7 +146,32 @@ int ssd_pipeline_next(ssd_pipeline *p, ssd_frame_result *results, int capacity, 
   *nframes = p->frames[k];
   p->frames[k] = 0;
   p->fetched++;
+  p->lastFetched = k;
   return SSD_OK;
+}
+
+int ssd_pipeline_set_timing(ssd_pipeline *p, int enable)
+{
+  if(!p)
+    return pfail(SSD_E_ARG, "ssd_pipeline_set_timing: null pipeline");
+  g_perr.clear();
+  for(ssd_handle *h : p->handles)
+  {
+    const int rc = ssd_set_timing(h, enable);
+    if(rc != SSD_OK)
+      return rc;
+  }
+  return SSD_OK;
+}
+
+int ssd_pipeline_stage_times(ssd_pipeline *p, float ms[7])
+{
+  if(!p || !ms)
+    return pfail(SSD_E_ARG, "ssd_pipeline_stage_times: null argument");
+  g_perr.clear();
+  if(p->lastFetched < 0 || p->frames[p->lastFetched] != 0)
+    return pfail(SSD_E_ARG, "ssd_pipeline_stage_times: no fetched batch whose handle has not been given the next one already");
+  return ssd_get_stage_times(p->handles[p->lastFetched], ms);
 }
 
 } // extern "C"
