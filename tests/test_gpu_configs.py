@@ -247,3 +247,37 @@ def test_pipeline_overlaps_batches_and_returns_them_in_order(ssd, oracle, gpu_de
     for i in range(0, len(flat), 7):
         parity.check_results_only(ssd, oracle, cfg, trans.constants, host[i], flat[i])
     buf.free()
+
+
+def test_pipeline_stage_times_belong_to_the_batch_fetched_last(ssd, gpu_device):
+    """ssd_pipeline_set_timing / ssd_pipeline_stage_times: seven positive stage times for the batch ssd_pipeline_next returned
+    last; refused before anything was fetched and once that batch's handle has been given the next one; results unchanged by
+    the events."""
+    W, H = 640, 480
+    sc_list = scenes.batch_scenes(ssd, W, H, 6, base_seed=62000, rng_seed=12)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    cfg = ssd.default_config(W, H, max_frames_per_batch=6)
+    buf = ssd.DeviceBuffer(W * H * 12 * 6, gpu_device)
+    ssd.synth_device(sc_list, buf.ptr, device=gpu_device)
+    plain = ssd.Pipeline(cfg, trans, gpu_device, depth=2)
+    plain.submit(buf.ptr, 6)
+    want = plain.next()
+    plain.close()
+    pipe = ssd.Pipeline(cfg, trans, gpu_device, depth=2)
+    pipe.set_timing(True)
+    with pytest.raises(ssd.SsdError, match="no fetched batch"):
+        pipe.stage_times_ms()
+    pipe.submit(buf.ptr, 6)
+    pipe.submit(buf.ptr, 3)
+    got = pipe.next()
+    st = pipe.stage_times_ms()
+    assert list(st) == list(ssd.STAGE_NAMES) and all(v > 0.0 for v in st.values()), st
+    assert [bytes(r) for r in got] == [bytes(r) for r in want]
+    pipe.submit(buf.ptr, 2)                                          # goes to the handle whose batch was fetched last
+    with pytest.raises(ssd.SsdError, match="no fetched batch"):
+        pipe.stage_times_ms()
+    while pipe.pending():
+        pipe.next()
+    assert all(v > 0.0 for v in pipe.stage_times_ms().values())
+    pipe.close()
+    buf.free()
