@@ -669,10 +669,6 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
  * on where the window is; when more lanes missed than hit during a tile the wave flushes and re-anchors at
  * the lowest missing (image, row).  Everything is decided with ballots and shuffles inside the wave. */
 constexpr int kWinWords = 256;      /* 2 KiB per wave; shaped (256 >> winShift) rows x (1 << winShift) word columns, see PixelParams::winShift */
-/* In LDS a window row is one word longer than it is wide (row r, word c at r * ((1 << winShift) + 1) + c): with rows of 8 or 16
- * dwords the pixels of a cell — two or three word columns, five or six rows — fell on the same few banks (rows r and r + 4,
- * r + 2 alike; LDSBankConflict 12 % of k_raster's time); 10 / 18 dwords spread sixteen consecutive rows over all banks. */
-constexpr int kWinStore = kWinWords + 128;     /* winShift >= 1: at most 128 rows */
 
 struct ImageBox { int yMin, yMax, xMin, xMax; };
 
@@ -732,13 +728,12 @@ __device__ __forceinline__ void wavewin_flush(unsigned long long *ww, const Wave
   for(int k = 0; k < kWinWords / 64; k++)
   {
     const int i = k * 64 + lane;
-    const int at = i + (i >> winShift);                            /* the padded row stride */
-    const unsigned long long v = ww[at];
+    const unsigned long long v = ww[i];
     if(v)
     {
       const int y = w.row0 + (i >> winShift), x = w.col0 + (i & ((1 << winShift) - 1));
       atomicOr(img + static_cast<size_t>(y) * W64 + x, v);
-      ww[at] = 0ull;
+      ww[i] = 0ull;
       y0 = min(y0, y); y1 = max(y1, y);
       x0 = min(x0, x); x1 = max(x1, x);
     }
@@ -821,7 +816,7 @@ __device__ __forceinline__ void wavewin_emit(unsigned long long *ww, unsigned in
     const unsigned int k = key[j], d = k - base;
     const unsigned int bit = 1u << (k & 31u);
     if(window_hit(d, winShift))
-      atomicOr(&ww32[(d >> 13) * ((2u << winShift) + 2u) + ((d & 0x1fffu) >> 5)], bit);
+      atomicOr(&ww32[((d >> 13) << (winShift + 1)) + ((d & 0x1fffu) >> 5)], bit);
     else if(k != kNoPixel)
     {
       const unsigned int slot = k >> 26, iy = (k >> 13) & 0x1fffu, ix = k & 0x1fffu, xw = ix >> 6;
@@ -859,7 +854,7 @@ constexpr long long kMagicBits = 0x40B8000000000000ll;       /* bits of 6144.0 *
 
 struct RasterLds
 {
-  unsigned long long wins[kThreads / 64][kWinStore];
+  unsigned long long wins[kThreads / 64][kWinWords];
   unsigned int wmiss[kThreads / 64][kWaveMissWords];
   ImageBox boxes[kMaxStepImages];
   unsigned char lut[kMaxBins];
@@ -876,7 +871,7 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
                                              const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, const DepthSrc &D,
                                              const int frame, const int chunkIdx)
 {
-  unsigned long long (&wins)[kThreads / 64][kWinStore] = L.wins;
+  unsigned long long (&wins)[kThreads / 64][kWinWords] = L.wins;
   unsigned int (&wmiss)[kThreads / 64][kWaveMissWords] = L.wmiss;
   ImageBox (&boxes)[kMaxStepImages] = L.boxes;
   unsigned char (&lut)[kMaxBins] = L.lut;
@@ -903,7 +898,7 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
     (&ltot[0][0])[tid] = 0ull;
   if(tid == 0)
     lOob = 0;
-  for(int i = tid; i < (kThreads / 64) * kWinStore; i += kThreads)
+  for(int i = tid; i < (kThreads / 64) * kWinWords; i += kThreads)
     (&wins[0][0])[i] = 0ull;
   if(tid < kThreads / 64)
     wavemiss_init(wmiss[tid]);
@@ -1804,7 +1799,7 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
 
 struct InquadLds
 {
-  unsigned long long wins[kThreads / 64][kWinStore];
+  unsigned long long wins[kThreads / 64][kWinWords];
   unsigned int wmiss[kThreads / 64][kWaveMissWords];
   ImageBox box[1];
   QuadTest qts[kMaxLive];                       /* FrameState::qtLive: slot k = accumulator liveAcc[k] */
@@ -1828,7 +1823,7 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
                                              const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, const DepthSrc &D,
                                              const int frame, const int chunkIdx)
 {
-  unsigned long long (&wins)[kThreads / 64][kWinStore] = L.wins;
+  unsigned long long (&wins)[kThreads / 64][kWinWords] = L.wins;
   unsigned int (&wmiss)[kThreads / 64][kWaveMissWords] = L.wmiss;
   ImageBox (&box)[1] = L.box;
   QuadTest (&qts)[kMaxLive] = L.qts;
@@ -1873,7 +1868,7 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
     (&lsum[0][0])[i] = 0ull;
     (&lcnt[0][0])[i] = 0u;
   }
-  for(int i = tid; i < (kThreads / 64) * kWinStore; i += kThreads)
+  for(int i = tid; i < (kThreads / 64) * kWinWords; i += kThreads)
     (&wins[0][0])[i] = 0ull;
   if(tid < kThreads / 64)
     wavemiss_init(wmiss[tid]);
