@@ -11,6 +11,12 @@ pass of the whole path (K1 hist .. K5 final + results to the host) over the batc
 its own F frames on its own GPU (frames are independent: no collective on the data path; weak scaling) and
 value = N * F * K / max-over-ranks time.
 
+The timed steps go through the plain handle API (ssd_enqueue / ssd_fetch_back) of a handle that keeps
+ssd_config::batches_in_flight = 3 batches in flight on its own streams (the default from 128 frames per batch on): the
+steps overlap, so an event-bracketed stage inside them is no kernel duration.  `stage_ms` and `roofline` therefore come
+from a few EXTRA steps after the timed region, run one at a time with HIP events between the launches
+("stage_ms_source": "separate timed steps"), next to a plain read stream over the same buffer (`k1_over_plain_stream`).
+
 PyTorch is plumbing here: device memory, the stream, the barrier and the max-reduce (torch.distributed over
 `gloo` on CPU tensors: the data path has no exchange step, so RCCL is never loaded).  The hot path is
 libssd_hip.so through its C ABI.  The CPU oracle is used only for the cpu_baseline leg and the parity
@@ -211,7 +217,7 @@ def main():
     frames = torch.empty(F * frame_bytes, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     det = ssd.Detector(cfg, trans, device)
-    det.set_timing(True)
+    depth = det.batches_in_flight
     if args.risers:
         det.set_risers(True, tolerance=0.03, min_support=200)
     intr = ssd.intrinsics_for_scene(sc_list[0])
@@ -227,15 +233,20 @@ def main():
         else:
             det.enqueue(frames.data_ptr(), F, stream=stream)
 
+    ahead = max(depth, 2) - 1            # enqueues kept ahead of the fetches (the handle's result slots: max(2, depth))
+
     def run(n_steps):
-        """n_steps passes over the batch, every pass's results fetched to the host: pass i+1 is enqueued before the
-        results of pass i are read (they travel with their own enqueue), so the GPU never waits for the host."""
+        """n_steps passes over the batch, every pass's results fetched to the host: pass i + `ahead` is enqueued before the
+        results of pass i are read (they travel with their own enqueue), so the GPU never waits for the host and the handle
+        has its `depth` batches in flight."""
         res = None
         for i in range(n_steps):
             enqueue()
-            if i > 0:
-                res = det.fetch(F, back=1)
-        return det.fetch(F) if n_steps > 0 else res
+            if i >= ahead:
+                res = det.fetch(F, back=ahead)
+        for back in range(min(ahead, n_steps) - 1, -1, -1):
+            res = det.fetch(F, back=back)
+        return res
 
     res = run(args.warmup)
 
@@ -250,17 +261,36 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
-    # per-stage device times of the timed steps (HIP events recorded on the kernels' stream)
-    n_timed = min(args.steps, 63)
+    # Per-stage device times: EXTRA steps after the timed region, one at a time (enqueue, fetch, then the next), HIP events
+    # recorded between the launches on the stream the kernels run on.  The timed steps above overlap (depth batches in
+    # flight), where an event-bracketed stage is a kernel's share of a machine it splits with the other batches' kernels.
+    # A plain read stream over the same buffer is timed before and after (what the memory system delivers right now).
+    n_extra = 6
+    det.set_timing(True)
+    stream_ms = [ssd.stream_read_ms(frames.data_ptr(), F * frame_bytes, reps=5, device=device)] if not depth_in else []
     stage = {k: 0.0 for k in ssd.STAGE_NAMES}
-    for b in range(n_timed):
-        for k, v in det.stage_times_ms(b).items():
-            stage[k] += v / n_timed
+    c0 = time.perf_counter()
+    for b in range(n_extra + 1):
+        enqueue()
+        det.fetch(F)
+        if b > 0:                                        # the first one warms the events up
+            for k, v in det.stage_times_ms().items():
+                stage[k] += v / n_extra
+        else:
+            c0 = time.perf_counter()
+    one_at_a_time_ms = (time.perf_counter() - c0) / n_extra * 1e3
+    if not depth_in:
+        stream_ms.append(ssd.stream_read_ms(frames.data_ptr(), F * frame_bytes, reps=5, device=device))
+    det.set_timing(False)
 
     dt_max = ranks.max(dt)
     # which frames of the global index space each rank processed, and on which device (rank 0 reports it); with more
     # than one rank every rank also checks a few frames of ITS shard against the CPU oracle (outside the timed region)
-    mine = {"rank": rank, "device": device, "frames": [lo, hi], "seconds": dt, "steps_found": int(sum(r.n_steps for r in res))}
+    k1_ms = stage["hist"]
+    alg_bytes = (2.0 if depth_in else 12.0) * W * H * F    # 12 B per raw point (2 B per depth pixel), read once
+    mine = {"rank": rank, "device": device, "frames": [lo, hi], "seconds": dt, "steps_found": int(sum(r.n_steps for r in res)),
+            "stage_ms": stage, "k1_frac_of_hbm_peak": (alg_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k1_ms > 0 else 0.0,
+            "one_batch_at_a_time_ms": one_at_a_time_ms}
     if world > 1 and not args.no_cpu:
         import oracle_binding as ob
         import parity
@@ -276,9 +306,8 @@ def main():
 
     if rank == 0:
         value = world * F * args.steps / dt_max
-        k1_ms = stage["hist"]
-        alg_bytes = (2.0 if depth_in else 12.0) * W * H * F    # 12 B per raw point (2 B per depth pixel), read once
         achieved = alg_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        plain_ms = sum(stream_ms) / len(stream_ms) if stream_ms else None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_k_hist.json")
         if os.path.exists(pmc):
@@ -311,13 +340,22 @@ def main():
                                      "BASELINE configs[2]: ") +
                                     "batch of %d synthetic %dx%d frames (3-step staircases, randomised rise/"
                                     "tread/yaw/noise) resident in HBM, streamed through the whole per-frame path; per GPU") % (F, W, H),
-                       "frames_per_gpu_per_step": F, "width": W, "height": H, "input": args.input, "risers": bool(args.risers), "parallelism": "frame-sharded x%d, no collective" % world},
+                       "frames_per_gpu_per_step": F, "width": W, "height": H, "input": args.input, "risers": bool(args.risers),
+                       "batches_in_flight": depth, "parallelism": "frame-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "kernel": "k_hist (K1: transform+crop+bin+histogram)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": None if traffic is None else "profiles/pmc_k_hist.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                            "of this command, committed; not re-measured in this run)",
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,
+                         "plain_stream_GBps": None if plain_ms is None else alg_bytes / (plain_ms * 1e-3) / 1e9,
+                         "k1_over_plain_stream": None if plain_ms is None or k1_ms <= 0 else plain_ms / k1_ms,
+                         "plain_stream_note": "ssd_test_stream_read (tools/loadbench.hip variant C: 16-byte loads, wave-contiguous) over the "
+                                              "same buffer, 5 launches before and 5 after the separate timed steps"},
             "stage_ms": stage,
+            "stage_ms_source": "separate timed steps: %d extra passes after the timed region, one batch at a time (enqueue, fetch), HIP events "
+                               "between the launches on the kernels' stream; the timed region itself keeps %d batches in flight" % (n_extra, depth),
+            "one_batch_at_a_time": {"ms_per_step": one_at_a_time_ms, "frames_per_s": F / one_at_a_time_ms * 1e3,
+                                    "note": "the same handle fed one batch at a time (no overlap; with the stage events)"},
             "pipeline_bytes_moved": pipeline_moved,
             "pipeline_bytes_algorithmic_frac_of_peak": (alg_bytes * args.steps / dt_max / 1e9) / HBM_PEAK_GBS,
         }
@@ -387,16 +425,15 @@ def main():
                         st1[k] += v / 16
             one.close()
             out["single_frame"] = {"latency_ms_device_resident": sorted(lat)[len(lat) // 2] * 1e3, "stage_ms": st1,
-                                   "note": "one %dx%d frame already in HBM, ssd_enqueue + ssd_fetch (state memset + 7 dependent launches, the last "
+                                   "note": "one %dx%d frame already in HBM, ssd_enqueue + ssd_fetch (7 dependent launches, the last "
                                            "one storing the result into pinned host memory); median of 48 calls without timing events; stage_ms "
                                            "from 16 further calls with events between the launches; bounded by the GPU-side latency of the "
                                            "kernels' short phases (DESIGN.md section 3), not by HBM" % (W, H)}
         if world == 1 and not depth_in and not args.no_latency:
-            # Two handles (each with its own workspace) on two streams, fed alternately, no timing events: the launches of one
-            # batch fill the gaps the other's small, latency-bound kernels leave.  Reported beside `value`, which stays the
-            # single-handle rate the roofline's live per-kernel durations belong to (timing events keep launches from overlapping).
-            out["pipelined"] = {"note": "same batch, same K steps through ssd_pipeline_* (depth handles on depth HIP streams fed "
-                                         "round-robin, per-stage timing events off; INTEGRATION.md section 4)", "unit": "frames/s"}
+            # The same overlap across handles (ssd_pipeline_*: depth handles with one workspace each on depth streams, fed
+            # round-robin), as a cross-check of what `value` — one handle with its own workspaces — delivers.
+            out["pipelined"] = {"note": "same batch, same K steps through ssd_pipeline_* (depth single-workspace handles on depth HIP "
+                                         "streams fed round-robin, per-stage timing events off; INTEGRATION.md section 4)", "unit": "frames/s"}
             for depth in (2, 3, 4):
                 pipe = ssd.Pipeline(cfg, trans, device, depth=depth)
                 torch.cuda.synchronize()

@@ -22,11 +22,13 @@
  * Plain pointers and sizes only; no C++ or torch types.  All functions return
  * 0 on success or a negative SSD_E_* code; nothing throws across the boundary.
  * A handle is bound to one device and is not thread-safe (one host thread per GPU).
- * Streams: a handle's workspace is single-buffered, so its calls execute in the order they were made.  Use one stream
- * per handle; if a call names another stream than the previous one (ssd_process_*_host use the default stream), the
- * library orders it behind the previous call with an event — correct, but the two do not overlap.
+ * Streams: see ssd_config::batches_in_flight.  With one workspace a handle's calls execute on the caller's stream in the
+ * order they were made; if a call names another stream than the previous one, the library orders it behind the previous
+ * call with an event — correct, but the two do not overlap.  With several workspaces the batches run on streams of the
+ * handle's own.  ssd_process_host / ssd_process_depth_host always use two non-blocking streams of the handle's own (copy and
+ * compute) and return when the results are on the host; they do not synchronise with the legacy default stream.
  * Configuration limits: max(|z_min|, |z_max|) < 2048 m and max|z| * width * height < 2^23 (the mean height of a step
- * is accumulated in 2^-40 m fixed point), 3..SSD_MAX_BINS histogram bins, width and height <= 8192.
+ * is accumulated in 2^-40 m fixed point), 3..SSD_MAX_BINS histogram bins, width <= 8192, height <= 8064.
  */
 #ifndef SSD_HIP_H_
 #define SSD_HIP_H_
@@ -68,8 +70,17 @@ typedef struct
   double height_interval;                            /* 0.01 */
   double min_height_above_ground;                    /* 0.05 */
   double min_step_depth;                             /* 0.1 */
-  int32_t max_frames_per_batch;                      /* workspace is sized for this many frames in flight */
+  int32_t max_frames_per_batch;                      /* a workspace is sized for this many frames per call */
   int32_t max_step_plateaus;                         /* <= SSD_MAX_STEP_IMAGES */
+  /* Workspaces of the handle = batches it keeps in flight (1..4; 0 = automatic: 3 when max_frames_per_batch >= 128, else 1).
+   * 1: every call runs on the caller's stream, strictly in stream order (lowest latency; single frames).
+   * > 1: successive ssd_enqueue calls take the workspaces in turn, each on a stream of the handle's own, so that the
+   *      launches of one batch fill the gaps the one-block-per-frame kernels of the others leave (1024 XGA frames per call:
+   *      +10 %).  Memory = batches_in_flight x 1.75 MB per XGA frame of max_frames_per_batch (1024 frames, 3 in flight: 5.4 GB
+   *      beside 9.7 GB of frames).  Stream contract then: a batch starts behind the work `stream` holds at the time of the
+   *      call, but work put on `stream` afterwards is NOT ordered behind the batch — its frames must stay untouched until
+   *      its results were fetched, or until a stream was made to wait for it with ssd_stream_wait. */
+  int32_t batches_in_flight;
 } ssd_config;
 
 /* the constants of GeometricTransformation (transformation.h:102-126) */
@@ -134,10 +145,17 @@ size_t ssd_workspace_bytes(const ssd_handle *h);
 int ssd_process_host(ssd_handle *h, const float *xyz, int nframes, ssd_frame_result *results);
 int ssd_enqueue(ssd_handle *h, const void *d_xyz, size_t frame_stride_bytes, int nframes, void *stream);
 int ssd_fetch(ssd_handle *h, ssd_frame_result *results, int nframes, void *stream);
-/* The results of a batch travel to the host as part of its ssd_enqueue (two slots, used alternately), so a caller may
- * keep the GPU busy: ssd_enqueue(batch i+1) first, then ssd_fetch_back(.., back = 1) for batch i.  back = 0 is
- * ssd_fetch.  Waits only for that batch. */
+/* The results of a batch travel to the host as part of its ssd_enqueue (max(2, batches_in_flight) slots, used in turn), so
+ * a caller may keep the GPU busy: ssd_enqueue(batch i+1) first, then ssd_fetch_back(.., back = 1) for batch i — with 3
+ * batches in flight: two enqueues ahead, back = 2.  back = 0 is ssd_fetch.  Waits only for that batch.  A slot is reused by
+ * the enqueue max(2, batches_in_flight) calls later: fetch before that. */
 int ssd_fetch_back(ssd_handle *h, ssd_frame_result *results, int nframes, int back);
+/* makes `stream` (a hipStream_t, NULL = default stream) wait for the batch `back` enqueues ago, without blocking the host:
+ * what a producer that overwrites the batch's frames, or a consumer of device-side state, needs when the handle keeps
+ * several batches in flight (with one workspace the caller's stream is already ordered) */
+int ssd_stream_wait(ssd_handle *h, int back, void *stream);
+/* the number of workspaces the handle was created with (ssd_config::batches_in_flight resolved) */
+int ssd_batches_in_flight(const ssd_handle *h);
 
 /* ---- batches overlapped across handles ------------------------------------------------------------------------
  * One handle runs a batch as a chain of dependent launches; its small kernels (one block per frame or image) leave the
@@ -215,7 +233,9 @@ typedef struct
 /* enable != 0: every later ssd_enqueue / ssd_process_* also gathers riser evidence (one more pass over the points
  * of the bins between the surfaces).  tolerance in (0, 1] metres, min_support >= 1. */
 int ssd_set_risers(ssd_handle *h, int enable, double tolerance, int min_support);
-/* risers of the last enqueue (after ssd_fetch, or instead of it: synchronises `stream`) */
+/* risers of the last enqueue (after ssd_fetch, or instead of it: synchronises `stream`), or of the whole batch of the last
+ * ssd_process_host / ssd_process_depth_host call (collected slice by slice); nframes <= what that call processed.  While
+ * risers are on, a handle with several workspaces runs its batches one after the other (the riser buffer is single). */
 int ssd_fetch_risers(ssd_handle *h, ssd_frame_risers *out, int nframes, void *stream);
 /* stage selector for profiling / roofline measurement: runs only the chosen stage(s) of the pipeline */
 #define SSD_STAGE_HIST 1       /* K1: transform + crop + bin + histogram */

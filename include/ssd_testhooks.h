@@ -43,6 +43,10 @@ int ssd_test_grid_boxes_device(int device, const double quad[8], double x_min, d
  * number of bytes copied or a negative error */
 long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, long long layout[8]);
 
+/* measurement hook (bench.py, tools/clockstate.py): average milliseconds of `reps` launches of a plain 16-byte-per-lane read
+ * stream over `bytes` bytes at d_ptr (tools/loadbench.hip variant C) on `stream` — what the memory system delivers right now */
+int ssd_test_stream_read(int device, const void *d_ptr, size_t bytes, int reps, void *stream, float *ms_avg);
+
 const char *ssd_testhooks_last_error(void);
 
 #ifdef __cplusplus

@@ -1,9 +1,10 @@
 /*
- * ref_wrap.cpp — C entry points around the two reference translation units that
- * compile from their own sources with no third-party dependency:
+ * ref_wrap.cpp — C entry points around the reference pieces that compile from their own sources with no
+ * third-party dependency:
  *   /root/reference/stairs.cpp            (Stairs::serialize, stairs.cpp:55-70)
  *   /root/reference/quadrilateralTest.cpp (QuadrilateralTest, quadrilateralTest.cpp:275-451)
  *   /root/reference/calibrationTriangle.cpp (CalibrationTriangle::load / isValid, calibrationTriangle.cpp:97-172)
+ *   /root/reference/configuration.h       (struct Configuration: the compile-time constants, configuration.h:27-52)
  * The reference sources are compiled where they lie (see Makefile target `ref`);
  * nothing of them is copied into this repository.  Output: oracle/_ref/libssd_ref.so.
  * TEST INFRASTRUCTURE ONLY: used to pin oracle/ssd_oracle.cpp's restatement of
@@ -12,6 +13,7 @@
 #include "stairs.h"
 #include "quadrilateralTest.h"
 #include "calibrationTriangle.h"
+#include "configuration.h"
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -83,4 +85,16 @@ extern "C" int ssdref_load_triangle(const char *dir, double world[9], int *side)
   }
   *side = t.getLowerQuadrant() == stairs::CalibrationTriangle::Side::left ? 1 : (t.getLowerQuadrant() == stairs::CalibrationTriangle::Side::right ? 2 : 0);
   return valid ? 0 : 2;
+}
+
+/* the reference's compile-time Configuration (configuration.h:27-52), default-constructed:
+ * out = x.min, x.max, y.min, y.max, z.min, z.max, heightInterval, minHeightAboveGround, minStepDepth; wh = depth stream width, height */
+extern "C" void ssdref_configuration(double out[9], int wh[2])
+{
+  const stairs::Configuration c;
+  out[0] = c.measuringRange.x.min; out[1] = c.measuringRange.x.max;
+  out[2] = c.measuringRange.y.min; out[3] = c.measuringRange.y.max;
+  out[4] = c.measuringRange.z.min; out[5] = c.measuringRange.z.max;
+  out[6] = c.heightInterval; out[7] = c.minHeightAboveGround; out[8] = c.minStepDepth;
+  wh[0] = c.streams.depth.width; wh[1] = c.streams.depth.height;
 }

@@ -46,7 +46,8 @@ class Config(C.Structure):
                 ("x_min", C.c_double), ("x_max", C.c_double), ("y_min", C.c_double), ("y_max", C.c_double),
                 ("z_min", C.c_double), ("z_max", C.c_double),
                 ("height_interval", C.c_double), ("min_height_above_ground", C.c_double), ("min_step_depth", C.c_double),
-                ("max_frames_per_batch", C.c_int32), ("max_step_plateaus", C.c_int32)]
+                ("max_frames_per_batch", C.c_int32), ("max_step_plateaus", C.c_int32),
+                ("batches_in_flight", C.c_int32)]
 
 
 class Calibration(C.Structure):
@@ -126,7 +127,7 @@ EXPORTS = [
     "ssd_create", "ssd_destroy", "ssd_last_error", "ssd_workspace_bytes",
     "ssd_process_host", "ssd_enqueue", "ssd_fetch", "ssd_enqueue_stages",
     "ssd_set_intrinsics", "ssd_process_depth_host", "ssd_enqueue_depth", "ssd_deproject_host",
-    "ssd_fetch_back", "ssd_set_risers", "ssd_fetch_risers", "ssd_set_timing", "ssd_get_stage_times", "ssd_get_stage_times_back", "ssd_serialize",
+    "ssd_fetch_back", "ssd_stream_wait", "ssd_batches_in_flight", "ssd_set_risers", "ssd_fetch_risers", "ssd_set_timing", "ssd_get_stage_times", "ssd_get_stage_times_back", "ssd_serialize",
     "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
     "ssd_device_count", "ssd_device_alloc", "ssd_device_free", "ssd_device_upload", "ssd_device_download",
     "ssd_device_sync", "ssd_host_alloc", "ssd_host_free",
@@ -141,7 +142,7 @@ SOURCE_EXPORTS = [
 # libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
 HOOK_EXPORTS = [
     "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_best_line_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
-    "ssd_test_sort_device", "ssd_testhooks_last_error",
+    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_testhooks_last_error",
 ]
 SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
 HOOKS_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_testhooks.so")
@@ -181,6 +182,8 @@ def lib():
     L.ssd_deproject_host.argtypes = [C.POINTER(Intrinsics), i32, i32, vp, vp]
     L.ssd_set_timing.argtypes = [vp, i32]
     L.ssd_fetch_back.argtypes = [vp, C.POINTER(FrameResult), i32, i32]
+    L.ssd_stream_wait.argtypes = [vp, i32, vp]
+    L.ssd_batches_in_flight.argtypes = [vp]
     L.ssd_set_risers.argtypes = [vp, i32, C.c_double, i32]
     L.ssd_fetch_risers.argtypes = [vp, C.POINTER(FrameRisers), i32, vp]
     L.ssd_get_stage_times.argtypes = [vp, C.POINTER(C.c_float)]
@@ -256,6 +259,7 @@ def hooks_lib():
     L.ssd_test_sort_device.argtypes = [i32, vp, i32, vp]
     L.ssd_test_quad_device.argtypes = [i32, vp, vp, i32, vp, C.POINTER(C.c_int)]
     L.ssd_test_grid_boxes_device.argtypes = [i32, vp, C.c_double, C.c_double, C.c_double, C.c_double, vp, i32, vp, C.POINTER(C.c_int)]
+    L.ssd_test_stream_read.argtypes = [i32, vp, C.c_size_t, i32, vp, C.POINTER(C.c_float)]
     _hooks_lib = L
     return L
 
@@ -272,11 +276,13 @@ def device_count():
     return lib().ssd_device_count()
 
 
-def default_config(width, height, max_frames_per_batch=64, max_step_plateaus=MAX_STEP_IMAGES):
+def default_config(width, height, max_frames_per_batch=64, max_step_plateaus=MAX_STEP_IMAGES, batches_in_flight=0):
+    """batches_in_flight: workspaces of the handle (ssd_config); 0 = automatic (3 from 128 frames per batch on, else 1)"""
     cfg = Config()
     _check(lib().ssd_default_config(C.byref(cfg), width, height))
     cfg.max_frames_per_batch = max_frames_per_batch
     cfg.max_step_plateaus = max_step_plateaus
+    cfg.batches_in_flight = batches_in_flight
     return cfg
 
 
@@ -358,6 +364,15 @@ class Detector:
     @property
     def workspace_bytes(self):
         return lib().ssd_workspace_bytes(self._h)
+
+    @property
+    def batches_in_flight(self):
+        """workspaces of the handle = batches it keeps in flight (ssd_config::batches_in_flight resolved)"""
+        return lib().ssd_batches_in_flight(self._h)
+
+    def stream_wait(self, back=0, stream=None):
+        """makes `stream` wait for the batch `back` enqueues ago (ssd_stream_wait)"""
+        _check(lib().ssd_stream_wait(self._h, back, C.c_void_p(stream or 0)))
 
     def process_host(self, xyz):
         """xyz: float32 array [n, H, W, 3] (or [H, W, 3]) on the host -> list of FrameResult."""
@@ -529,6 +544,13 @@ class Pointcloud:
 
 
 # --------------------------------------------------------------------------- synthetic frame source
+def stream_read_ms(d_ptr, nbytes, reps=5, device=0, stream=None):
+    """Average milliseconds of a plain read stream over nbytes at d_ptr (measurement hook, libssd_testhooks.so)."""
+    ms = C.c_float(0.0)
+    _check(hooks_lib().ssd_test_stream_read(device, C.c_void_p(d_ptr), nbytes, reps, C.c_void_p(stream), C.byref(ms)), "hooks")
+    return float(ms.value)
+
+
 def sort_perm(dist, device=None):
     """test hook: libstdc++'s std::sort restated (csrc/ssd_sort.h), on the host (device=None) or on a GPU"""
     d = np.ascontiguousarray(dist, dtype=np.float64)

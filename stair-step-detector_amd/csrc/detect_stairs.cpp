@@ -6,10 +6,14 @@
  *
  *   detect-stairs-amd [--width W] [--height H] [--frames N] [--steps K] [--seed S] [--file frames.f32]
  *                     [--calibration files]   (GeometricCalibration::load() from the working directory, as detect-stairs.cpp:30)
- *                     [--devices D | --device-list 0,1,..]   frame-sharded over D GPUs of this node:
- *                         one host thread + one handle per device, contiguous frame ranges, frames generated and kept in
- *                         HBM, processed as one batch per device through the C ABI; nothing is exchanged between devices.
- *                         Lines come out in frame order; frames/s on stderr.  A device may be listed more than once.
+ *                     [--devices D | --device-list 0,1,..] [--passes P]   frame-sharded over D GPUs of this node (SURVEY.md
+ *                         section 8(e); BASELINE configs[3] is --devices 8 --frames 16384): one host thread + one handle per
+ *                         device, contiguous frame ranges, every shard generated into HBM and kept there (2,048 XGA frames =
+ *                         19.3 GB), then — all devices from one start line, generation outside the timed region — P passes
+ *                         (default 1) over the resident frames in batches of up to 2,048 through the C ABI; nothing is exchanged
+ *                         between devices.  Lines (last pass) come out in frame order; per-device and total frames/s on stderr.
+ *                         A device may be listed more than once.  A frame the reference would throw on ends the output there
+ *                         with exit code 1, as the reference process ends.
  */
 #include "../../include/stairs/stairs_api.h"
 #include "../../include/ssd_source.h"
@@ -18,7 +22,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <condition_variable>
 #include <iostream>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -31,43 +37,115 @@ static ssd_scene makeScene(int W, int H, int K, uint64_t seed)
   return s;
 }
 
-/* frames [lo, hi) of the synthetic sequence on one device: generated in HBM, one batch per kBatch frames */
-static void runShard(int device, const ssd_calibration &cal, int W, int H, int K, uint64_t seed, int lo, int hi,
-                     std::vector<std::string> &lines, std::string &error)
+/* all shard threads meet here: the timed region starts when every device holds its frames */
+struct StartLine
 {
-  const int kBatch = 256;
+  std::mutex m;
+  std::condition_variable cv;
+  int waiting = 0, parties = 0;
+  unsigned long long turn = 0;
+  void arrive()
+  {
+    std::unique_lock<std::mutex> lk(m);
+    const unsigned long long mine = turn;
+    if(++waiting == parties)
+    {
+      waiting = 0;
+      turn++;
+      cv.notify_all();
+    }
+    else
+      cv.wait(lk, [&] { return turn != mine; });
+  }
+};
+
+struct ShardReport
+{
+  std::string error;
+  double seconds = 0.0;       /* the timed region: `passes` passes over the resident frames */
+  int frames = 0;
+};
+
+/* Frames [lo, hi) of the synthetic sequence on one device ("2,048 per GPU, 8 host threads",
+ * frames resident): the whole shard is generated into HBM first, outside the timed region; then, from a common start line,
+ * `passes` passes over it through the plain handle API in batches of at most kBatch frames, as many batches ahead of the
+ * fetches as the handle keeps in flight.  The lines are those of the last pass. */
+static void runShard(int device, const ssd_calibration &cal, int W, int H, int K, uint64_t seed, int lo, int hi, int passes,
+                     std::vector<std::string> &lines, std::vector<char> &threw, StartLine &start, ShardReport &rep)
+{
+  const int kBatch = 2048, kGen = 256;
+  rep.frames = hi - lo;
+  if(hi <= lo)
+  {
+    start.arrive();                                         /* an empty shard (more devices than frames) only keeps the line moving */
+    return;
+  }
   ssd_config cfg;
   ssd_default_config(&cfg, W, H);
   cfg.max_frames_per_batch = hi - lo < kBatch ? hi - lo : kBatch;
   ssd_handle *h = nullptr;
   void *dFrames = nullptr;
   const size_t frameBytes = static_cast<size_t>(W) * H * 12;
-  auto fail = [&](const char *what) { error = std::string(what) + ": " + ssd_last_error(); };
-  if(ssd_create(&cfg, &cal, device, &h) != SSD_OK) { fail("ssd_create"); return; }
-  if(ssd_device_alloc(device, frameBytes * cfg.max_frames_per_batch, &dFrames) != SSD_OK) { fail("ssd_device_alloc"); ssd_destroy(h); return; }
-  std::vector<ssd_scene> scenes(cfg.max_frames_per_batch);
-  std::vector<ssd_frame_result> results(cfg.max_frames_per_batch);
-  std::vector<char> line(SSD_LINE_CAP);
-  for(int at = lo; at < hi && error.empty(); at += cfg.max_frames_per_batch)
+  auto fail = [&](const char *what) { rep.error = std::string(what) + ": " + ssd_last_error(); };
+  if(ssd_create(&cfg, &cal, device, &h) != SSD_OK)
+    fail("ssd_create");
+  else if(ssd_device_alloc(device, frameBytes * static_cast<size_t>(hi - lo), &dFrames) != SSD_OK)
+    fail("ssd_device_alloc (the shard's frames stay resident)");
+  std::vector<ssd_scene> scenes(kGen);
+  for(int at = lo; at < hi && rep.error.empty(); at += kGen)
   {
-    const int n = hi - at < cfg.max_frames_per_batch ? hi - at : cfg.max_frames_per_batch;
+    const int n = hi - at < kGen ? hi - at : kGen;
     for(int i = 0; i < n; i++)
       ssd_source_default_scene(&scenes[i], W, H, K, seed + static_cast<uint64_t>(at + i));
-    if(ssd_synth_generate_device(scenes.data(), n, dFrames, frameBytes, device, nullptr) != SSD_OK) { error = std::string("synth: ") + ssd_source_last_error(); break; }
-    if(ssd_enqueue(h, dFrames, frameBytes, n, nullptr) != SSD_OK || ssd_fetch(h, results.data(), n, nullptr) != SSD_OK) { fail("ssd_enqueue"); break; }
-    for(int i = 0; i < n; i++)
+    if(ssd_synth_generate_device(scenes.data(), n, static_cast<char *>(dFrames) + frameBytes * static_cast<size_t>(at - lo), frameBytes, device, nullptr) != SSD_OK)
+      rep.error = std::string("synth: ") + ssd_source_last_error();
+  }
+  if(rep.error.empty() && ssd_device_sync(device) != SSD_OK)
+    fail("ssd_device_sync");
+  start.arrive();
+  if(rep.error.empty())
+  {
+    std::vector<ssd_frame_result> results(hi - lo);
+    struct Item { int at, n; };
+    std::vector<Item> work;
+    for(int p = 0; p < passes; p++)
+      for(int at = 0; at < hi - lo; at += cfg.max_frames_per_batch)
+        work.push_back(Item{ at, hi - lo - at < cfg.max_frames_per_batch ? hi - lo - at : cfg.max_frames_per_batch });
+    const int inFlight = ssd_batches_in_flight(h);
+    const int ahead = (inFlight > 2 ? inFlight : 2) - 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    for(size_t i = 0; i < work.size() && rep.error.empty(); i++)
     {
-      ssd_serialize(&results[i], line.data(), line.size());
-      lines[at + i] = line.data();
+      if(ssd_enqueue(h, static_cast<char *>(dFrames) + frameBytes * static_cast<size_t>(work[i].at), frameBytes, work[i].n, nullptr) != SSD_OK)
+        fail("ssd_enqueue");
+      else if(i >= static_cast<size_t>(ahead) && ssd_fetch_back(h, results.data() + work[i - ahead].at, work[i - ahead].n, ahead) != SSD_OK)
+        fail("ssd_fetch_back");
+    }
+    const int tail = static_cast<int>(work.size()) < ahead ? static_cast<int>(work.size()) : ahead;
+    for(int back = tail - 1; back >= 0 && rep.error.empty(); back--)
+    {
+      const Item &it = work[work.size() - 1 - back];
+      if(ssd_fetch_back(h, results.data() + it.at, it.n, back) != SSD_OK)
+        fail("ssd_fetch_back");
+    }
+    rep.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<char> line(SSD_LINE_CAP);
+    for(int i = 0; i < hi - lo && rep.error.empty(); i++)
+    {
+      /* a frame the reference would have thrown on (QuadrilateralTest, uncaught: the process ends there) has no line */
+      threw[lo + i] = (results[i].status & SSD_ST_THROW) ? 1 : 0;
+      if(ssd_serialize(&results[i], line.data(), line.size()) < 0)
+        fail("ssd_serialize");
+      lines[lo + i] = line.data();
     }
   }
-  ssd_device_free(device, dFrames);
-  ssd_destroy(h);
+  if(dFrames) ssd_device_free(device, dFrames);
+  if(h) ssd_destroy(h);
 }
 
 int main(int argc, char **argv)
 {
-  int W = 1024, H = 768, frames = 1, K = 3;
+  int W = 1024, H = 768, frames = 1, K = 3, passes = 1;
   std::vector<int> devices;
   uint64_t seed = 12345;
   const char *file = nullptr;
@@ -78,6 +156,7 @@ int main(int argc, char **argv)
     else if(!std::strcmp(argv[i], "--height")) H = std::atoi(argv[i + 1]);
     else if(!std::strcmp(argv[i], "--frames")) frames = std::atoi(argv[i + 1]);
     else if(!std::strcmp(argv[i], "--steps")) K = std::atoi(argv[i + 1]);
+    else if(!std::strcmp(argv[i], "--passes")) passes = std::atoi(argv[i + 1]) > 0 ? std::atoi(argv[i + 1]) : 1;
     else if(!std::strcmp(argv[i], "--seed")) seed = std::strtoull(argv[i + 1], nullptr, 10);
     else if(!std::strcmp(argv[i], "--file")) file = argv[i + 1];
     else if(!std::strcmp(argv[i], "--calibration")) calibrationFromFiles = !std::strcmp(argv[i + 1], "files");
@@ -124,26 +203,48 @@ int main(int argc, char **argv)
         return 1;
       }
     const ssd_calibration &cal = (calibrationFromFiles ? transFiles : transSynthetic).constants();
-    std::vector<std::string> lines(frames), errors(D);
+    std::vector<std::string> lines(frames);
+    std::vector<char> threw(frames, 0);
+    std::vector<ShardReport> reports(D);
     std::vector<std::thread> workers;
-    const auto t0 = std::chrono::steady_clock::now();
+    StartLine start;
+    start.parties = D;
     for(int d = 0; d < D; d++)
     {
       const int lo = static_cast<int>(static_cast<long long>(frames) * d / D), hi = static_cast<int>(static_cast<long long>(frames) * (d + 1) / D);
-      workers.emplace_back(runShard, devices[d], std::cref(cal), W, H, K, seed, lo, hi, std::ref(lines), std::ref(errors[d]));
+      workers.emplace_back(runShard, devices[d], std::cref(cal), W, H, K, seed, lo, hi, passes, std::ref(lines), std::ref(threw), std::ref(start),
+                           std::ref(reports[d]));
     }
     for(std::thread &t : workers)
       t.join();
-    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    for(const std::string &e : errors)
-      if(!e.empty())
+    double slowest = 0.0;
+    for(int d = 0; d < D; d++)
+    {
+      if(!reports[d].error.empty())
       {
-        std::cerr << "detect-stairs-amd: " << e << std::endl;
+        std::cerr << "detect-stairs-amd: shard " << d << " (device " << devices[d] << "): " << reports[d].error << std::endl;
         return 1;
       }
-    for(const std::string &l : lines)
-      std::cout << l << "\n";
-    std::cerr << frames << " frames on " << D << " device shard(s) in " << dt << " s (" << frames / dt << " frames/s incl. frame generation)" << std::endl;
+      if(reports[d].seconds > slowest)
+        slowest = reports[d].seconds;
+    }
+    for(int f = 0; f < frames; f++)
+    {
+      if(threw[f])
+      {
+        std::cout.flush();
+        std::cerr << "detect-stairs-amd: frame " << f << ": the reference throws std::invalid_argument here (QuadrilateralTest) and terminates" << std::endl;
+        return 1;
+      }
+      std::cout << lines[f] << "\n";
+    }
+    for(int d = 0; d < D; d++)
+      if(reports[d].frames > 0)
+        std::cerr << "  shard " << d << " on device " << devices[d] << ": " << reports[d].frames << " resident frames x " << passes << " pass(es) in "
+                  << reports[d].seconds << " s = " << static_cast<double>(reports[d].frames) * passes / reports[d].seconds << " frames/s" << std::endl;
+    std::cerr << frames << " frames on " << D << " device shard(s), " << passes << " pass(es): "
+              << (slowest > 0.0 ? static_cast<double>(frames) * passes / slowest : 0.0)
+              << " frames/s (frames resident in HBM; generation outside the timed region; slowest shard " << slowest << " s)" << std::endl;
     return 0;
   }
   const Pointcloud pointcloud(app, calibrationFromFiles ? transFiles : transSynthetic);

@@ -39,11 +39,32 @@ int fail(int code, const std::string &msg)
       return fail(SSD_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                        \
   } while(0)
 
+#ifdef SSD_TUNING
+/* tools builds only (see ssd_tuning, ssd_handle.h): overrides from the environment, read once per handle */
 int env_int(const char *name, int dflt)
 {
   const char *v = std::getenv(name);
   return v && *v ? std::atoi(v) : dflt;
 }
+void tuning_from_env(ssd_tuning &t)
+{
+  t.chunkPoints = env_int("SSD_CHUNK_POINTS", t.chunkPoints);
+  t.targetBlocks = env_int("SSD_TARGET_BLOCKS", t.targetBlocks);
+  t.k1BlocksPerFrame = env_int("SSD_K1_BLOCKS_PER_FRAME", t.k1BlocksPerFrame);
+  t.k24MinBlocks = env_int("SSD_K24_MIN_BLOCKS", t.k24MinBlocks);
+  t.k24TallBlocks = env_int("SSD_K24_TALL_BLOCKS", t.k24TallBlocks);
+  t.k2ChunkTiles = env_int("SSD_K2_CHUNK_TILES", t.k2ChunkTiles);
+  t.k4ChunkTiles = env_int("SSD_K4_CHUNK_TILES", t.k4ChunkTiles);
+  t.winShift = env_int("SSD_WIN_SHIFT", 0);
+  t.winShiftGround = env_int("SSD_WIN_SHIFT_G", 0);
+}
+#endif
+
+/* ssd_config::batches_in_flight = 0: handles for batches (>= kOverlapMinFrames frames per call) get kOverlapDepth
+ * workspaces; measured with ssd_pipeline_* (the same overlap across handles), XGA, depth 1 / 2 / 3 / 4: 64 frames per batch
+ * 181 k / 235 k / 248 k / 232 k frames/s, 256: 230 k / 272 k / 282 k / 274 k, 1024: 257 k / 284 k / 304 k / 295 k */
+constexpr int kOverlapMinFrames = 128;
+constexpr int kOverlapDepth = 3;
 
 } // namespace
 
@@ -71,6 +92,7 @@ int ssd_default_config(ssd_config *cfg, int width, int height)
   cfg->min_step_depth = 0.1;
   cfg->max_frames_per_batch = 64;
   cfg->max_step_plateaus = SSD_MAX_STEP_IMAGES;
+  cfg->batches_in_flight = 0;                 /* automatic: see ssd_config */
   return SSD_OK;
 }
 
@@ -276,8 +298,11 @@ int ssd_device_count(void)
 
 static int make_params(const ssd_config &c, const ssd_calibration &k, Params &P)
 {
-  if(c.width <= 0 || c.height <= 0 || c.width > 8192 || c.height > 8192)
-    return fail(SSD_E_ARG, "config: resolution out of range");
+  /* height: a pixel key's row field is 13 bits and "inside the wave's LDS window" is one subtraction on the key
+   * (ssd_kernels.hip, window_hit): a window anchored within its own height (<= 128 rows) of row 8192 would take pixels of
+   * the next image slot for its own */
+  if(c.width <= 0 || c.height <= 0 || c.width > 8192 || c.height > 8064)
+    return fail(SSD_E_ARG, "config: resolution out of range (width <= 8192, height <= 8064)");
   if(!(c.x_max > c.x_min) || !(c.y_max > c.y_min) || !(c.z_max > c.z_min) || !(c.height_interval > 0))
     return fail(SSD_E_ARG, "config: empty measuring range");
   P.W = c.width; P.H = c.height;
@@ -337,18 +362,6 @@ static int make_params(const ssd_config &c, const ssd_calibration &k, Params &P)
       P.px.winShift++;
     P.px.winShiftGround = P.px.winShift;
   }
-  if(const char *e = getenv("SSD_WIN_SHIFT"))
-  {
-    const int v = atoi(e);
-    if(v >= 1 && v <= 6)
-      P.px.winShift = v;
-  }
-  if(const char *e = getenv("SSD_WIN_SHIFT_G"))
-  {
-    const int v = atoi(e);
-    if(v >= 1 && v <= 6)
-      P.px.winShiftGround = v;
-  }
   if((c.width - 1) / 25 + 2 > SSD_MAX_SCANS)
     return fail(SSD_E_ARG, "config: width needs more scan columns than SSD_MAX_SCANS");
   return SSD_OK;
@@ -372,11 +385,25 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
     return fail(SSD_E_ARG, "ssd_create: device index out of range");
   HIP_TRY(hipSetDevice(device));
 
+  int depth = cfg->batches_in_flight;
+  if(depth < 0 || depth > kMaxLanes)
+    return fail(SSD_E_ARG, "ssd_create: batches_in_flight must be 0 (automatic) .. " + std::to_string(kMaxLanes));
+  if(depth == 0)
+    depth = cfg->max_frames_per_batch >= kOverlapMinFrames ? kOverlapDepth : 1;
+
   ssd_handle *h = new ssd_handle();
   h->device = device;
   h->cfg = *cfg;
+  h->cfg.batches_in_flight = depth;
   h->P = P;
+#ifdef SSD_TUNING
+  tuning_from_env(h->tune);
+  if(h->tune.winShift >= 1 && h->tune.winShift <= 6) h->P.px.winShift = h->tune.winShift;
+  if(h->tune.winShiftGround >= 1 && h->tune.winShiftGround <= 6) h->P.px.winShiftGround = h->tune.winShiftGround;
+#endif
   h->F = cfg->max_frames_per_batch;
+  h->depth = depth;
+  h->nSlots = depth > 2 ? depth : 2;
   h->imgWords = static_cast<size_t>(P.H) * P.W64;
   const size_t stepBytes = static_cast<size_t>(h->F) * P.maxStepImages * h->imgWords * 8;
   const size_t groundBytes = static_cast<size_t>(h->F) * h->imgWords * 8;
@@ -391,25 +418,34 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
       return fail(e_ == hipErrorOutOfMemory ? SSD_E_NOMEM : SSD_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     }                                                                                                   \
   } while(0)
-  HIP_TRY_H(hipMalloc(&h->dState, sizeof(FrameState) * h->F));
-  HIP_TRY_H(hipMalloc(&h->dStepImg, stepBytes));
-  HIP_TRY_H(hipMalloc(&h->dGroundImg, groundBytes));
-  h->tileMaskStride = (static_cast<size_t>(P.nPoints) + kTileHost - 1) / kTileHost * (kTileHost / kCellHost);   /* masks (u32) per frame */
-  HIP_TRY_H(hipMalloc(&h->dTileMasks, h->tileMaskStride * sizeof(uint2) * h->F));
-  HIP_TRY_H(hipMalloc(&h->dResults, sizeof(ssd_frame_result) * h->F * 2));
-  HIP_TRY_H(hipHostMalloc(&h->hResults, sizeof(ssd_frame_result) * h->F * 2, hipHostMallocDefault));
-  std::memset(h->hResults, 0, sizeof(ssd_frame_result) * h->F * 2);
+  h->tileMaskStride = (static_cast<size_t>(P.nPoints) + kTileHost - 1) / kTileHost * (kTileHost / kCellHost);   /* cell records per frame */
+  const size_t maskBytes = h->tileMaskStride * sizeof(uint2) * h->F;
+  for(int k = 0; k < depth; k++)
+  {
+    ssd_lane &L = h->lane[k];
+    HIP_TRY_H(hipMalloc(&L.dState, sizeof(FrameState) * h->F));
+    HIP_TRY_H(hipMalloc(&L.dStepImg, stepBytes));
+    HIP_TRY_H(hipMalloc(&L.dGroundImg, groundBytes));
+    HIP_TRY_H(hipMalloc(&L.dTileMasks, maskBytes));
+    HIP_TRY_H(hipEventCreateWithFlags(&L.in, hipEventDisableTiming));
+    HIP_TRY_H(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+    if(depth > 1)
+      HIP_TRY_H(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    HIP_TRY_H(hipMemset(L.dState, 0, sizeof(FrameState) * h->F));
+    HIP_TRY_H(hipMemset(L.dStepImg, 0, stepBytes));
+    HIP_TRY_H(hipMemset(L.dGroundImg, 0, groundBytes));
+  }
+  const size_t resBytes = sizeof(ssd_frame_result) * h->F * h->nSlots;
+  HIP_TRY_H(hipMalloc(&h->dResults, resBytes));
+  HIP_TRY_H(hipHostMalloc(&h->hResults, resBytes, hipHostMallocDefault));
+  std::memset(h->hResults, 0, resBytes);
   HIP_TRY_H(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->hResultsDev), h->hResults, 0));
-  HIP_TRY_H(hipEventCreateWithFlags(&h->resultsReady[0], hipEventDisableTiming));
-  HIP_TRY_H(hipEventCreateWithFlags(&h->resultsReady[1], hipEventDisableTiming));
-  HIP_TRY_H(hipEventCreateWithFlags(&h->lastDone, hipEventDisableTiming));
-  HIP_TRY_H(hipMemset(h->dState, 0, sizeof(FrameState) * h->F));
-  HIP_TRY_H(hipMemset(h->dStepImg, 0, stepBytes));
-  HIP_TRY_H(hipMemset(h->dGroundImg, 0, groundBytes));
-  HIP_TRY_H(hipMemset(h->dResults, 0, sizeof(ssd_frame_result) * h->F * 2));
+  for(int k = 0; k < h->nSlots; k++)
+    HIP_TRY_H(hipEventCreateWithFlags(&h->resultsReady[k], hipEventDisableTiming));
+  HIP_TRY_H(hipMemset(h->dResults, 0, resBytes));
   HIP_TRY_H(hipDeviceSynchronize());
 #undef HIP_TRY_H
-  h->bytes = sizeof(FrameState) * h->F + stepBytes + groundBytes + h->tileMaskStride * sizeof(uint2) * h->F + sizeof(ssd_frame_result) * h->F;
+  h->bytes = static_cast<size_t>(depth) * (sizeof(FrameState) * h->F + stepBytes + groundBytes + maskBytes) + resBytes;
   *out = h;
   return SSD_OK;
 }
@@ -419,16 +455,22 @@ int ssd_destroy(ssd_handle *h)
   if(!h)
     return SSD_OK;
   (void)hipSetDevice(h->device);
-  if(h->dState) (void)hipFree(h->dState);
-  if(h->dStepImg) (void)hipFree(h->dStepImg);
-  if(h->dGroundImg) (void)hipFree(h->dGroundImg);
-  if(h->dTileMasks) (void)hipFree(h->dTileMasks);
+  (void)hipDeviceSynchronize();               /* nothing of this handle is in flight any more (lanes run on their own streams) */
+  for(ssd_lane &L : h->lane)
+  {
+    if(L.dState) (void)hipFree(L.dState);
+    if(L.dStepImg) (void)hipFree(L.dStepImg);
+    if(L.dGroundImg) (void)hipFree(L.dGroundImg);
+    if(L.dTileMasks) (void)hipFree(L.dTileMasks);
+    if(L.in) (void)hipEventDestroy(L.in);
+    if(L.done) (void)hipEventDestroy(L.done);
+    if(L.stream) (void)hipStreamDestroy(L.stream);
+  }
   if(h->dDepthMaps) (void)hipFree(h->dDepthMaps);
   if(h->dResults) (void)hipFree(h->dResults);
   if(h->hResults) (void)hipHostFree(h->hResults);
   for(hipEvent_t e : h->resultsReady)
     if(e) (void)hipEventDestroy(e);
-  if(h->lastDone) (void)hipEventDestroy(h->lastDone);
   for(int k = 0; k < 2; k++)
   {
     if(h->ingestBuf[k]) (void)hipFree(h->ingestBuf[k]);
@@ -439,6 +481,7 @@ int ssd_destroy(ssd_handle *h)
   if(h->ingestCompute) (void)hipStreamDestroy(h->ingestCompute);
   if(h->dRisers) (void)hipFree(h->dRisers);
   if(h->hRisers) (void)hipHostFree(h->hRisers);
+  if(h->hRisersBatch) (void)hipHostFree(h->hRisersBatch);
   if(h->dDebug) (void)hipFree(h->dDebug);
   if(h->dDebugImg) (void)hipFree(h->dDebugImg);
   for(hipEvent_t e : h->ev)
@@ -457,11 +500,21 @@ int ssd_set_debug(ssd_handle *h, int enable)
   if(!h)
     return fail(SSD_E_ARG, "ssd_set_debug: null handle");
   HIP_TRY(hipSetDevice(h->device));
-  if(enable && !h->dDebug)
+  if(enable && (!h->dDebug || !h->dDebugImg))
   {
+    /* both buffers or neither: a failed second allocation must not leave the first behind as "debug is set up" */
     const size_t imgBytes = static_cast<size_t>(h->F) * (h->P.maxStepImages + 1) * 2 * h->imgWords * 8;
-    HIP_TRY(hipMalloc(&h->dDebug, sizeof(DebugFrame) * h->F));
-    HIP_TRY(hipMalloc(&h->dDebugImg, imgBytes));
+    DebugFrame *d = nullptr;
+    unsigned long long *di = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(DebugFrame) * h->F));
+    const hipError_t e = hipMalloc(&di, imgBytes);
+    if(e != hipSuccess)
+    {
+      (void)hipFree(d);
+      return fail(e == hipErrorOutOfMemory ? SSD_E_NOMEM : SSD_E_HIP, std::string("ssd_set_debug: ") + hipGetErrorString(e));
+    }
+    h->dDebug = d;
+    h->dDebugImg = di;
     h->bytes += sizeof(DebugFrame) * h->F + imgBytes;
   }
   h->debug = enable != 0;
@@ -475,12 +528,21 @@ int ssd_set_risers(ssd_handle *h, int enable, double tolerance, int min_support)
   if(enable && (!(tolerance > 0.0) || tolerance > 1.0 || min_support < 1))
     return fail(SSD_E_ARG, "ssd_set_risers: tolerance must be in (0, 1] m, min_support >= 1");
   HIP_TRY(hipSetDevice(h->device));
-  if(enable && !h->dRisers)
+  if(enable && (!h->dRisers || !h->hRisers))
   {
     const size_t bytes = sizeof(ssd_frame_risers) * h->F;
-    HIP_TRY(hipMalloc(&h->dRisers, bytes));
-    HIP_TRY(hipMemset(h->dRisers, 0, bytes));
-    HIP_TRY(hipHostMalloc(&h->hRisers, bytes, hipHostMallocDefault));
+    ssd_frame_risers *d = nullptr, *hh = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    hipError_t e = hipMemset(d, 0, bytes);
+    if(e == hipSuccess)
+      e = hipHostMalloc(&hh, bytes, hipHostMallocDefault);
+    if(e != hipSuccess)
+    {
+      (void)hipFree(d);
+      return fail(e == hipErrorOutOfMemory ? SSD_E_NOMEM : SSD_E_HIP, std::string("ssd_set_risers: ") + hipGetErrorString(e));
+    }
+    h->dRisers = d;
+    h->hRisers = hh;
     h->bytes += bytes;
   }
   h->P.risers = enable ? 1 : 0;
@@ -498,12 +560,21 @@ int ssd_fetch_risers(ssd_handle *h, ssd_frame_risers *out, int nframes, void *st
     return fail(SSD_E_ARG, "ssd_fetch_risers: null argument");
   if(!h->P.risers || !h->dRisers)
     return fail(SSD_E_ARG, "ssd_fetch_risers: call ssd_set_risers(h, 1, ...) before the enqueue");
-  if(nframes < 1 || nframes > h->F)
-    return fail(SSD_E_ARG, "ssd_fetch_risers: nframes out of range");
   HIP_TRY(hipSetDevice(h->device));
+  if(h->hRisersBatchFrames > 0)
+  {
+    /* the last call was ssd_process_host / ssd_process_depth_host: its risers were collected slice by slice */
+    if(nframes < 1 || nframes > h->hRisersBatchFrames)
+      return fail(SSD_E_ARG, "ssd_fetch_risers: nframes exceeds what the last call processed");
+    HIP_TRY(hipStreamSynchronize(h->ingestCompute));
+    std::memcpy(out, h->hRisersBatch, sizeof(ssd_frame_risers) * nframes);
+    return SSD_OK;
+  }
+  if(nframes < 1 || nframes > h->lastFrames)
+    return fail(SSD_E_ARG, "ssd_fetch_risers: nframes exceeds what the last enqueue processed");
+  /* the riser buffer is single: enqueues with risers on all run in lane 0, whose `done` event covers the last one */
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if(h->haveLast && s != h->lastStream)
-    HIP_TRY(hipStreamWaitEvent(s, h->lastDone, 0));
+  HIP_TRY(hipStreamWaitEvent(s, h->lane[h->lastLane].done, 0));
   HIP_TRY(hipMemcpyAsync(h->hRisers, h->dRisers, sizeof(ssd_frame_risers) * nframes, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   std::memcpy(out, h->hRisers, sizeof(ssd_frame_risers) * nframes);
@@ -538,15 +609,15 @@ int ssd_set_timing(ssd_handle *h, int enable)
   return SSD_OK;
 }
 
-static int choose_chunk(int nPoints, int nframes)
+static int choose_chunk(const ssd_tuning &tune, int nPoints, int nframes)
 {
-  const int forced = env_int("SSD_CHUNK_POINTS", 0);
+  const int forced = tune.chunkPoints;
   if(forced > 0)
   {
     const int c = ((forced + kTileHost - 1) / kTileHost) * kTileHost;
     return c > kMaxTilesPerBlockHost * kTileHost ? kMaxTilesPerBlockHost * kTileHost : c;
   }
-  const int target = env_int("SSD_TARGET_BLOCKS", 32768);
+  const int target = tune.targetBlocks;
   int cpf = (target + nframes - 1) / nframes;
   const int maxCpf = (nPoints + kTileHost - 1) / kTileHost;
   if(cpf > maxCpf) cpf = maxCpf;
@@ -591,22 +662,45 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
       return fail(SSD_E_ARG, "ssd_enqueue: frame pointer must be 4-byte aligned");
   }
   HIP_TRY(hipSetDevice(h->device));
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  /* the workspace is single-buffered: work enqueued on another stream than the previous call's waits for it */
-  if(h->haveLast && s != h->lastStream)
-    HIP_TRY(hipStreamWaitEvent(s, h->lastDone, 0));
   const Params &P = h->P;
+  /* Which workspace.  A handle with one runs on the caller's stream (a switch of streams is ordered by the lane's event: the
+   * workspace is single-buffered).  With several, successive batches take them in turn, each on the lane's own stream behind
+   * an event recorded on the caller's stream now: the batch starts after the work the caller's stream holds, but the caller's
+   * stream does not wait for the batch (ssd_fetch* / ssd_stream_wait do).  Debug capture, the riser pass and partial runs
+   * (ssd_enqueue_stages) own single buffers / leave state behind for the next call: they stay in lane 0. */
+  const bool pinned = h->debug || P.risers || stages != SSD_STAGE_ALL;
+  const int li = h->depth == 1 || pinned ? 0 : static_cast<int>(h->laneTurn++ % static_cast<unsigned long long>(h->depth));
+  ssd_lane &L = h->lane[li];
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if(h->depth == 1)
+  {
+    if(L.haveLast && s != L.lastStream)
+      HIP_TRY(hipStreamWaitEvent(s, L.done, 0));
+  }
+  else
+  {
+    HIP_TRY(hipEventRecord(L.in, s));
+    s = L.stream;
+    HIP_TRY(hipStreamWaitEvent(s, L.in, 0));
+    /* the single debug / riser buffers: a pinned call after free-running ones (or the other way round) must not overtake
+     * what the other lanes still hold — rare (a switch of mode), so simply wait for all of them */
+    if(pinned != h->lastPinned)
+      for(int k = 0; k < h->depth; k++)
+        if(k != li && h->lane[k].haveLast)
+          HIP_TRY(hipStreamWaitEvent(s, h->lane[k].done, 0));
+  }
+  h->lastPinned = pinned;
   const float *xyz = static_cast<const float *>(d_xyz);
   const size_t strideFloats = depthInput ? frame_stride_bytes / 2 : frame_stride_bytes / 4;    /* elements of the source type */
   const DepthSrc depthSrc{ h->dDepthMaps, h->dDepthMaps ? h->dDepthMaps + P.W : nullptr, h->intr.depth_units, P.W, P.H };
   const DepthSrc *depth = depthInput ? &depthSrc : nullptr;
-  const int chunk = choose_chunk(P.nPoints, nframes);
+  const int chunk = choose_chunk(h->tune, P.nPoints, nframes);
   /* K2 and K4 walk cell columns: the taller a block's chunk, the fewer window flushes and block starts per cell (below) */
   /* K1 ends every block with up to 121 global atomics into the frame's histogram: with one-tile chunks (single frames) 768
-   * blocks queue up on the same addresses; at most SSD_K1_BLOCKS_PER_FRAME blocks per frame keeps that short */
+   * blocks queue up on the same addresses; at most ssd_tuning::k1BlocksPerFrame blocks per frame keeps that short */
   int chunkHist = chunk;
   {
-    const int perFrame = env_int("SSD_K1_BLOCKS_PER_FRAME", 256);
+    const int perFrame = h->tune.k1BlocksPerFrame;
     const int tilesPerFrame = (P.nPoints + kTileHost - 1) / kTileHost;
     int t = (tilesPerFrame + perFrame - 1) / perFrame;
     if(t > kMaxTilesPerBlockHost) t = kMaxTilesPerBlockHost;
@@ -620,8 +714,8 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
      * only while they leave >= 6144 blocks (three rounds); else as tall as leaves >= 1536 blocks, K2 never below 2 tiles.
      * Against the former ">= 600 blocks": 8 / 16 / 32 / 64 frames 46 -> 49 k, 73 -> 82 k, 113 -> 124 k, 159 -> 172 k frames/s. */
     const long long totalTiles = (static_cast<long long>(P.nPoints) + kTileHost - 1) / kTileHost * nframes;
-    const int minBlocks = env_int("SSD_K24_MIN_BLOCKS", 1536), tallBlocks = env_int("SSD_K24_TALL_BLOCKS", 6144);
-    int t2 = env_int("SSD_K2_CHUNK_TILES", 32), t4 = env_int("SSD_K4_CHUNK_TILES", 16);
+    const int minBlocks = h->tune.k24MinBlocks, tallBlocks = h->tune.k24TallBlocks;
+    int t2 = h->tune.k2ChunkTiles, t4 = h->tune.k4ChunkTiles;
     if(t2 > kMaxTilesPerBlockRasterHost) t2 = kMaxTilesPerBlockRasterHost;
     if(t4 > kMaxTilesPerBlockInquadHost) t4 = kMaxTilesPerBlockInquadHost;
     auto pick = [&](int t, int tMin)
@@ -641,54 +735,56 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   int evi = static_cast<int>(h->enqueueCount % SSD_TIMING_SLOTS) * 8;
   auto mark = [&]() { if(timing) (void)hipEventRecord(h->ev[evi++], s); };
 
-  if(h->imagesDirty)
+  if(L.imagesDirty)
   {
-    HIP_TRY(hipMemsetAsync(h->dStepImg, 0, static_cast<size_t>(h->F) * P.maxStepImages * h->imgWords * 8, s));
-    HIP_TRY(hipMemsetAsync(h->dGroundImg, 0, static_cast<size_t>(h->F) * h->imgWords * 8, s));
-    h->imagesDirty = false;
+    HIP_TRY(hipMemsetAsync(L.dStepImg, 0, static_cast<size_t>(h->F) * P.maxStepImages * h->imgWords * 8, s));
+    HIP_TRY(hipMemsetAsync(L.dGroundImg, 0, static_cast<size_t>(h->F) * h->imgWords * 8, s));
+    L.imagesDirty = false;
   }
   if(stages & SSD_STAGE_HIST)
   {
     /* No memset of the state in front of a call: K1 only needs its accumulators zero, and k_peaks — their one reader —
      * clears them as it takes them (everything else in FrameState is written before it is read).  Only after a call that
      * ran K1 without k_peaks (ssd_enqueue_stages), or one that failed half way, the state is zeroed here. */
-    if(h->dirtyFrames > 0)
-      HIP_TRY(hipMemsetAsync(h->dState, 0, sizeof(FrameState) * h->dirtyFrames, s));
-    h->dirtyFrames = nframes;
+    if(L.dirtyFrames > 0)
+      HIP_TRY(hipMemsetAsync(L.dState, 0, sizeof(FrameState) * L.dirtyFrames, s));
+    L.dirtyFrames = nframes;
     if(dbg)
       HIP_TRY(hipMemsetAsync(dbg, 0, sizeof(DebugFrame) * nframes, s));
   }
   mark();
   if(stages & SSD_STAGE_HIST)
-    launch_hist(xyz, strideFloats, P, h->dState, h->dTileMasks, h->tileMaskStride, nframes, chunkHist, depth, s);
+    launch_hist(xyz, strideFloats, P, L.dState, L.dTileMasks, h->tileMaskStride, nframes, chunkHist, depth, s);
   mark();
   if(stages & SSD_STAGE_PEAKS)
-    launch_peaks(P, h->dState, nframes, dbg, s);
+    launch_peaks(P, L.dState, nframes, dbg, s);
   mark();
   if(stages & SSD_STAGE_RASTER)
-    launch_raster(xyz, strideFloats, P, h->dState, h->dStepImg, h->dTileMasks, h->tileMaskStride, nframes, chunkRaster, depth, s);
+    launch_raster(xyz, strideFloats, P, L.dState, L.dStepImg, L.dTileMasks, h->tileMaskStride, nframes, chunkRaster, depth, s);
   mark();
   if(stages & SSD_STAGE_OUTLINE)
-    launch_outline(P, h->dState, h->dStepImg, nframes, dbg, dbgImg, s);
+    launch_outline(P, L.dState, L.dStepImg, nframes, dbg, dbgImg, s);
   mark();
   if(stages & SSD_STAGE_QUADS)
-    launch_quads(P, h->dState, nframes, dbg, s);
+    launch_quads(P, L.dState, nframes, dbg, s);
   mark();
   if(stages & SSD_STAGE_INQUAD)
-    launch_inquad(xyz, strideFloats, P, h->dState, h->dGroundImg, h->dTileMasks, h->tileMaskStride, nframes, chunkInquad, depth, s);
+    launch_inquad(xyz, strideFloats, P, L.dState, L.dGroundImg, L.dTileMasks, h->tileMaskStride, nframes, chunkInquad, depth, s);
   mark();
   /* The results leave with the batch, into this enqueue's pinned slot (event for ssd_fetch / ssd_fetch_back).  A few frames:
    * k_final stores them there itself — a kilobyte per frame of posted writes, visible to the host once the event has
    * fired — instead of a device-to-host copy command behind the kernel (single frame: one command less in the chain).
    * Batches go through device memory and one copy: a megabyte of scattered stores over PCIe would hold k_final's blocks. */
-  const int slot = static_cast<int>(h->finalCount & 1ull);
+  const int slot = static_cast<int>(h->finalCount % static_cast<unsigned long long>(h->nSlots));
   const bool direct = nframes <= kDirectResultFrames && h->hResultsDev != nullptr;
+  if((stages & SSD_STAGE_FINAL) && h->depth > 1 && h->resultsLane[slot] != li && h->lane[h->resultsLane[slot]].haveLast)
+    HIP_TRY(hipStreamWaitEvent(s, h->lane[h->resultsLane[slot]].done, 0));     /* the slot's previous writer was another lane */
   if(stages & SSD_STAGE_FINAL)
   {
     ssd_frame_result *out = (direct ? h->hResultsDev : h->dResults) + static_cast<size_t>(slot) * h->F;
-    launch_final(P, h->dState, h->dGroundImg, out, nframes, dbg, dbgImg, s);
+    launch_final(P, L.dState, L.dGroundImg, out, nframes, dbg, dbgImg, s);
     if(P.risers)
-      launch_risers(xyz, strideFloats, P, h->dState, h->dTileMasks, h->tileMaskStride, h->dRisers, nframes, chunk, depth, s);
+      launch_risers(xyz, strideFloats, P, L.dState, L.dTileMasks, h->tileMaskStride, h->dRisers, nframes, chunk, depth, s);
   }
   mark();
   if(stages & SSD_STAGE_FINAL)
@@ -698,18 +794,21 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
                              sizeof(ssd_frame_result) * nframes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(h->resultsReady[slot], s));
     h->resultsFrames[slot] = nframes;
+    h->resultsLane[slot] = li;
     h->finalCount++;
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(h->lastDone, s));
-  if((stages & SSD_STAGE_PEAKS) && nframes >= h->dirtyFrames)
-    h->dirtyFrames = 0;
-  h->lastStream = s;
-  h->haveLast = true;
+  HIP_TRY(hipEventRecord(L.done, s));
+  if((stages & SSD_STAGE_PEAKS) && nframes >= L.dirtyFrames)
+    L.dirtyFrames = 0;
+  L.lastStream = s;
+  L.haveLast = true;
   /* a raster without its consumer leaves bits behind */
   if(((stages & SSD_STAGE_RASTER) && !(stages & SSD_STAGE_OUTLINE)) || ((stages & SSD_STAGE_INQUAD) && !(stages & SSD_STAGE_FINAL)))
-    h->imagesDirty = true;
+    L.imagesDirty = true;
   h->lastFrames = nframes;
+  h->lastLane = li;
+  h->hRisersBatchFrames = 0;
   h->enqueueCount++;
   return SSD_OK;
 }
@@ -798,15 +897,32 @@ int ssd_fetch_back(ssd_handle *h, ssd_frame_result *results, int nframes, int ba
 {
   if(!h || !results)
     return fail(SSD_E_ARG, "ssd_fetch: null argument");
-  if(back < 0 || back > 1 || h->finalCount < static_cast<unsigned long long>(back) + 1)
-    return fail(SSD_E_ARG, "ssd_fetch: no enqueue at that position (back = 0: the last one, 1: the one before)");
-  const int slot = static_cast<int>((h->finalCount - 1 - back) & 1ull);
+  if(back < 0 || back >= h->nSlots || h->finalCount < static_cast<unsigned long long>(back) + 1)
+    return fail(SSD_E_ARG, "ssd_fetch: no enqueue at that position (back = 0: the last one, 1: the one before, .. < max(2, batches_in_flight))");
+  const int slot = static_cast<int>((h->finalCount - 1 - back) % static_cast<unsigned long long>(h->nSlots));
   if(nframes < 1 || nframes > h->resultsFrames[slot])
     return fail(SSD_E_ARG, "ssd_fetch: nframes exceeds what that enqueue processed");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipEventSynchronize(h->resultsReady[slot]));
   std::memcpy(results, h->hResults + static_cast<size_t>(slot) * h->F, sizeof(ssd_frame_result) * nframes);
   return SSD_OK;
+}
+
+int ssd_stream_wait(ssd_handle *h, int back, void *stream)
+{
+  if(!h)
+    return fail(SSD_E_ARG, "ssd_stream_wait: null handle");
+  if(back < 0 || back >= h->nSlots || h->finalCount < static_cast<unsigned long long>(back) + 1)
+    return fail(SSD_E_ARG, "ssd_stream_wait: no enqueue at that position");
+  const int slot = static_cast<int>((h->finalCount - 1 - back) % static_cast<unsigned long long>(h->nSlots));
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->resultsReady[slot], 0));
+  return SSD_OK;
+}
+
+int ssd_batches_in_flight(const ssd_handle *h)
+{
+  return h ? h->depth : 0;
 }
 
 int ssd_fetch(ssd_handle *h, ssd_frame_result *results, int nframes, void *stream)
@@ -859,6 +975,17 @@ static int process_host_impl(ssd_handle *h, const void *src, size_t srcFrameByte
   const int slice = h->F < kIngestFrames ? h->F : kIngestFrames;
   int rc = ingest_prepare(h, static_cast<size_t>(slice) * devFrameBytes);
   if(rc) return rc;
+  const bool risers = h->P.risers && h->dRisers;
+  if(risers && h->hRisersBatchCap < nframes)
+  {
+    /* the risers of the whole batch, slice by slice (the device buffer holds one enqueue's) */
+    HIP_TRY(hipStreamSynchronize(h->ingestCompute));
+    if(h->hRisersBatch) (void)hipHostFree(h->hRisersBatch);
+    h->hRisersBatch = nullptr;
+    h->hRisersBatchCap = 0;
+    HIP_TRY(hipHostMalloc(&h->hRisersBatch, sizeof(ssd_frame_risers) * static_cast<size_t>(nframes), hipHostMallocDefault));
+    h->hRisersBatchCap = nframes;
+  }
   const unsigned char *from = static_cast<const unsigned char *>(src);
   int prevFrames = 0, prevAt = 0, c = 0;
   for(int done = 0; done < nframes; c++)
@@ -877,6 +1004,11 @@ static int process_host_impl(ssd_handle *h, const void *src, size_t srcFrameByte
     HIP_TRY(hipStreamWaitEvent(h->ingestCompute, h->ingestCopied[k], 0));
     rc = enqueue_impl(h, h->ingestBuf[k], devFrameBytes, n, h->ingestCompute, SSD_STAGE_ALL, depthInput);
     if(rc) return rc;
+    /* with several workspaces the slice runs on its lane's stream: "consumed" is its end, not this stream's position */
+    rc = ssd_stream_wait(h, 0, h->ingestCompute);
+    if(rc) return rc;
+    if(risers)
+      HIP_TRY(hipMemcpyAsync(h->hRisersBatch + done, h->dRisers, sizeof(ssd_frame_risers) * n, hipMemcpyDeviceToHost, h->ingestCompute));
     HIP_TRY(hipEventRecord(h->ingestConsumed[k], h->ingestCompute));
     if(prevFrames)
     {
@@ -887,7 +1019,10 @@ static int process_host_impl(ssd_handle *h, const void *src, size_t srcFrameByte
     prevAt = done;
     done += n;
   }
-  return ssd_fetch_back(h, results + prevAt, prevFrames, 0);
+  rc = ssd_fetch_back(h, results + prevAt, prevFrames, 0);
+  if(rc) return rc;
+  h->hRisersBatchFrames = risers ? nframes : 0;
+  return SSD_OK;
 }
 
 int ssd_process_host(ssd_handle *h, const float *xyz, int nframes, ssd_frame_result *results)

@@ -8,34 +8,68 @@
 #include "ssd_device.h"
 #include <vector>
 
+/* Launch-geometry constants of a handle.  The product uses the compiled defaults below (each one measured: ssd_capi.hip,
+ * choose_chunk / enqueue_impl).  Only a tools build (make EXTRA=-DSSD_TUNING OUT=../lib_tuning, tools/exp*.sh) reads
+ * overrides from the environment (SSD_CHUNK_POINTS, SSD_TARGET_BLOCKS, SSD_K1_BLOCKS_PER_FRAME, SSD_K24_MIN_BLOCKS,
+ * SSD_K24_TALL_BLOCKS, SSD_K2_CHUNK_TILES, SSD_K4_CHUNK_TILES, SSD_WIN_SHIFT, SSD_WIN_SHIFT_G), and only once, in ssd_create:
+ * no entry point of the product library calls getenv. */
+struct ssd_tuning
+{
+  int chunkPoints = 0;            /* > 0: the general chunk, forced */
+  int targetBlocks = 32768;       /* blocks a streaming launch aims at */
+  int k1BlocksPerFrame = 256;     /* K1: at most this many blocks per frame (their final atomics share the frame's histogram) */
+  int k24MinBlocks = 1536, k24TallBlocks = 6144;
+  int k2ChunkTiles = 32, k4ChunkTiles = 16;
+  int winShift = 0, winShiftGround = 0;     /* > 0: shape of the waves' LDS image windows, forced */
+};
+
+/* One complete workspace of a handle: everything a batch in flight owns on the device.  A handle has `depth` of them
+ * (ssd_config::batches_in_flight); successive enqueues take them in turn, each on the lane's own stream, so that the launches
+ * of one batch fill the gaps the one-block-per-frame kernels of the others leave. */
+struct ssd_lane
+{
+  ssd::FrameState *dState = nullptr;
+  unsigned long long *dStepImg = nullptr;
+  unsigned long long *dGroundImg = nullptr;
+  uint2 *dTileMasks = nullptr;             /* per cell (64 points): which groups of 4 height bins occur; K1 -> K2, K4, K6 */
+  hipStream_t stream = nullptr;             /* the lane's own stream (depth > 1 only; depth 1 runs on the caller's stream) */
+  hipEvent_t in = nullptr;                  /* recorded on the caller's stream at the enqueue: the lane's work starts behind it */
+  hipEvent_t done = nullptr;                /* recorded behind the lane's last enqueue */
+  hipStream_t lastStream = nullptr;         /* depth 1: the stream of the previous call (a switch is ordered by `done`) */
+  bool haveLast = false;
+  bool imagesDirty = false;
+  int dirtyFrames = 0;                      /* leading FrameStates whose K1 accumulators may be non-zero (k_peaks clears them) */
+};
+
+constexpr int kMaxLanes = 4;
+
 struct ssd_handle
 {
   int device = 0;
   ssd_config cfg{};
   ssd::Params P{};
+  ssd_tuning tune{};
   int F = 0;                      /* max frames per batch */
   size_t imgWords = 0;            /* 64-bit words per bit image */
-  ssd::FrameState *dState = nullptr;
-  unsigned long long *dStepImg = nullptr;
-  unsigned long long *dGroundImg = nullptr;
-  uint2 *dTileMasks = nullptr;             /* per cell (64 points): which groups of 4 height bins occur; K1 -> K2, K4, K6 */
+  int depth = 1;                  /* lanes in use */
+  ssd_lane lane[kMaxLanes];
+  int lastLane = 0;               /* the lane of the last enqueue (debug capture, test hooks, riser fetch read it) */
+  unsigned long long laneTurn = 0;
+  bool lastPinned = false;        /* the last enqueue was held in lane 0 (debug capture, risers, partial stages) */
   size_t tileMaskStride = 0;
   float *dDepthMaps = nullptr;              /* xmap[W] then ymap[H] (ssd_set_intrinsics) */
   ssd_intrinsics intr{};
   bool haveIntr = false;
-  /* two result slots, used alternately by the enqueues that run the last stage: the device -> pinned-host copy of
-   * a batch's results is part of its enqueue, so that the next batch can be enqueued before the results are read */
-  ssd_frame_result *dResults = nullptr;     /* 2 x F */
-  ssd_frame_result *hResults = nullptr;     /* 2 x F, pinned */
+  /* result slots (max(2, depth)), used in turn by the enqueues that run the last stage: the device -> pinned-host copy of
+   * a batch's results is part of its enqueue, so that the next batches can be enqueued before the results are read */
+  int nSlots = 2;
+  ssd_frame_result *dResults = nullptr;     /* nSlots x F */
+  ssd_frame_result *hResults = nullptr;     /* nSlots x F, pinned */
   ssd_frame_result *hResultsDev = nullptr;  /* the same memory as the kernels address it (small batches write it directly) */
-  hipEvent_t resultsReady[2] = { nullptr, nullptr };
-  int resultsFrames[2] = { 0, 0 };
+  hipEvent_t resultsReady[kMaxLanes] = { nullptr, nullptr, nullptr, nullptr };
+  int resultsFrames[kMaxLanes] = { 0, 0, 0, 0 };
+  int resultsLane[kMaxLanes] = { 0, 0, 0, 0 };
   unsigned long long finalCount = 0;        /* enqueues that produced results */
-  /* the workspace (frame state, bit images, result slots) is single-buffered: an event recorded after every enqueue
-   * orders the next one behind it when the caller switches streams */
-  hipEvent_t lastDone = nullptr;
-  hipStream_t lastStream = nullptr;
-  bool haveLast = false;
   ssd_frame_risers *dRisers = nullptr;      /* vertical faces (extension), allocated by ssd_set_risers */
   ssd_frame_risers *hRisers = nullptr;      /* pinned */
   /* ssd_process_host / ssd_process_depth_host: two device staging buffers, a copy and a compute stream (ssd_capi.hip) */
@@ -43,11 +77,12 @@ struct ssd_handle
   size_t ingestCap = 0;                     /* bytes per buffer */
   hipStream_t ingestCopy = nullptr, ingestCompute = nullptr;
   hipEvent_t ingestCopied[2] = { nullptr, nullptr }, ingestConsumed[2] = { nullptr, nullptr };
+  /* risers of a host-fed batch, slice by slice (the device buffer holds one enqueue's) */
+  ssd_frame_risers *hRisersBatch = nullptr; /* pinned */
+  int hRisersBatchCap = 0, hRisersBatchFrames = 0;
   ssd::DebugFrame *dDebug = nullptr;
   unsigned long long *dDebugImg = nullptr;
   bool debug = false;
-  bool imagesDirty = false;
-  int dirtyFrames = 0;                      /* leading FrameStates whose K1 accumulators may be non-zero (k_peaks clears them) */
   int lastFrames = 0;
   size_t bytes = 0;
   /* per-stage timing: a ring of event sets, one per enqueue, so that a timed loop never has to synchronise */

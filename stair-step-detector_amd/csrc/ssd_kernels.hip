@@ -2613,12 +2613,6 @@ void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameSt
                  int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
-  static const int dynLds = getenv("SSD_K1_DYN_LDS") ? atoi(getenv("SSD_K1_DYN_LDS")) : 0;     /* experiment knob: limits residency */
-  if(dynLds > 0)
-  {
-    hipLaunchKernelGGL(k_hist<kSrcF3Aligned>, grid, dim3(kThreads), dynLds, s, xyz, strideFloats, P.pt, st, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
-    return;
-  }
   if(depth)
     hipLaunchKernelGGL(k_hist<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, tileMasks, tileMaskStride, chunkPoints, *depth);
   else if(aligned16(xyz, strideFloats, P.nPoints))

@@ -66,10 +66,12 @@ int ssd_pipeline_create(const ssd_config *cfg, const ssd_calibration *cal, int d
   ssd_pipeline *p = new ssd_pipeline();
   p->device = device;
   p->depth = depth;
+  ssd_config one = *cfg;
+  one.batches_in_flight = 1;               /* the overlap is across this pipeline's handles: one workspace each */
   for(int k = 0; k < depth; k++)
   {
     ssd_handle *h = nullptr;
-    const int rc = ssd_create(cfg, cal, device, &h);
+    const int rc = ssd_create(&one, cal, device, &h);
     if(rc != SSD_OK)
     {
       ssd_pipeline_destroy(p);

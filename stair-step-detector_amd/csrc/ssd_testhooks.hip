@@ -119,6 +119,28 @@ __global__ void k_hypot(const double *a, const double *b, double *out, int n)
     out[i] = hypot_ref(a[i], b[i]);
 }
 
+/* measurement hook: a plain read stream (tools/loadbench.hip, variant C: every wave reads 3 KiB contiguously as three 16-byte
+ * loads per lane, 1024 "points" of 12 bytes per block iteration, chunk bytes per block) — what the memory system of this GPU
+ * delivers right now, to put beside K1's time on the same buffer (bench.py: roofline.k1_over_plain_stream) */
+__global__ __launch_bounds__(256) void k_stream_read(const float4 *__restrict__ p, size_t nVec, int chunkVec, float *out)
+{
+  const size_t begin = static_cast<size_t>(blockIdx.x) * chunkVec, end = begin + chunkVec < nVec ? begin + chunkVec : nVec;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float acc = 0.0f;
+  for(size_t i0 = begin; i0 < end; i0 += 768)                 /* 768 float4 = 1024 points of 12 bytes */
+  {
+    const size_t q = i0 + 192 * wave;
+    float4 a = { 0, 0, 0, 0 }, b = a, c = a;
+    if(q + 192 <= end)
+    {
+      a = p[q + lane]; b = p[q + 64 + lane]; c = p[q + 128 + lane];
+    }
+    acc += a.x * 1.0001f + a.y * 0.5f + a.z + a.w * 1.0001f + b.x * 0.5f + b.y + b.z * 1.0001f + b.w * 0.5f + c.x + c.y * 1.0001f + c.z * 0.5f + c.w;
+  }
+  if(acc == 1234.5f)
+    out[0] = acc;
+}
+
 } // namespace ssd
 
 extern "C"
@@ -153,7 +175,7 @@ long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, 
   const size_t n = cap < sizeof(FrameState) ? cap : sizeof(FrameState);
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, h->dState + frame, n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, h->lane[h->lastLane].dState + frame, n, hipMemcpyDeviceToHost));
   return static_cast<long long>(n);
 }
 
@@ -357,5 +379,34 @@ int ssd_test_hypot_device(int device, const double *a, const double *b, double *
   return SSD_OK;
 }
 
+int ssd_test_stream_read(int device, const void *d_ptr, size_t bytes, int reps, void *stream, float *ms_avg)
+{
+  if(!d_ptr || !ms_avg || reps < 1 || bytes < 12288 || (reinterpret_cast<uintptr_t>(d_ptr) & 15u) != 0)
+    return fail(SSD_E_ARG, "ssd_test_stream_read: bad argument (16-byte aligned buffer of >= 12288 bytes)");
+  if(device_count() <= 0)
+    return fail(SSD_E_NODEVICE, "ssd_test_stream_read: no HIP device");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t nVec = bytes / 12288 * 768;                    /* whole block iterations only */
+  const int chunkVec = 768 * 32;                              /* 32 iterations per block, as K1's chunks */
+  const unsigned int blocks = static_cast<unsigned int>((nVec + chunkVec - 1) / chunkVec);
+  float *out = nullptr;
+  HIP_TRY(hipMalloc(&out, 16));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k_stream_read, dim3(blocks), dim3(256), 0, s, static_cast<const float4 *>(d_ptr), nVec, chunkVec, out);
+  HIP_TRY(hipEventRecord(e0, s));
+  for(int r = 0; r < reps; r++)
+    hipLaunchKernelGGL(k_stream_read, dim3(blocks), dim3(256), 0, s, static_cast<const float4 *>(d_ptr), nVec, chunkVec, out);
+  HIP_TRY(hipEventRecord(e1, s));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.0f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  *ms_avg = ms / static_cast<float>(reps);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(out);
+  return SSD_OK;
+}
 
 } // extern "C"

@@ -1,6 +1,8 @@
-"""Generates tests/golden/ref_serialize.json and ref_quadtest.json by running the REAL reference code
-(oracle/_ref/libssd_ref.so = /root/reference/stairs.cpp + quadrilateralTest.cpp compiled in place by
-oracle/Makefile) on seeded inputs.  Run in the build container (needs /root/reference):
+"""Generates tests/golden/ref_serialize.json, ref_quadtest.json, ref_configuration.json and ref_print_stairs.json by running
+the REAL reference code on seeded inputs: oracle/_ref/libssd_ref.so (= /root/reference/stairs.cpp + quadrilateralTest.cpp +
+configuration.h compiled in place by oracle/Makefile), and /root/reference/print-stairs.py — the reference's own consumer of
+the stdout line — run as a subprocess where it lies, fed the lines of tests/golden/oracle_goldens.json on stdin.
+Run in the build container (needs /root/reference):
 
     make -C oracle && python tests/golden/make_ref_goldens.py
 
@@ -90,6 +92,24 @@ def main():
         json.dump(out_q, f, indent=0)
     print("serialize cases:", len(out_ser), "quad cases:", len(out_q), "throwing:", sum(1 for c in out_q if c["rc"] != 0),
           {c["rc"] for c in out_q})
+
+    # configuration.h:27-52, default-constructed by the reference's own compiler-generated constructor
+    vals, wh = ref.configuration()
+    names = ["x_min", "x_max", "y_min", "y_max", "z_min", "z_max", "height_interval", "min_height_above_ground", "min_step_depth"]
+    with open(os.path.join(HERE, "ref_configuration.json"), "w") as f:
+        json.dump({"what": "stairs::Configuration{} of /root/reference/configuration.h:27-52 (doubles as hex)",
+                   "values": {n: float(v).hex() for n, v in zip(names, vals)}, "depth_stream": {"width": wh[0], "height": wh[1]}}, f, indent=1)
+
+    # print-stairs.py:53-77 — the reference's terminal consumer of the line: what IT reads out of each golden line
+    import subprocess
+    gold = json.load(open(os.path.join(HERE, "oracle_goldens.json")))["frames"]
+    lines = [(name, fr["line"]) for name, fr in sorted(gold.items()) if fr.get("line")]
+    proc = subprocess.run([sys.executable, "/root/reference/print-stairs.py"], input="".join(l + "\n" for _, l in lines),
+                          capture_output=True, text=True, check=True)
+    with open(os.path.join(HERE, "ref_print_stairs.json"), "w") as f:
+        json.dump({"what": "stdout of /root/reference/print-stairs.py (run unmodified, where it lies) fed the golden lines below, one per line, on stdin",
+                   "frames": [n for n, _ in lines], "stdin_lines": [l for _, l in lines], "stdout": proc.stdout}, f, indent=1)
+    print("configuration:", dict(zip(names, vals)), wh, "| print-stairs.py: %d lines in, %d bytes out" % (len(lines), len(proc.stdout)))
 
 
 if __name__ == "__main__":

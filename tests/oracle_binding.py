@@ -191,6 +191,15 @@ class Ref:
         lib.ssdref_serialize.argtypes = [C.c_int, C.c_void_p, C.c_char_p, C.c_int]
         lib.ssdref_quad_test.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         lib.ssdref_load_triangle.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(C.c_int)]
+        lib.ssdref_configuration.argtypes = [C.c_void_p, C.c_void_p]
+        lib.ssdref_configuration.restype = None
+
+    def configuration(self):
+        """the reference's default-constructed Configuration (configuration.h:27-52) -> (9 doubles, (width, height))"""
+        out = np.zeros(9)
+        wh = np.zeros(2, dtype=np.int32)
+        self.lib.ssdref_configuration(out.ctypes.data_as(C.c_void_p), wh.ctypes.data_as(C.c_void_p))
+        return out, (int(wh[0]), int(wh[1]))
 
     def serialize(self, steps_ext):
         s = np.ascontiguousarray(steps_ext, dtype=np.float64).reshape(-1, 9)

@@ -62,7 +62,7 @@ def test_struct_layouts_match_the_header(ssd):
     assert C.sizeof(ssd.Step) == 72
     assert C.sizeof(ssd.FrameResult) == 8 + 72 * ssd.MAX_STEPS
     assert C.sizeof(ssd.Calibration) == 19 * 8
-    assert C.sizeof(ssd.Config) == 8 + 9 * 8 + 8
+    assert C.sizeof(ssd.Config) == 8 + 9 * 8 + 8 + 8          # 3 trailing int32 + padding to 8
     assert C.sizeof(ssd.Scene) % 8 == 0
     assert C.sizeof(ssd.Riser) == 8 + 7 * 8
     assert C.sizeof(ssd.FrameRisers) == 8 + C.sizeof(ssd.Riser) * (ssd.MAX_STEPS - 1)
@@ -220,6 +220,20 @@ def test_create_rejects_ranges_the_fixed_point_mean_cannot_hold(ssd):
         assert b"2^23" in ssd.lib().ssd_last_error()
 
 
+def _consumer_reads(line):
+    """What the reference's consumers take out of one stdout line, restated: ros/stair_step_detector_pkg/.../stair_step_detector.py:33-56
+    (ident, count, then per step height = step[0][1] and the corners step[1][1..4] as x, y) — print-stairs.py:55-71 indexes the
+    same way.  -> (ident, count, [(height, [(x, y) x 4])])"""
+    import json
+    jdata = json.loads(line)
+    ident, count = jdata[0], jdata[1][1]
+    steps = []
+    if count > 0:
+        for step in jdata[2]:
+            steps.append((step[0][1], [(step[1][k][0], step[1][k][1]) for k in (1, 2, 3, 4)]))
+    return ident, count, steps
+
+
 def test_wire_format_parses_like_the_ros_node(ssd, oracle):
     """ros/stair_step_detector_pkg/.../stair_step_detector.py:34-61 and print-stairs.py:55-71 index the line like this."""
     import json
@@ -233,8 +247,73 @@ def test_wire_format_parses_like_the_ros_node(ssd, oracle):
     assert jdata[0] == "stairs" and jdata[1][1] == 2
     assert jdata[2][1][0][1] == pytest.approx(0.17)
     assert [len(jdata[2][0][1][k]) for k in range(1, 5)] == [2, 2, 2, 2]
+    ident, count, steps = _consumer_reads(ssd.Stairs(fr).serialize())
+    assert (ident, count) == ("stairs", 2) and steps[1][0] == pytest.approx(0.17)
+    assert steps[0][1] == [(pytest.approx(0.1 * (2 * k) - 0.35, abs=5e-4), pytest.approx(0.1 * (2 * k + 1) - 0.35, abs=5e-4)) for k in range(4)]
     fr.n_steps = 0
     assert json.loads(ssd.Stairs(fr).serialize()) == ["stairs", ["stairSteps", 0]]
+
+
+def test_the_references_own_consumer_reads_the_same_numbers(ssd):
+    """Reference pin of the wire format's CONSUMER side: tests/golden/ref_print_stairs.json holds
+    what /root/reference/print-stairs.py — run unmodified as a subprocess in the build container (tests/golden/make_ref_goldens.py) —
+    printed for the 69 golden lines.  print-stairs.py:53-77 draws every step (last one first) as its height and the corners
+    quadri[3], quadri[4], quadri[1], quadri[2] at fixed terminal positions, each number as `6.3f`.  The hand-restated indexing
+    above (_consumer_reads, the ROS node's) must pull exactly those numbers out of the same lines, and ssd_serialize must print
+    those lines from the numbers (round trip)."""
+    import json
+    import re
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_print_stairs.json")))
+    screens = fx["stdout"].split("\x1b[1;1H")[1:]
+    assert len(screens) == len(fx["stdin_lines"]) == 69
+    number = re.compile(r"\x1b\[(\d+);(\d+)H([ -]?\d+\.\d{3})(?![\d])")
+    seen_steps = 0
+    for line, screen in zip(fx["stdin_lines"], screens):
+        ident, count, steps = _consumer_reads(line)
+        head = re.match(r"(\w+), number of stair steps: (\d+)\n", screen)
+        assert head and head.group(1) == ident == "stairs" and int(head.group(2)) == count
+        drawn = number.findall(screen)
+        assert len(drawn) == 9 * count
+        top = 4
+        for i in range(count - 1, -1, -1):                      # the terminal shows the highest step first
+            height, quad = steps[i]
+            got = {(int(r), int(c)): txt for r, c, txt in drawn[9 * (count - 1 - i):9 * (count - i)]}
+            want = {(top + 2, 13): height, (top, 3): quad[2][0], (top + 1, 3): quad[2][1], (top, 23): quad[3][0], (top + 1, 23): quad[3][1],
+                    (top + 3, 3): quad[0][0], (top + 4, 3): quad[0][1], (top + 3, 23): quad[1][0], (top + 4, 23): quad[1][1]}
+            assert set(got) == set(want), (line, i)
+            for pos, v in want.items():
+                assert got[pos] == "%6.3f" % v, (line, i, pos)
+            top += 7
+            seen_steps += 1
+        # and back: the numbers the consumer read, through ssd_serialize, give the line again
+        fr = ssd.FrameResult()
+        fr.n_steps = count
+        for i, (height, quad) in enumerate(steps):
+            fr.steps[i].height = height
+            for k in range(4):
+                fr.steps[i].quad[2 * k], fr.steps[i].quad[2 * k + 1] = quad[k]
+        assert ssd.Stairs(fr).serialize() == line
+    assert seen_steps > 200
+
+
+def test_default_config_is_the_references_configuration(ssd, oracle):
+    """Reference pin of configuration.h:27-52: ssd_default_config (and the oracle's) against stairs::Configuration{} as the
+    reference's own header defines it — compiled into oracle/_ref (live, where that exists) and as the committed golden
+    tests/golden/ref_configuration.json (made by tests/golden/make_ref_goldens.py from the same call)."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_configuration.json")))
+    names = ["x_min", "x_max", "y_min", "y_max", "z_min", "z_max", "height_interval", "min_height_above_ground", "min_step_depth"]
+    want = [float.fromhex(gold["values"][n]) for n in names]
+    W, H = gold["depth_stream"]["width"], gold["depth_stream"]["height"]
+    assert (W, H) == (640, 480)
+    r = ob.load_ref()
+    if r is not None:
+        vals, wh = r.configuration()
+        assert [float(v).hex() for v in vals] == [gold["values"][n] for n in names] and wh == (W, H)
+    cfg = ssd.default_config(W, H)
+    assert [getattr(cfg, n) for n in names] == want and (cfg.width, cfg.height) == (W, H)
+    ocfg = oracle.config(W, H)
+    assert [getattr(ocfg, n) for n in names] == want and (ocfg.width, ocfg.height) == (W, H)
 
 
 def test_host_generator_is_deterministic_and_plausible(ssd):

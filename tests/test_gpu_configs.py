@@ -33,17 +33,52 @@ def test_config3_full_batch(ssd, oracle, gpu_device):
     buf = ssd.DeviceBuffer(W * H * 12 * n, gpu_device)
     ssd.synth_device(sc_list, buf.ptr, device=gpu_device)
     det = ssd.Detector(cfg, trans, gpu_device)
+    assert det.batches_in_flight == 3                  # the default for batches: three workspaces used in turn
     det.enqueue(buf.ptr, n)
     r1 = det.fetch_list(n)
     for i in range(n):
         hist, n_nonzero, n_inrange = _state_counts(ssd, det, i)
         assert int(hist.sum()) == n_inrange <= n_nonzero <= W * H, "frame %d" % i
         assert n_inrange > W * H // 4, "frame %d: implausibly few points in range" % i
-    det.enqueue(buf.ptr, n)
-    r2 = det.fetch_list(n)
-    assert [bytes(x) for x in r1] == [bytes(x) for x in r2]
+    for _ in range(3):                                 # the other two workspaces, then the first one again
+        det.enqueue(buf.ptr, n)
+        r2 = det.fetch_list(n)
+        assert [bytes(x) for x in r1] == [bytes(x) for x in r2]
     rep = {}
     for i in range(0, n, 64):
+        parity.check_results_only(ssd, oracle, cfg, trans.constants, ssd.synth_host([sc_list[i]])[0], r1[i], rep)
+    assert rep.get("max_corner_err", 0.0) == 0.0 and rep.get("max_height_err", 0.0) <= parity.TOL_HEIGHT
+    assert sum(1 for r in r1 if r.n_steps >= 3) >= n * 9 // 10
+    det.close()
+    buf.free()
+
+
+def test_config4_rank_share(ssd, oracle, gpu_device):
+    """BASELINE configs[3] (SURVEY.md section 8(d) "config 4": 16,384 frames over 8 GPUs) at the size ONE rank gets: 2048 XGA
+    frames resident in HBM (19.3 GB), max_frames_per_batch = 2048, one batch per call (grid.x = 2048, ~49 k blocks per streaming
+    kernel, 3.6 GB per workspace).  The frames are rank 0's of that run (bench.py --gpus 8 --frames 2048).  Every 128th frame
+    against the oracle; four calls (every workspace, the first one twice) bitwise equal; histogram mass = in-range count
+    <= non-zero count <= W H for all 2048 frames."""
+    n, W, H = 2048, 1024, 768
+    sc_list = scenes.batch_scenes(ssd, W, H, n, base_seed=100000, rng_seed=1000)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    cfg = ssd.default_config(W, H, max_frames_per_batch=n)
+    buf = ssd.DeviceBuffer(W * H * 12 * n, gpu_device)
+    ssd.synth_device(sc_list, buf.ptr, device=gpu_device)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    assert det.batches_in_flight == 3
+    det.enqueue(buf.ptr, n)
+    r1 = det.fetch_list(n)
+    for i in range(n):
+        hist, n_nonzero, n_inrange = _state_counts(ssd, det, i)
+        assert int(hist.sum()) == n_inrange <= n_nonzero <= W * H, "frame %d" % i
+        assert n_inrange > W * H // 4, "frame %d: implausibly few points in range" % i
+    for _ in range(3):
+        det.enqueue(buf.ptr, n)
+        r2 = det.fetch_list(n)
+        assert [bytes(x) for x in r1] == [bytes(x) for x in r2]
+    rep = {}
+    for i in range(0, n, 128):
         parity.check_results_only(ssd, oracle, cfg, trans.constants, ssd.synth_host([sc_list[i]])[0], r1[i], rep)
     assert rep.get("max_corner_err", 0.0) == 0.0 and rep.get("max_height_err", 0.0) <= parity.TOL_HEIGHT
     assert sum(1 for r in r1 if r.n_steps >= 3) >= n * 9 // 10
@@ -104,6 +139,39 @@ def test_bench_runs_two_ranks_on_this_gpu():
     assert "cpu_baseline" not in d                      # reported at N = 1 only
 
 
+def test_bench_config4_two_ranks_at_their_full_share_on_this_gpu():
+    """BASELINE configs[3] as far as one GPU can carry it: 2 of the 8 ranks, each with its full share of 2048 XGA frames
+    (19.3 GB of frames + 3 x 3.6 GB of workspaces per rank, both on this one device via SSD_BENCH_DEVICE=0).  Frame ranges
+    [0, 2048) and [2048, 4096) of the global index space, each rank's own frames checked against the oracle, per-rank stage
+    times and K1's fraction of the HBM peak in the line, the workload named as configs[3]."""
+    env = dict(os.environ, SSD_BENCH_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "2048", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_gpu_per_step"] == 2048
+    assert d["config"]["workload"].startswith("BASELINE configs[3]: 4096-frame batch frame-sharded over 2 GPUs")
+    assert d["config"]["batches_in_flight"] == 3
+    ranks = sorted(d["ranks"], key=lambda r: r["rank"])
+    assert [r["frames"] for r in ranks] == [[0, 2048], [2048, 4096]] and [r["device"] for r in ranks] == [0, 0]
+    for r in ranks:
+        assert r["parity"]["frames_checked_against_oracle"] == 5
+        assert r["parity"]["max_abs_corner_err_m"] == 0.0 and r["parity"]["max_abs_height_err_m"] <= parity.TOL_HEIGHT
+        assert r["steps_found"] >= 2048 * 3                       # ground + >= 3 steps in nearly every frame
+        assert set(r["stage_ms"]) == {"hist", "peaks", "raster", "outline", "quads", "inquad", "final"}
+        assert all(v > 0.0 for v in r["stage_ms"].values()) and 0.0 < r["k1_frac_of_hbm_peak"] < 1.0
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["algorithmic_bytes_per_launch"] == 12.0 * 1024 * 768 * 2048
+    assert d["value"] == pytest.approx(2 * 2048 * 3 / (d["ms_per_step"] * 3 * 1e-3), rel=1e-6)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):                                         # kept for profiles/ (the builder copies it)
+        with open(os.path.join(out, "config4_two_ranks_one_gpu.json"), "w") as f:
+            f.write(lines[0] + "\n")
+
+
 def test_bench_refuses_two_ranks_without_two_gpus():
     """without the override, 2 ranks on a 1-GPU box must fail loudly instead of printing a line"""
     import importlib
@@ -127,6 +195,10 @@ def test_native_driver_shards_frames_over_device_threads(ssd):
     assert sharded.stdout.splitlines() == single and len(single) == 10
     assert "3 device shard(s)" in sharded.stderr
     assert all(l.startswith('["stairs",["stairSteps",4]') for l in single)
+    assert sharded.stderr.count("resident frames x 1 pass(es)") == 3 and "generation outside the timed region" in sharded.stderr
+    # more shards than frames (empty shards are skipped), and several passes over the resident frames
+    few = subprocess.run(args[:6] + ["2"] + args[7:] + ["--device-list", "0,0,0", "--passes", "3"], check=True, capture_output=True, text=True, timeout=600)
+    assert few.stdout.splitlines() == single[:2] and few.stderr.count("resident frames x 3 pass(es)") == 2
     bad = subprocess.run(args + ["--device-list", "0,7"], capture_output=True, text=True, timeout=600)
     if ssd.device_count() < 8:
         assert bad.returncode != 0 and "not present" in bad.stderr
@@ -204,6 +276,97 @@ def test_calls_on_different_streams_are_ordered_by_the_library(ssd, oracle, gpu_
     b.free()
     for st in streams:
         hip.hipStreamDestroy(st)
+
+
+def test_handle_keeps_three_batches_in_flight(ssd, oracle, gpu_device):
+    """ssd_config::batches_in_flight: a handle with three workspaces takes them in turn on streams of its own.  Nine batches of
+    different frames and sizes are enqueued two ahead of the fetches (ssd_fetch_back(back = 2)); in between, calls that the
+    library holds in the first workspace — debug capture, the riser pass, a partial run (ssd_enqueue_stages) — are mixed in
+    without any host synchronisation.  Every batch must equal, bytewise, what a one-workspace handle (strict stream order)
+    returns for it, risers and debug records included; every 9th frame the oracle's.  ssd_stream_wait orders a producer
+    that overwrites a batch's frames behind that batch."""
+    import ctypes as C
+    W, H, cap = 640, 480, 40
+    sizes = [40, 17, 40, 33, 40, 8, 40, 25, 40]
+    sc_list = scenes.batch_scenes(ssd, W, H, sum(sizes), base_seed=71000, rng_seed=13)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    fb = W * H * 12
+    buf = ssd.DeviceBuffer(fb * sum(sizes), gpu_device)
+    ssd.synth_device(sc_list, buf.ptr, device=gpu_device)
+    host = ssd.synth_host(sc_list)
+    starts = [sum(sizes[:i]) for i in range(len(sizes))]
+    one = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=cap, batches_in_flight=1), trans, gpu_device)
+    assert one.batches_in_flight == 1
+    want = []
+    for at, n in zip(starts, sizes):
+        one.enqueue(buf.ptr + at * fb, n)
+        want.append([bytes(r) for r in one.fetch(n)])
+    one.set_risers(True, 0.03, 200)
+    one.enqueue(buf.ptr + starts[3] * fb, sizes[3])
+    one.fetch(sizes[3])
+    want_risers = [bytes(r) for r in one.fetch_risers(sizes[3])]
+    one.set_risers(False)
+    one.set_debug(True)
+    one.enqueue(buf.ptr + starts[5] * fb, sizes[5])
+    one.fetch(sizes[5])
+    want_dbg = bytes(one.debug(sizes[5] - 1))
+    one_ws = one.workspace_bytes
+    one.close()
+
+    det = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=cap, batches_in_flight=3), trans, gpu_device)
+    assert det.batches_in_flight == 3 and det.workspace_bytes > 2.5 * one_ws
+    for rep in range(2):
+        got = [None] * len(sizes)
+        for i, (at, n) in enumerate(zip(starts, sizes)):
+            det.enqueue(buf.ptr + at * fb, n)
+            if i >= 2:
+                got[i - 2] = [bytes(r) for r in det.fetch(sizes[i - 2], back=2)]
+        got[-2] = [bytes(r) for r in det.fetch(sizes[-2], back=1)]
+        got[-1] = [bytes(r) for r in det.fetch(sizes[-1], back=0)]
+        assert got == want, "round %d" % rep
+        # calls held in the first workspace, straight behind free-running ones and followed by free-running ones
+        det.enqueue(buf.ptr + starts[0] * fb, sizes[0])
+        det.enqueue(buf.ptr + starts[1] * fb, sizes[1])
+        det.set_risers(True, 0.03, 200)
+        det.enqueue(buf.ptr + starts[3] * fb, sizes[3])
+        det.set_risers(False)
+        det.enqueue(buf.ptr + starts[2] * fb, sizes[2])
+        assert [bytes(r) for r in det.fetch(sizes[3], back=1)] == want[3]
+        assert [bytes(r) for r in det.fetch(sizes[2], back=0)] == want[2]
+        assert [bytes(r) for r in det.fetch(sizes[1], back=2)] == want[1]
+        det.set_risers(True, 0.03, 200)
+        det.enqueue(buf.ptr + starts[3] * fb, sizes[3])
+        assert [bytes(r) for r in det.fetch_risers(sizes[3])] == want_risers
+        det.set_risers(False)
+        det.enqueue(buf.ptr + starts[4] * fb, sizes[4])
+        det.set_debug(True)
+        det.enqueue(buf.ptr + starts[5] * fb, sizes[5])
+        assert [bytes(r) for r in det.fetch(sizes[5])] == want[5]
+        assert bytes(det.debug(sizes[5] - 1)) == want_dbg
+        det.set_debug(False)
+        det.enqueue(buf.ptr + starts[6] * fb, sizes[6], stages=ssd.STAGE_HIST)          # K1 alone: leaves accumulators behind
+        det.enqueue(buf.ptr + starts[7] * fb, sizes[7])
+        det.enqueue(buf.ptr + starts[8] * fb, sizes[8])
+        assert [bytes(r) for r in det.fetch(sizes[7], back=1)] == want[7]
+        assert [bytes(r) for r in det.fetch(sizes[8], back=0)] == want[8]
+    flat = [r for w in want for r in w]
+    for i in range(0, len(flat), 9):
+        parity.check_results_only(ssd, oracle, det.cfg, trans.constants, host[i], ssd.FrameResult.from_buffer_copy(flat[i]))
+    # a producer that recycles a batch's frame buffer: ordered behind the batch by ssd_stream_wait, no host synchronisation
+    hip = C.CDLL("libamdhip64.so")
+    st = C.c_void_p()
+    assert hip.hipStreamCreateWithFlags(C.byref(st), 1) == 0
+    scratch = ssd.DeviceBuffer(fb * cap, gpu_device)
+    for rep in range(3):
+        ssd.synth_device(sc_list[starts[0]:starts[0] + cap], scratch.ptr, device=gpu_device, stream=st.value)
+        det.enqueue(scratch.ptr, cap, stream=st.value)
+        det.stream_wait(0, st.value)
+        assert hip.hipMemsetAsync(C.c_void_p(scratch.ptr), 0, C.c_size_t(fb * cap), st) == 0       # the "next producer"
+        assert [bytes(r) for r in det.fetch(cap)] == want[0]
+    hip.hipStreamDestroy(st)
+    scratch.free()
+    det.close()
+    buf.free()
 
 
 def test_pipeline_overlaps_batches_and_returns_them_in_order(ssd, oracle, gpu_device):
