@@ -310,13 +310,15 @@ typedef struct
   ssd_debug_plateau plateaus[SSD_MAX_PLATEAUS];
 } ssd_debug_frame;
 
-/* Enables debug capture for subsequent enqueues (costs memory and time; off by default). */
+/* Enables debug capture for subsequent enqueues (costs memory and time; off by default).  enable = 1: the records below and
+ * the raw / closed images (for which the whole ground image is rastered, not only the pixel strips the bottom scan reads);
+ * enable = 2: the records only — the kernels run exactly as without capture and report their intermediates; 0: off. */
 int ssd_set_debug(ssd_handle *h, int enable);
 /* Copies the debug record of frame `frame` of the last batch. */
 int ssd_get_debug(ssd_handle *h, int frame, ssd_debug_frame *out);
 /* Raw (pre-close) and closed plateau images of the last batch as H x W bytes (0 / 0xff), like the
  * reference's cv::Mat.  step_slot = index among the step plateaus, or -1 for the ground image.
- * Only valid when debug capture was enabled for the batch. */
+ * Only valid when capture with images (ssd_set_debug(h, 1)) was on for the batch. */
 int ssd_get_debug_image(ssd_handle *h, int frame, int step_slot, int closed, uint8_t *out);
 
 /* pinned (page-locked) host memory for frames handed to ssd_process_host / ssd_process_depth_host */

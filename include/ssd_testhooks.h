@@ -42,6 +42,10 @@ int ssd_test_grid_boxes_device(int device, const double quad[8], double x_min, d
  * sizeof state, offsets of hist, lut, image boxes, plateau table, quadrilateral tests, sums, counts); returns the
  * number of bytes copied or a negative error */
 long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, long long layout[8]);
+/* test hook: the ground bit image of one frame as it lies in the workspace of the last enqueue, as height x width bytes (0 / 0xff).
+ * After a full enqueue it is all zero (k_final clears what it read); after ssd_enqueue_stages(.. up to SSD_STAGE_INQUAD) it
+ * holds what k_inquad rastered: outside image capture only the pixel strips the bottom scan reads */
+int ssd_test_ground_image(ssd_handle *h, int frame, uint8_t *out);
 
 /* measurement hook (bench.py, tools/clockstate.py): average milliseconds of `reps` launches of a plain 16-byte-per-lane read
  * stream over `bytes` bytes at d_ptr (tools/loadbench.hip variant C) on `stream` — what the memory system delivers right now */

@@ -141,7 +141,7 @@ SOURCE_EXPORTS = [
 ]
 # libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
 HOOK_EXPORTS = [
-    "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_best_line_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
+    "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_ground_image", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_best_line_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
     "ssd_test_sort_device", "ssd_test_stream_read", "ssd_testhooks_last_error",
 ]
 SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
@@ -255,6 +255,7 @@ def hooks_lib():
     L.ssd_test_quad_host.restype = i32
     L.ssd_test_frame_state.argtypes = [vp, i32, vp, C.c_size_t, vp]
     L.ssd_test_frame_state.restype = C.c_longlong
+    L.ssd_test_ground_image.argtypes = [vp, i32, vp]
     L.ssd_test_sort_host.argtypes = [vp, i32, vp]
     L.ssd_test_sort_device.argtypes = [i32, vp, i32, vp]
     L.ssd_test_quad_device.argtypes = [i32, vp, vp, i32, vp, C.POINTER(C.c_int)]
@@ -435,8 +436,10 @@ class Detector:
         _check(lib().ssd_get_stage_times_back(self._h, back, ms))
         return dict(zip(STAGE_NAMES, [float(x) for x in ms]))
 
-    def set_debug(self, on=True):
-        _check(lib().ssd_set_debug(self._h, 1 if on else 0))
+    def set_debug(self, on=True, images=True):
+        """debug capture: records + images (the whole ground image is rastered for it), or records only (images=False:
+        the kernels run exactly as in production)"""
+        _check(lib().ssd_set_debug(self._h, (1 if images else 2) if on else 0))
 
     def debug(self, frame=0):
         d = DebugFrame()
@@ -450,6 +453,12 @@ class Detector:
         n = _check(hooks_lib().ssd_test_frame_state(self._h, frame, buf, len(buf), lay), "hooks")
         names = ("size", "hist", "lut", "boxes", "plateaus", "quad_tests", "sum_z", "cnt")
         return buf.raw[:n], dict(zip(names, [int(x) for x in lay]))
+
+    def ground_image_raw(self, frame):
+        """test hook: the ground bit image as it lies in the last enqueue's workspace (height x width bytes)"""
+        out = np.empty((self.cfg.height, self.cfg.width), dtype=np.uint8)
+        _check(hooks_lib().ssd_test_ground_image(self._h, frame, out.ctypes.data_as(C.c_void_p)), "hooks")
+        return out
 
     def debug_image(self, frame, step_slot, closed):
         out = np.empty((self.cfg.height, self.cfg.width), dtype=np.uint8)

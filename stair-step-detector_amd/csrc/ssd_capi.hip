@@ -517,7 +517,7 @@ int ssd_set_debug(ssd_handle *h, int enable)
     h->dDebugImg = di;
     h->bytes += sizeof(DebugFrame) * h->F + imgBytes;
   }
-  h->debug = enable != 0;
+  h->debug = enable == 0 ? 0 : enable == 2 ? 2 : 1;
   return SSD_OK;
 }
 
@@ -662,13 +662,14 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
       return fail(SSD_E_ARG, "ssd_enqueue: frame pointer must be 4-byte aligned");
   }
   HIP_TRY(hipSetDevice(h->device));
-  const Params &P = h->P;
+  Params P = h->P;
+  P.px.groundFull = h->debug == 1 ? 1 : 0;     /* image capture compares the whole ground image; otherwise only what k_final reads is rastered */
   /* Which workspace.  A handle with one runs on the caller's stream (a switch of streams is ordered by the lane's event: the
    * workspace is single-buffered).  With several, successive batches take them in turn, each on the lane's own stream behind
    * an event recorded on the caller's stream now: the batch starts after the work the caller's stream holds, but the caller's
    * stream does not wait for the batch (ssd_fetch* / ssd_stream_wait do).  Debug capture, the riser pass and partial runs
    * (ssd_enqueue_stages) own single buffers / leave state behind for the next call: they stay in lane 0. */
-  const bool pinned = h->debug || P.risers || stages != SSD_STAGE_ALL;
+  const bool pinned = h->debug != 0 || P.risers || stages != SSD_STAGE_ALL;
   const int li = h->depth == 1 || pinned ? 0 : static_cast<int>(h->laneTurn++ % static_cast<unsigned long long>(h->depth));
   ssd_lane &L = h->lane[li];
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -730,7 +731,7 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
     if(t4 * kTileHost > chunkInquad) chunkInquad = t4 * kTileHost;
   }
   DebugFrame *dbg = h->debug ? h->dDebug : nullptr;
-  unsigned long long *dbgImg = h->debug ? h->dDebugImg : nullptr;
+  unsigned long long *dbgImg = h->debug == 1 ? h->dDebugImg : nullptr;
   const bool timing = h->timing && !h->ev.empty();
   int evi = static_cast<int>(h->enqueueCount % SSD_TIMING_SLOTS) * 8;
   auto mark = [&]() { if(timing) (void)hipEventRecord(h->ev[evi++], s); };
@@ -1135,8 +1136,8 @@ int ssd_get_debug_image(ssd_handle *h, int frame, int step_slot, int closed, uin
 {
   if(!h || !out)
     return fail(SSD_E_ARG, "ssd_get_debug_image: null");
-  if(!h->dDebugImg || frame < 0 || frame >= h->lastFrames || step_slot < -1 || step_slot >= h->P.maxStepImages)
-    return fail(SSD_E_ARG, "ssd_get_debug_image: debug capture off or index out of range");
+  if(!h->dDebugImg || h->debug != 1 || frame < 0 || frame >= h->lastFrames || step_slot < -1 || step_slot >= h->P.maxStepImages)
+    return fail(SSD_E_ARG, "ssd_get_debug_image: image capture off (ssd_set_debug(h, 1)) or index out of range");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
   const int slot = step_slot < 0 ? h->P.maxStepImages : step_slot;

@@ -50,6 +50,8 @@ struct PixelParams
   int winShiftGround;                         /* the same for the ground image of k_inquad */
   int cellCols;                               /* cells (64 consecutive points) per camera row, rounded: cells this far apart are
                                                  vertical neighbours in the camera image (order of the kernels' cell lists) */
+  int groundFull;                             /* k_inquad rasters every ground pixel (debug capture: the whole image is compared);
+                                                 0 = only the pixels k_final's bottom scan can see (ground_strip_pixel) */
 };
 
 /* what the 16-bit depth source needs beside the depth image: rs2::pointcloud's pre-computed maps

@@ -82,7 +82,7 @@ struct ssd_handle
   int hRisersBatchCap = 0, hRisersBatchFrames = 0;
   ssd::DebugFrame *dDebug = nullptr;
   unsigned long long *dDebugImg = nullptr;
-  bool debug = false;
+  int debug = 0;                  /* 0 off, 1 records + images (the whole ground image is rastered for it), 2 records only */
   int lastFrames = 0;
   size_t bytes = 0;
   /* per-stage timing: a ring of event sets, one per enqueue, so that a timed loop never has to synchronise */

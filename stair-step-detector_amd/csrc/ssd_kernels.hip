@@ -35,6 +35,45 @@ __device__ unsigned long long g_phase[4][32];
 #endif
 #define SSD_PHASE(k, i) SSD_PHASE_IF(threadIdx.x == 0, k, i)
 
+/* Where a block of a streaming kernel spends its life (tools/blockphases.py; the same tools-only build): lane 0 of EVERY wave adds
+ * the wall-clock ticks (100 MHz) between consecutive marks to g_blockphase[kernel][mark]; [kernel][15] counts the waves. */
+#ifdef SSD_PHASE_TIMING
+__device__ unsigned long long g_blockphase[4][64][8];      /* [kernel][copy = blockIdx.x & 63][mark]; [..][7] counts the waves */
+struct BlockPhase
+{
+  unsigned long long t, acc[7];
+  int k;
+  __device__ __forceinline__ BlockPhase(int kernel) : t(wall_clock64()), k(kernel)
+  {
+    for(int i = 0; i < 7; i++) acc[i] = 0ull;
+  }
+  __device__ __forceinline__ void mark(int i)
+  {
+    const unsigned long long now = wall_clock64();
+    acc[i] += now - t;
+    t = now;
+  }
+  /* at the very end: the wave's sums into one of 64 copies (no hot address while the phases are being measured) */
+  __device__ __forceinline__ void finish()
+  {
+    if((threadIdx.x & 63) == 0)
+    {
+      unsigned long long *g = g_blockphase[k][blockIdx.x & 63];
+      for(int i = 0; i < 7; i++)
+        if(acc[i]) atomicAdd(&g[i], acc[i]);
+      atomicAdd(&g[7], 1ull);
+    }
+  }
+};
+#else
+struct BlockPhase
+{
+  __device__ __forceinline__ BlockPhase(int) { }
+  __device__ __forceinline__ void mark(int) { }
+  __device__ __forceinline__ void finish() { }
+};
+#endif
+
 /* ========================================================================= */
 /* shared per-point arithmetic                                                */
 
@@ -885,6 +924,7 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
   const int nImg = fs.nStepImages;
   if(nImg == 0)
     return;
+  BlockPhase ph(0);
   const int firstStep = fs.firstStep;
   if(tid < kMaxBins)
   {
@@ -903,6 +943,7 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
   if(tid < kThreads / 64)
     wavemiss_init(wmiss[tid]);
   __syncthreads();
+  ph.mark(0);
 
   /* strideFloats counts floats, or 16-bit depth values for kSrcDepth16 */
   const float *base = SRC == kSrcDepth16
@@ -935,6 +976,7 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
   const unsigned int wantedSteps = fs.wantedSteps;
   const int count = cell_list_build(tileMasks + static_cast<size_t>(frame) * tileMaskStride + cell0, nCells, X.cellCols,
                                     [&](const uint2 info) { return (info.x & wantedSteps) != 0u; }, cellList, listScratch);
+  ph.mark(1);
   const int nGroups = (count + 3) >> 2;
   int g = (tid >> 6) * nGroups / kWavesPerBlock;
   const int gEnd = ((tid >> 6) + 1) * nGroups / kWavesPerBlock;
@@ -979,12 +1021,15 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
       v[j] = vn[j];
     }
   }
+  ph.mark(2);
   wavewin_flush(ww, win, frameImg, imgWords, X.W64, X.winShift, boxes, lane);
   wavemiss_flush(wm, boxes, lane);
   flushT();
   if(oob)
     atomicAdd(&lOob, oob);
+  ph.mark(5);
   __syncthreads();
+  ph.mark(3);
   if(tid < nImg)
   {
     unsigned long long t = 0;
@@ -1004,6 +1049,8 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
     atomicAdd(&fs.nOob, lOob);
     atomicOr(&fs.status, static_cast<unsigned int>(SSD_ST_OOB_PIXEL));
   }
+  ph.mark(4);
+  ph.finish();
 }
 
 template<int SRC>
@@ -1797,10 +1844,29 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
 /* ========================================================================= */
 /* K4: in-quadrilateral filter, z sums, ground image                           */
 
+/* What of the ground image is ever looked at: detectFrontEdge (segmentation.cpp:879-917) closes it and BottomScanner
+ * (:159-241) probes the pixel columns x_j = W/2 + 50 k bottom-up, stopping at the image centre.  A closed pixel is a function
+ * of the raw 5 x 5 neighbourhood (ssd_closing.h, closed_scan_column), so k_final reads raw pixels only in the columns
+ * x_j - 2 .. x_j + 2 and the rows >= H/2 - 1.  Outside debug capture k_inquad therefore sets just those: a twentieth of the
+ * ground pixels, few enough to go to memory one atomic each — no LDS windows, no flushes, no keys in the production kernel.
+ * (kGroundScanStep = BottomScanner's column distance; the same constants are k_final's.) */
+constexpr int kGroundScanStep = 50;
+__device__ __forceinline__ int ground_scan_x0(int W) { return (W / 2) % kGroundScanStep; }
+__device__ __forceinline__ int ground_strip_row0(int H) { return H / 2 - 1; }
+/* is pixel column ix within two of a scan column x_j = x0 + 50 j, j any integer (also j = -1 and beyond the last scanned
+ * column: k_final clears those strips with the others)?  u / 50 by multiply-high: exact for u < 2^17 */
+__device__ __forceinline__ bool ground_strip_column(int ix, int x0)
+{
+  const unsigned int u = static_cast<unsigned int>(ix + 2 - x0 + kGroundScanStep);       /* >= 3 */
+  const unsigned int r = u - kGroundScanStep * ((u * 1311u) >> 16);
+  return r <= 4u;
+}
+
+template<bool FULL>
 struct InquadLds
 {
-  unsigned long long wins[kThreads / 64][kWinWords];
-  unsigned int wmiss[kThreads / 64][kWaveMissWords];
+  unsigned long long wins[FULL ? kThreads / 64 : 1][FULL ? kWinWords : 1];
+  unsigned int wmiss[FULL ? kThreads / 64 : 1][kWaveMissWords];
   ImageBox box[1];
   QuadTest qts[kMaxLive];                       /* FrameState::qtLive: slot k = accumulator liveAcc[k] */
   QuadGridSegs segs[kMaxLive];                  /* FrameState::segLive */
@@ -1816,15 +1882,15 @@ struct InquadLds
   int nLive, groundSlot;
 };
 
-template<int SRC>
-__device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restrict__ xyz, size_t strideFloats, const PointParams &P,
+template<int SRC, bool FULL>
+__device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__restrict__ xyz, size_t strideFloats, const PointParams &P,
                                              const PixelParams &X, FrameState *__restrict__ st,
                                              unsigned long long *__restrict__ groundImg,
                                              const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, const DepthSrc &D,
                                              const int frame, const int chunkIdx)
 {
-  unsigned long long (&wins)[kThreads / 64][kWinWords] = L.wins;
-  unsigned int (&wmiss)[kThreads / 64][kWaveMissWords] = L.wmiss;
+  auto &wins = L.wins;
+  auto &wmiss = L.wmiss;
   ImageBox (&box)[1] = L.box;
   QuadTest (&qts)[kMaxLive] = L.qts;
   QuadGridSegs (&segs)[kMaxLive] = L.segs;
@@ -1844,6 +1910,7 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
   FrameState &fs = st[frame];
   if(!fs.anyActive)                                         /* block-uniform: set by k_quads */
     return;
+  BlockPhase ph(1);
   if(tid == 0)
   {
     box[0] = ImageBox{ 0x7fffffff, -1, 0x7fffffff, -1 };
@@ -1868,10 +1935,13 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
     (&lsum[0][0])[i] = 0ull;
     (&lcnt[0][0])[i] = 0u;
   }
-  for(int i = tid; i < (kThreads / 64) * kWinWords; i += kThreads)
-    (&wins[0][0])[i] = 0ull;
-  if(tid < kThreads / 64)
-    wavemiss_init(wmiss[tid]);
+  if(FULL)
+  {
+    for(int i = tid; i < (kThreads / 64) * kWinWords; i += kThreads)
+      (&wins[0][0])[i] = 0ull;
+    if(tid < kThreads / 64)
+      wavemiss_init(wmiss[tid]);
+  }
   {
     /* copy the live quadrilateral tests as 32-bit words */
     const unsigned int *src = reinterpret_cast<const unsigned int *>(fs.qtLive);
@@ -1913,6 +1983,7 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
     liveBox[tid] = b;
   }
   __syncthreads();
+  ph.mark(0);                                               /* tables in LDS */
 
   /* strideFloats counts floats, or 16-bit depth values for kSrcDepth16 */
   const float *base = SRC == kSrcDepth16
@@ -1923,9 +1994,13 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
   unsigned long long *gimg = groundImg + static_cast<size_t>(frame) * X.H * X.W64;
   const int copy = lane & 7;
   const unsigned int imgWords = static_cast<unsigned int>(X.H) * X.W64;
-  unsigned long long *ww = wins[tid >> 6];
-  unsigned int *wm = wmiss[tid >> 6];
+  unsigned long long *ww = wins[FULL ? tid >> 6 : 0];
+  unsigned int *wm = wmiss[FULL ? tid >> 6 : 0];
   WaveWindow win;
+  /* strips only (!FULL): the scan columns' offset, the first row of interest, the lane's rows written so far */
+  const int stripX0 = ground_scan_x0(X.W), stripRow0 = ground_strip_row0(X.H);
+  int gy0 = 0x7fffffff, gy1 = -1;
+  unsigned int *gimg32 = reinterpret_cast<unsigned int *>(gimg);
 
   /* calcAverageZ (pointcloud.cpp:574-581) as an order-independent fixed-point sum: a thread walks down a
    * camera column, so consecutive hits nearly always belong to the same quadrilateral — the running sum
@@ -1979,6 +2054,7 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
                                       }
                                       return need;
                                     }, cellList, listScratch);
+  ph.mark(1);                                               /* cell list */
   const int nGroups = (count + 3) >> 2;
   const int gEnd = ((tid >> 6) + 1) * nGroups / kWavesPerBlock;
   /* the loads of the NEXT group issued before the current one is processed (as in k_raster): 0.89 -> 0.86 ms even though
@@ -2024,20 +2100,48 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
         int ix, iy;
         const bool inside = image_pixel(P, X, wx, wy, ix, iy);
         oob += inside ? 0u : 1u;                              /* quirk Q5 */
-        key[j] = inside ? pixel_key(0, iy, ix) : kNoPixel;
+        if(FULL)
+          key[j] = inside ? pixel_key(0, iy, ix) : kNoPixel;
+        else if(inside && iy >= stripRow0 && ground_strip_column(ix, stripX0))
+        {
+          /* one of the few pixels the bottom scan can see: straight to memory */
+          atomicOr(gimg32 + (static_cast<unsigned int>(iy) * (2u * X.W64) + (static_cast<unsigned int>(ix) >> 5)), 1u << (ix & 31));
+          gy0 = min(gy0, iy);
+          gy1 = max(gy1, iy);
+        }
       }
     }
-    wavewin_emit(ww, wm, win, gimg, imgWords, X.W64, X.winShiftGround, box, key, lane);
+    if(FULL)
+      wavewin_emit(ww, wm, win, gimg, imgWords, X.W64, X.winShiftGround, box, key, lane);
 #pragma unroll
     for(int j = 0; j < kPts; j++)
       v[j] = vn[j];
   }
-  wavewin_flush(ww, win, gimg, imgWords, X.W64, X.winShiftGround, box, lane);
-  wavemiss_flush(wm, box, lane);
+  if(FULL)
+  {
+    wavewin_flush(ww, win, gimg, imgWords, X.W64, X.winShiftGround, box, lane);
+    wavemiss_flush(wm, box, lane);
+  }
+  else
+  {
+    /* the rows this wave wrote; all strips of those rows are k_final's to read and to clear (word columns: the whole row) */
+    gy1 = wave_max_i(gy1);
+    if(gy1 >= 0)
+    {
+      gy0 = wave_min_i(gy0);
+      if(lane == 0)
+      {
+        atomicMin(&box[0].yMin, gy0); atomicMax(&box[0].yMax, gy1);
+        atomicMin(&box[0].xMin, 0); atomicMax(&box[0].xMax, X.W64 - 1);
+      }
+    }
+  }
+  ph.mark(2);                                               /* the walk */
   flushAcc();
   if(oob)
     atomicAdd(&lOob, oob);
   __syncthreads();
+  ph.mark(3);                                               /* waiting for the block's other waves */
   if(tid < nLive)
   {
     unsigned long long s = 0;
@@ -2067,16 +2171,18 @@ __device__ __forceinline__ void inquad_block(InquadLds &L, const float *__restri
       atomicOr(&fs.status, static_cast<unsigned int>(SSD_ST_OOB_PIXEL));
     }
   }
+  ph.mark(4);                                               /* sums out */
+  ph.finish();
 }
 
-template<int SRC>
+template<int SRC, bool FULL>
 __global__ __launch_bounds__(kThreads, SSD_K4_WAVES) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                         PixelParams X, FrameState *__restrict__ st,
                                                         unsigned long long *__restrict__ groundImg,
                                                         const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
-  __shared__ InquadLds L;
-  inquad_block<SRC>(L, xyz, strideFloats, P, X, st, groundImg, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
+  __shared__ InquadLds<FULL> L;
+  inquad_block<SRC, FULL>(L, xyz, strideFloats, P, X, st, groundImg, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
 }
 
 /* ========================================================================= */
@@ -2115,9 +2221,9 @@ __global__ __launch_bounds__(T) void k_final(Params P, FrameState *__restrict__ 
   const BitImg im{ img, P.W, P.H, P.W64 };
 
   /* bottom-scan columns: x_j = xr0 + 50 j, centre column j = jc */
-  const int xStep = 50;
+  const int xStep = kGroundScanStep;
   const int xc = P.W / 2;
-  const int xr0 = xc % xStep;
+  const int xr0 = ground_scan_x0(P.W);
   const int jc = xc / xStep;
   const int nCols = min(kMaxCols, (P.W - 1 - xr0) / xStep + 1);
   SSD_PHASE(2, 0);
@@ -2433,11 +2539,30 @@ __global__ __launch_bounds__(T) void k_final(Params P, FrameState *__restrict__ 
   {
     const int cy0 = fs.imgYMin[kMaxStepImages], cc0 = fs.imgXMin[kMaxStepImages];
     const int cw = fs.imgXMax[kMaxStepImages] - cc0 + 1, ch = fs.imgYMax[kMaxStepImages] - cy0 + 1;
-    for(int idx = tid; idx < cw * ch; idx += T)
+    if(P.px.groundFull)
     {
-      const int ry = idx / cw;
-      const size_t o = static_cast<size_t>(cy0 + ry) * P.W64 + cc0 + (idx - ry * cw);
-      img[o] = 0ull;                                 /* unconditionally: a load first would make every word a round trip */
+      for(int idx = tid; idx < cw * ch; idx += T)
+      {
+        const int ry = idx / cw;
+        const size_t o = static_cast<size_t>(cy0 + ry) * P.W64 + cc0 + (idx - ry * cw);
+        img[o] = 0ull;                                 /* unconditionally: a load first would make every word a round trip */
+      }
+    }
+    else
+    {
+      /* k_inquad set strip pixels only (ground_strip_column: within two of x_j for ANY integer j, also j = -1 and one past the
+       * last scanned column): the one or two 32-bit words of every such strip, rows cy0 .. */
+      unsigned int *img32 = reinterpret_cast<unsigned int *>(img);
+      const int nStrips = (P.W - 1 + 2 - xr0) / xStep + 3;           /* j = -1 .. (W + 1 - xr0) / 50 */
+      const int words32 = 2 * P.W64;
+      for(int idx = tid; idx < ch * nStrips * 2; idx += T)
+      {
+        const int ry = idx / (nStrips * 2), rest = idx - ry * (nStrips * 2);
+        const int x = xr0 + xStep * ((rest >> 1) - 1) + ((rest & 1) ? 2 : -2);
+        const int w = x >> 5;                                          /* arithmetic shift: negative stays negative */
+        if(x >= 0 && w < words32)
+          img32[static_cast<size_t>(cy0 + ry) * words32 + w] = 0u;
+      }
     }
   }
   SSD_PHASE(2, 6);
@@ -2652,12 +2777,23 @@ void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, Frame
                    const uint2 *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
-  if(depth)
-    hipLaunchKernelGGL(k_inquad<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, groundImg, tileMasks, tileMaskStride, chunkPoints, *depth);
-  else if(aligned16(xyz, strideFloats, P.nPoints))
-    hipLaunchKernelGGL(k_inquad<kSrcF3Aligned>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, groundImg, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
+  const int src = depth ? kSrcDepth16 : aligned16(xyz, strideFloats, P.nPoints) ? kSrcF3Aligned : kSrcF3;
+  const DepthSrc D = depth ? *depth : DepthSrc{};
+#define SSD_LAUNCH_INQUAD(SRC, FULL) \
+  hipLaunchKernelGGL((k_inquad<SRC, FULL>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, groundImg, tileMasks, tileMaskStride, chunkPoints, D)
+  if(P.px.groundFull)
+  {
+    if(src == kSrcDepth16) SSD_LAUNCH_INQUAD(kSrcDepth16, true);
+    else if(src == kSrcF3Aligned) SSD_LAUNCH_INQUAD(kSrcF3Aligned, true);
+    else SSD_LAUNCH_INQUAD(kSrcF3, true);
+  }
   else
-    hipLaunchKernelGGL(k_inquad<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, groundImg, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
+  {
+    if(src == kSrcDepth16) SSD_LAUNCH_INQUAD(kSrcDepth16, false);
+    else if(src == kSrcF3Aligned) SSD_LAUNCH_INQUAD(kSrcF3Aligned, false);
+    else SSD_LAUNCH_INQUAD(kSrcF3, false);
+  }
+#undef SSD_LAUNCH_INQUAD
 }
 void launch_final(const Params &P, FrameState *st, unsigned long long *groundImg, ssd_frame_result *results, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
 {
@@ -2685,5 +2821,12 @@ void launch_risers(const float *xyz, size_t strideFloats, const Params &P, Frame
 extern "C" __attribute__((visibility("default"))) int ssd_phase_read(unsigned long long *out)
 {
   return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(ssd::g_phase), sizeof(ssd::g_phase)));
+}
+/* reads and clears the block-life accumulators of the streaming kernels (tools/blockphases.py) */
+extern "C" __attribute__((visibility("default"))) int ssd_blockphase_read(unsigned long long *out)
+{
+  const int rc = static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(ssd::g_blockphase), sizeof(ssd::g_blockphase)));
+  static const unsigned long long zero[4][64][8] = {};
+  return rc ? rc : static_cast<int>(hipMemcpyToSymbol(HIP_SYMBOL(ssd::g_blockphase), zero, sizeof(zero)));
 }
 #endif

@@ -179,6 +179,21 @@ long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, 
   return static_cast<long long>(n);
 }
 
+int ssd_test_ground_image(ssd_handle *h, int frame, uint8_t *out)
+{
+  if(!h || !out || frame < 0 || frame >= h->F)
+    return fail(SSD_E_ARG, "ssd_test_ground_image: bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<unsigned long long> words(h->imgWords);
+  HIP_TRY(hipMemcpy(words.data(), h->lane[h->lastLane].dGroundImg + static_cast<size_t>(frame) * h->imgWords, h->imgWords * 8, hipMemcpyDeviceToHost));
+  const int W = h->P.W, H = h->P.H, W64 = h->P.W64;
+  for(int y = 0; y < H; y++)
+    for(int x = 0; x < W; x++)
+      out[static_cast<size_t>(y) * W + x] = ((words[static_cast<size_t>(y) * W64 + (x >> 6)] >> (x & 63)) & 1ull) ? 0xff : 0;
+  return SSD_OK;
+}
+
 int ssd_test_sort_host(const double *dist, int n, int32_t *perm)
 {
   if(!dist || !perm || n < 0 || n > 32768)

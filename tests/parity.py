@@ -122,19 +122,26 @@ def check_frame(ssd, oracle, det, cfg, cal, xyz, images=True, report=None, depth
     the oracle deprojects first.  Returns the report dict; raises Mismatch on the first difference."""
     report = {} if report is None else report
     ocfg, ocal = ob.to_oracle_config(cfg), ob.to_oracle_calibration(cal)
-    det.set_debug(True)
     if depth_intr is not None:
         det.set_intrinsics(depth_intr)
-        fr = det.process_depth_host(xyz)[0]
-        xyz = oracle.deproject(depth_intr, xyz)
-    else:
-        fr = det.process_host(xyz)[0]
+    run = (lambda: det.process_depth_host(xyz)[0]) if depth_intr is not None else (lambda: det.process_host(xyz)[0])
+    # records only: the kernels exactly as in production (k_inquad rasters only the ground pixels the bottom scan reads)
+    det.set_debug(True, images=False)
+    fr = run()
     dbg = det.debug(0)
     n_img = ssd.MAX_STEP_IMAGES if images else 0
-    res, raw, closed, graw, gclosed = oracle.process(ocfg, ocal, xyz, images=n_img, ground_images=images)
+    oxyz = oracle.deproject(depth_intr, xyz) if depth_intr is not None else xyz
+    res, raw, closed, graw, gclosed = oracle.process(ocfg, ocal, oxyz, images=n_img, ground_images=images)
     compare_debug(dbg, res, report)
     compare_result(ssd, fr, res, report)
     if images:
+        # again with image capture (the whole ground image rastered): the same records and results, and every image
+        det.set_debug(True, images=True)
+        fr2 = run()
+        compare_debug(det.debug(0), res, report)
+        compare_result(ssd, fr2, res, report)
+        if bytes(fr2) != bytes(fr):
+            raise Mismatch("the result differs between debug capture with and without images")
         n_step_imgs = sum(1 for k in range(res.n_plateaus) if res.plateaus[k].is_step)
         for s in range(min(n_step_imgs, ssd.MAX_STEP_IMAGES)):
             if not np.array_equal(det.debug_image(0, s, False), raw[s]):

@@ -301,6 +301,7 @@ def test_handle_keeps_three_batches_in_flight(ssd, oracle, gpu_device):
     for at, n in zip(starts, sizes):
         one.enqueue(buf.ptr + at * fb, n)
         want.append([bytes(r) for r in one.fetch(n)])
+    one_ws = one.workspace_bytes
     one.set_risers(True, 0.03, 200)
     one.enqueue(buf.ptr + starts[3] * fb, sizes[3])
     one.fetch(sizes[3])
@@ -310,7 +311,6 @@ def test_handle_keeps_three_batches_in_flight(ssd, oracle, gpu_device):
     one.enqueue(buf.ptr + starts[5] * fb, sizes[5])
     one.fetch(sizes[5])
     want_dbg = bytes(one.debug(sizes[5] - 1))
-    one_ws = one.workspace_bytes
     one.close()
 
     det = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=cap, batches_in_flight=3), trans, gpu_device)

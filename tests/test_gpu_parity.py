@@ -47,6 +47,46 @@ def test_frame_results_without_debug_capture(ssd, oracle, gpu_device, name):
     assert rep.get("max_corner_err", 0.0) == 0.0
 
 
+@pytest.mark.parametrize("name", ["vga_3steps_noise2mm", "xga_config1", "xga_yaw_p8", "fhd_3steps_clean", "ragged_427x321_yaw", "ragged_600x450", "vga_yaw_outliers", "xga_low_camera"])
+def test_ground_raster_is_the_strips_the_bottom_scan_reads(ssd, oracle, gpu_device, name):
+    """Outside image capture k_inquad sets, of the ground points inside the ground quadrilateral (pointcloud.cpp:530-531), only the
+    pixels detectFrontEdge can see: the columns within two of a scan column W/2 + 50 k (BottomScanner, segmentation.cpp:159-241;
+    the closing reaches two pixels) and the rows from H/2 - 1 down.  The workspace image after ssd_enqueue_stages(.. INQUAD) must
+    be exactly the oracle's raw ground image restricted to those pixels; with image capture on it must be the whole image; and
+    after a full run it must be zero again (k_final clears what k_inquad set)."""
+    sc, trans, cfg = _setup(ssd, name)
+    W, H = sc.width, sc.height
+    xyz = ssd.synth_host([sc])[0]
+    res, _, _, graw, _ = oracle.process(ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants), xyz, images=0, ground_images=True)
+    assert res.first_valid_ind >= 0 and res.ground_ind >= 0 and graw.any()
+    xs = np.arange(W)
+    x0 = (W // 2) % 50
+    in_strip = ((xs + 2 - x0) % 50) <= 4
+    mask = np.zeros((H, W), dtype=bool)
+    mask[H // 2 - 1:, :] = in_strip[None, :]
+    buf = ssd.DeviceBuffer(W * H * 12, gpu_device)
+    buf.upload(xyz)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    upto_inquad = ssd.STAGE_ALL & ~64
+    det.enqueue(buf.ptr, 1, stages=upto_inquad)
+    got = det.ground_image_raw(0)
+    want = np.where(mask, graw, 0).astype(np.uint8)
+    assert np.array_equal(got, want), "%d pixels differ" % int((got != want).sum())
+    assert 0 < int((want != 0).sum()) < int((graw != 0).sum()) // 4
+    det.enqueue(buf.ptr, 1)                                   # the partial run left bits behind: the library clears them first
+    fr = det.fetch_list(1)[0]
+    assert not det.ground_image_raw(0).any()
+    parity.check_results_only(ssd, oracle, cfg, trans.constants, xyz, fr)
+    det.set_debug(True, images=True)
+    det.enqueue(buf.ptr, 1, stages=upto_inquad)
+    assert np.array_equal(det.ground_image_raw(0), graw)
+    det.set_debug(False)
+    det.enqueue(buf.ptr, 1)
+    assert bytes(det.fetch_list(1)[0]) == bytes(fr) and not det.ground_image_raw(0).any()
+    det.close()
+    buf.free()
+
+
 def test_scene_set_covers_the_interesting_outcomes(ssd, oracle):
     """Guards the fixture set itself (oracle only): it must contain N=0 lines, ground+steps, invalid plateaus."""
     outcomes = set()
