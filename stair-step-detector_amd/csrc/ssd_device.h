@@ -150,6 +150,7 @@ struct FrameState
   QuadTest qtLive[kMaxLive];
   QuadGridSegs segLive[kMaxLive];
   unsigned char liveAcc[kMaxLive];
+  int4 liveBox[kMaxLive];          /* thresholds of k_inquad's cell classification on K1's box grid (k_quads: live_box_thresholds) */
   unsigned char lutLive[kMaxBins];
   unsigned int liveGroups[kMaxLive];
   int nLive;

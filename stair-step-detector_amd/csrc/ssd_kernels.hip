@@ -310,13 +310,60 @@ __device__ __forceinline__ unsigned int row_pk_max_u16(unsigned int v)
  * window needs — and jumps only at a column change.  Entries are cell indices relative to the chunk's first cell.
  * wantCell(record) decides from the cell's record (x = mask of the groups of 4 height bins that occur, y = bounding box,
  * see cell_box_pack) whether the cell is walked.
- * All threads of the block call it; returns the number of entries (block-uniform).  scratch: kWavesPerBlock words. */
+ * All threads of the block call it; returns the number of entries (block-uniform).  scratch: 2 * kWavesPerBlock words. */
 template<typename Want>
 __device__ __forceinline__ int cell_list_build(const uint2 *__restrict__ cellInfo, int nCells, int cols, Want wantCell,
                                                unsigned short *list, unsigned int *scratch)
 {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rows = (nCells + cols - 1) / cols;
+  constexpr int kFastPasses = 2;                 /* chunks of up to 32 tiles: the product's geometry for batches */
+  if(rows * cols <= kFastPasses * kThreads)
+  {
+    /* All records of the chunk requested at once, every pass's ballot taken, ONE barrier for the counts, one for the list:
+     * two barriers and one memory round trip, where the loop below pays two of each per 256 cells (measured: the list was
+     * 11 % of a block's life in k_raster and k_inquad). */
+    int cidx[kFastPasses];
+    uint2 rec[kFastPasses];
+#pragma unroll
+    for(int p = 0; p < kFastPasses; p++)
+    {
+      const int i = p * kThreads + tid;
+      const int cx = i / rows, r = i - cx * rows;
+      const int c = r * cols + cx;
+      cidx[p] = (cx < cols && c < nCells) ? c : -1;
+      rec[p] = cidx[p] >= 0 ? cellInfo[c] : make_uint2(0u, 0u);
+    }
+    bool want[kFastPasses];
+    int pos[kFastPasses];
+#pragma unroll
+    for(int p = 0; p < kFastPasses; p++)
+    {
+      want[p] = cidx[p] >= 0 && wantCell(rec[p]);
+      const unsigned long long b = __ballot(want[p]);
+      pos[p] = __popcll(b & ((1ull << lane) - 1ull));
+      if(lane == 0)
+        scratch[p * kWavesPerBlock + wave] = static_cast<unsigned int>(__popcll(b));
+    }
+    __syncthreads();
+    int total = 0;
+#pragma unroll
+    for(int p = 0; p < kFastPasses; p++)
+    {
+      int before = total;
+#pragma unroll
+      for(int w = 0; w < kWavesPerBlock; w++)
+      {
+        const int n = static_cast<int>(scratch[p * kWavesPerBlock + w]);
+        before += w < wave ? n : 0;
+        total += n;
+      }
+      if(want[p])
+        list[before + pos[p]] = static_cast<unsigned short>(cidx[p]);
+    }
+    __syncthreads();
+    return total;
+  }
   int total = 0;
   for(int i0 = 0; i0 < rows * cols; i0 += kThreads)
   {
@@ -899,7 +946,7 @@ struct RasterLds
   unsigned char lut[kMaxBins];
   unsigned int lOob;
   unsigned short cellList[kMaxCellsPerBlockRaster];
-  unsigned int listScratch[kWavesPerBlock];
+  unsigned int listScratch[2 * kWavesPerBlock];
   unsigned long long ltot[kMaxStepImages][8];       /* sum of round(z * 2^40) over ALL points of each step plateau (this block's share) */
 };
 
@@ -916,21 +963,24 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
   unsigned char (&lut)[kMaxBins] = L.lut;
   unsigned int &lOob = L.lOob;
   unsigned short (&cellList)[kMaxCellsPerBlockRaster] = L.cellList;
-  unsigned int (&listScratch)[kWavesPerBlock] = L.listScratch;
+  unsigned int (&listScratch)[2 * kWavesPerBlock] = L.listScratch;
   unsigned long long (&ltot)[kMaxStepImages][8] = L.ltot;
 
   const int tid = threadIdx.x, lane = tid & 63;
   FrameState &fs = st[frame];
+  /* all the block needs of the frame's state in one memory round trip (the image count decides whether there is work) */
   const int nImg = fs.nStepImages;
+  const int firstStep = fs.firstStep;
+  const unsigned char lutMine = tid < kMaxBins ? fs.lut[tid] : static_cast<unsigned char>(0xff);
+  const unsigned int wantedSteps = fs.wantedSteps;
   if(nImg == 0)
     return;
   BlockPhase ph(0);
-  const int firstStep = fs.firstStep;
   if(tid < kMaxBins)
   {
     /* bin -> image slot of a step plateau, 0xff = no image for this bin */
-    const int sl = static_cast<int>(fs.lut[tid]) - firstStep;
-    lut[tid] = (fs.lut[tid] != 0xff && sl >= 0 && sl < nImg) ? static_cast<unsigned char>(sl) : static_cast<unsigned char>(0xff);
+    const int sl = static_cast<int>(lutMine) - firstStep;
+    lut[tid] = (lutMine != 0xff && sl >= 0 && sl < nImg) ? static_cast<unsigned char>(sl) : static_cast<unsigned char>(0xff);
   }
   if(tid < kMaxStepImages)
     boxes[tid] = ImageBox{ 0x7fffffff, -1, 0x7fffffff, -1 };
@@ -973,7 +1023,6 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
    * iteration leaves the SIMD to seven others, which no longer cover the memory latency once the body is this short. */
   const int cell0 = begin / kCell;
   const int nCells = (end - begin + kCell - 1) / kCell;
-  const unsigned int wantedSteps = fs.wantedSteps;
   const int count = cell_list_build(tileMasks + static_cast<size_t>(frame) * tileMaskStride + cell0, nCells, X.cellCols,
                                     [&](const uint2 info) { return (info.x & wantedSteps) != 0u; }, cellList, listScratch);
   ph.mark(1);
@@ -1700,6 +1749,31 @@ __global__ __launch_bounds__(T) void k_outline(Params P, FrameState *__restrict_
 /* ========================================================================= */
 /* K3b: ground quadrilateral and the prepared quadrilateral tests              */
 
+/* Thresholds of k_inquad's cell classification for one live quadrilateral, on the grid of K1's cell boxes.  A cell's box
+ * [x0, x1] x [y0, y1] holds points with xMin + x0 / boxX <= x < xMin + (x1 + 1) / boxX (K1 truncates).  Ground: the box lies
+ * wholly outside the quadrilateral's strict bounding box iff x1 <= b.x, x0 >= b.y, y1 <= b.z or y0 >= b.w; tread: wholly inside
+ * the constant cell iff x0 >= b.x, x1 <= b.y, y0 >= b.z, y1 <= b.w — with a 1e-9 m margin against the truncation's rounding. */
+__device__ __forceinline__ int4 live_box_thresholds(const QuadTest &t, bool ground, const PointParams &P)
+{
+  const double m = 1.0e-9;
+  int4 b;
+  if(ground)
+  {
+    b.x = static_cast<int>(floor((t.bxLo - P.xMin - m) * P.boxX)) - 1;
+    b.y = static_cast<int>(ceil((t.bxUp - P.xMin + m) * P.boxX));
+    b.z = static_cast<int>(floor((t.byLo - P.yMin - m) * P.boxY)) - 1;
+    b.w = static_cast<int>(ceil((t.byUp - P.yMin + m) * P.boxY));
+  }
+  else
+  {
+    b.x = static_cast<int>(ceil((t.fx0 - P.xMin + m) * P.boxX));
+    b.y = static_cast<int>(floor((t.fx1 - P.xMin - m) * P.boxX)) - 1;
+    b.z = static_cast<int>(ceil((t.fy0 - P.yMin + m) * P.boxY));
+    b.w = static_cast<int>(floor((t.fy1 - P.yMin - m) * P.boxY)) - 1;
+  }
+  return b;
+}
+
 /* one wave per frame: lane k < kMaxPlateaus builds the test of plateau k, lane kGroundAcc the ground's */
 __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__ st, int nframes, DebugFrame *__restrict__ dbg)
 {
@@ -1778,6 +1852,7 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
         QuadGridSegs sg;
         build_grid_segs(t, P.pt.xMin, P.pt.yMin, P.pt.boxX, P.pt.boxY, sg);
         fs.segLive[slot] = sg;
+        fs.liveBox[slot] = live_box_thresholds(t, groundLane, P.pt);
         fs.liveAcc[slot] = static_cast<unsigned char>(lane);
         /* the groups of 4 height bins this accumulator's plateau occupies (matched against the cells' masks) */
         const PlateauState &pl = fs.pl[groundLane ? groundInd : lane];
@@ -1875,11 +1950,12 @@ struct InquadLds
   unsigned int lcnt[kMaxLive][8];
   unsigned int lOob;
   unsigned short cellList[kMaxCellsPerBlockInquad];
-  unsigned int listScratch[kWavesPerBlock];
+  unsigned int listScratch[2 * kWavesPerBlock];
   unsigned int liveGroups[kMaxLive];
   int4 liveBox[kMaxLive];                       /* per live quadrilateral: thresholds of the cell classification on K1's grid */
   unsigned char liveAcc[kMaxLive];
   int nLive, groundSlot;
+  int nextGroup;                                /* the walk's groups of four cells are dealt out to the waves as they come free */
 };
 
 template<int SRC, bool FULL>
@@ -1899,7 +1975,7 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
   unsigned int (&lcnt)[kMaxLive][8] = L.lcnt;
   unsigned int &lOob = L.lOob;
   unsigned short (&cellList)[kMaxCellsPerBlockInquad] = L.cellList;
-  unsigned int (&listScratch)[kWavesPerBlock] = L.listScratch;
+  unsigned int (&listScratch)[2 * kWavesPerBlock] = L.listScratch;
   unsigned int (&liveGroups)[kMaxLive] = L.liveGroups;
   int4 (&liveBox)[kMaxLive] = L.liveBox;
   unsigned char (&liveAcc)[kMaxLive] = L.liveAcc;
@@ -1908,27 +1984,48 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
 
   const int tid = threadIdx.x, lane = tid & 63;
   FrameState &fs = st[frame];
-  if(!fs.anyActive)                                         /* block-uniform: set by k_quads */
+  /* Everything the block needs of the frame's state is requested at once, the "anything to do?" flag first: one memory round
+   * trip for the lot (as code in sequence — flag, early exit, tables — it was two, a tenth of a block's life). */
+  const unsigned int anyActive = fs.anyActive;              /* block-uniform: set by k_quads */
+  const unsigned char lutMine = tid < kMaxBins ? fs.lutLive[tid] : static_cast<unsigned char>(0xff);
+  const unsigned char accMine = tid < kMaxLive ? fs.liveAcc[tid] : static_cast<unsigned char>(0);
+  const unsigned int groupsMine = tid < kMaxLive ? fs.liveGroups[tid] : 0u;
+  const int4 boxMine = tid < kMaxLive ? fs.liveBox[tid] : make_int4(0, 0, 0, 0);
+  const int nLiveG = fs.nLive;
+  const unsigned char groundActive = fs.accActive[kGroundAcc];
+  constexpr int qtWords = kMaxLive * static_cast<int>(sizeof(QuadTest) / 4), sgWords = kMaxLive * static_cast<int>(sizeof(QuadGridSegs) / 4);
+  constexpr int qtPer = (qtWords + kThreads - 1) / kThreads, sgPer = (sgWords + kThreads - 1) / kThreads;
+  unsigned int qtw[qtPer], sgw[sgPer];
+  {
+    /* the live quadrilateral tests as 32-bit words: the whole table, unconditionally — asking "how many are live?" first
+     * would make every element two dependent round trips */
+    const unsigned int *src = reinterpret_cast<const unsigned int *>(fs.qtLive);
+    const unsigned int *srcS = reinterpret_cast<const unsigned int *>(fs.segLive);
+#pragma unroll
+    for(int k = 0; k < qtPer; k++)
+      qtw[k] = tid + k * kThreads < qtWords ? src[tid + k * kThreads] : 0u;
+#pragma unroll
+    for(int k = 0; k < sgPer; k++)
+      sgw[k] = tid + k * kThreads < sgWords ? srcS[tid + k * kThreads] : 0u;
+  }
+  if(!anyActive)
     return;
   BlockPhase ph(1);
   if(tid == 0)
   {
     box[0] = ImageBox{ 0x7fffffff, -1, 0x7fffffff, -1 };
     lOob = 0;
+    nLive = nLiveG;
+    groundSlot = (nLiveG > 0 && groundActive) ? nLiveG - 1 : -1;     /* the ground is the last accumulator */
+    L.nextGroup = 0;
   }
-
   if(tid < kMaxBins)
-    lut[tid] = fs.lutLive[tid];                 /* bin -> slot of the live table, 0xff = nothing to do for this bin */
+    lut[tid] = lutMine;                         /* bin -> slot of the live table, 0xff = nothing to do for this bin */
   if(tid < kMaxLive)
   {
-    liveAcc[tid] = fs.liveAcc[tid];
-    liveGroups[tid] = fs.liveGroups[tid];
-  }
-  if(tid == 0)
-  {
-    const int n = fs.nLive;
-    nLive = n;
-    groundSlot = (n > 0 && fs.accActive[kGroundAcc]) ? n - 1 : -1;     /* the ground is the last accumulator */
+    liveAcc[tid] = accMine;
+    liveGroups[tid] = groupsMine;
+    liveBox[tid] = boxMine;                     /* thresholds of the cell classification (k_quads, live_box_thresholds) */
   }
   for(int i = tid; i < kMaxLive * 8; i += kThreads)
   {
@@ -1943,44 +2040,16 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
       wavemiss_init(wmiss[tid]);
   }
   {
-    /* copy the live quadrilateral tests as 32-bit words */
-    const unsigned int *src = reinterpret_cast<const unsigned int *>(fs.qtLive);
     unsigned int *dst = reinterpret_cast<unsigned int *>(qts);
-    constexpr int wordsPer = sizeof(QuadTest) / 4;
-    /* the whole table, unconditionally: independent loads the compiler can issue together — asking "how many are live?"
-     * first made every element two dependent round trips, a large part of a block's life */
-#pragma unroll 4
-    for(int i = tid; i < kMaxLive * wordsPer; i += kThreads)
-      dst[i] = src[i];
-    const unsigned int *srcS = reinterpret_cast<const unsigned int *>(fs.segLive);
     unsigned int *dstS = reinterpret_cast<unsigned int *>(segs);
-    for(int i = tid; i < kMaxLive * static_cast<int>(sizeof(QuadGridSegs) / 4); i += kThreads)
-      dstS[i] = srcS[i];
-  }
-  __syncthreads();
-  if(tid < nLive)
-  {
-    /* A cell's box [x0, x1] x [y0, y1] on the grid holds points with xMin + x0 / boxX <= x < xMin + (x1 + 1) / boxX (K1
-     * truncates).  Ground: wholly outside the quadrilateral's strict bounding box iff x1 <= b.x, x0 >= b.y, ... ; tread:
-     * wholly inside the constant cell iff x0 >= b.x, x1 <= b.y, ... — with a 1e-9 m margin against the truncation's rounding. */
-    const QuadTest &t = qts[tid];
-    const double m = 1.0e-9;
-    int4 b;
-    if(tid == groundSlot)
-    {
-      b.x = static_cast<int>(floor((t.bxLo - P.xMin - m) * P.boxX)) - 1;
-      b.y = static_cast<int>(ceil((t.bxUp - P.xMin + m) * P.boxX));
-      b.z = static_cast<int>(floor((t.byLo - P.yMin - m) * P.boxY)) - 1;
-      b.w = static_cast<int>(ceil((t.byUp - P.yMin + m) * P.boxY));
-    }
-    else
-    {
-      b.x = static_cast<int>(ceil((t.fx0 - P.xMin + m) * P.boxX));
-      b.y = static_cast<int>(floor((t.fx1 - P.xMin - m) * P.boxX)) - 1;
-      b.z = static_cast<int>(ceil((t.fy0 - P.yMin + m) * P.boxY));
-      b.w = static_cast<int>(floor((t.fy1 - P.yMin - m) * P.boxY)) - 1;
-    }
-    liveBox[tid] = b;
+#pragma unroll
+    for(int k = 0; k < qtPer; k++)
+      if(tid + k * kThreads < qtWords)
+        dst[tid + k * kThreads] = qtw[k];
+#pragma unroll
+    for(int k = 0; k < sgPer; k++)
+      if(tid + k * kThreads < sgWords)
+        dstS[tid + k * kThreads] = sgw[k];
   }
   __syncthreads();
   ph.mark(0);                                               /* tables in LDS */
@@ -2056,17 +2125,26 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
                                     }, cellList, listScratch);
   ph.mark(1);                                               /* cell list */
   const int nGroups = (count + 3) >> 2;
-  const int gEnd = ((tid >> 6) + 1) * nGroups / kWavesPerBlock;
-  /* the loads of the NEXT group issued before the current one is processed (as in k_raster): 0.89 -> 0.86 ms even though
-   * the second register buffer costs 7 VGPR spills at 8 waves per SIMD; with 7 / 6 waves and no spills: 0.90 / 0.98 ms */
-  int g = (tid >> 6) * nGroups / kWavesPerBlock;
-  F3 v[kPts], vn[kPts];
-  if(g < gEnd)
-    load_cell<SRC>(base, cell0, cellList, 4 * g + (lane >> 4), count, lane, P.nPoints, v, D);
-  for( ; g < gEnd; g++)
+  /* The groups of four listed cells go to the waves as they come free (a counter in LDS, one returning atomic per group,
+   * asked for one group ahead so that its latency and the group's loads hide behind the current group's arithmetic): a
+   * quarter of the list each left the block waiting 8 % of its life for its slowest wave — treads' edges cost several
+   * times the ground's interior. */
+  auto grab = [&]()
   {
-    if(g + 1 < gEnd)
-      load_cell<SRC>(base, cell0, cellList, 4 * (g + 1) + (lane >> 4), count, lane, P.nPoints, vn, D);
+    int v = 0;
+    if(lane == 0)
+      v = atomicAdd(&L.nextGroup, 1);
+    return __builtin_amdgcn_readfirstlane(v);
+  };
+  int g = grab();
+  F3 v[kPts], vn[kPts];
+  if(g < nGroups)
+    load_cell<SRC>(base, cell0, cellList, 4 * g + (lane >> 4), count, lane, P.nPoints, v, D);
+  while(g < nGroups)
+  {
+    const int gNext = grab();
+    if(gNext < nGroups)
+      load_cell<SRC>(base, cell0, cellList, 4 * gNext + (lane >> 4), count, lane, P.nPoints, vn, D);
     unsigned int key[kPts];
     #pragma unroll
     for(int j = 0; j < kPts; j++)
@@ -2113,6 +2191,7 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
     }
     if(FULL)
       wavewin_emit(ww, wm, win, gimg, imgWords, X.W64, X.winShiftGround, box, key, lane);
+    g = gNext;
 #pragma unroll
     for(int j = 0; j < kPts; j++)
       v[j] = vn[j];
@@ -2577,7 +2656,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_risers(const float *__restrict_
                                                         size_t tileMaskStride, int chunkPoints, int cellCols, DepthSrc D)
 {
   __shared__ unsigned short cellList[kMaxCellsPerBlock];
-  __shared__ unsigned int listScratch[kWavesPerBlock];
+  __shared__ unsigned int listScratch[2 * kWavesPerBlock];
   __shared__ RiserState rs[kMaxRisers];
   __shared__ signed char riserOfBin[kMaxBins];
   __shared__ unsigned long long lsum[kMaxRisers][8];
