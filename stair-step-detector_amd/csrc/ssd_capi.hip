@@ -466,6 +466,9 @@ int ssd_destroy(ssd_handle *h)
     if(L.done) (void)hipEventDestroy(L.done);
     if(L.stream) (void)hipStreamDestroy(L.stream);
   }
+  for(ssd_handle::SmallGraph &g : h->graphs)
+    if(g.exec) (void)hipGraphExecDestroy(g.exec);
+  if(h->captureStream) (void)hipStreamDestroy(h->captureStream);
   if(h->dDepthMaps) (void)hipFree(h->dDepthMaps);
   if(h->dResults) (void)hipFree(h->dResults);
   if(h->hResults) (void)hipHostFree(h->hResults);
@@ -639,6 +642,18 @@ static int choose_chunk(const ssd_tuning &tune, int nPoints, int nframes)
 }
 
 static constexpr int kDirectResultFrames = 64;
+#ifdef SSD_SMALL_GRAPH
+static constexpr int kGraphFrames = 8;       /* calls of up to this many frames are replayed from a captured graph */
+#endif
+
+static void drop_graphs(ssd_handle *h)
+{
+  for(ssd_handle::SmallGraph &g : h->graphs)
+  {
+    if(g.exec) (void)hipGraphExecDestroy(g.exec);
+    g = ssd_handle::SmallGraph{};
+  }
+}
 
 static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_bytes, int nframes, void *stream, int stages, bool depthInput)
 {
@@ -734,60 +749,130 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   unsigned long long *dbgImg = h->debug == 1 ? h->dDebugImg : nullptr;
   const bool timing = h->timing && !h->ev.empty();
   int evi = static_cast<int>(h->enqueueCount % SSD_TIMING_SLOTS) * 8;
-  auto mark = [&]() { if(timing) (void)hipEventRecord(h->ev[evi++], s); };
 
-  if(L.imagesDirty)
-  {
-    HIP_TRY(hipMemsetAsync(L.dStepImg, 0, static_cast<size_t>(h->F) * P.maxStepImages * h->imgWords * 8, s));
-    HIP_TRY(hipMemsetAsync(L.dGroundImg, 0, static_cast<size_t>(h->F) * h->imgWords * 8, s));
-    L.imagesDirty = false;
-  }
-  if(stages & SSD_STAGE_HIST)
-  {
-    /* No memset of the state in front of a call: K1 only needs its accumulators zero, and k_peaks — their one reader —
-     * clears them as it takes them (everything else in FrameState is written before it is read).  Only after a call that
-     * ran K1 without k_peaks (ssd_enqueue_stages), or one that failed half way, the state is zeroed here. */
-    if(L.dirtyFrames > 0)
-      HIP_TRY(hipMemsetAsync(L.dState, 0, sizeof(FrameState) * L.dirtyFrames, s));
-    L.dirtyFrames = nframes;
-    if(dbg)
-      HIP_TRY(hipMemsetAsync(dbg, 0, sizeof(DebugFrame) * nframes, s));
-  }
-  mark();
-  if(stages & SSD_STAGE_HIST)
-    launch_hist(xyz, strideFloats, P, L.dState, L.dTileMasks, h->tileMaskStride, nframes, chunkHist, depth, s);
-  mark();
-  if(stages & SSD_STAGE_PEAKS)
-    launch_peaks(P, L.dState, nframes, dbg, s);
-  mark();
-  if(stages & SSD_STAGE_RASTER)
-    launch_raster(xyz, strideFloats, P, L.dState, L.dStepImg, L.dTileMasks, h->tileMaskStride, nframes, chunkRaster, depth, s);
-  mark();
-  if(stages & SSD_STAGE_OUTLINE)
-    launch_outline(P, L.dState, L.dStepImg, nframes, dbg, dbgImg, s);
-  mark();
-  if(stages & SSD_STAGE_QUADS)
-    launch_quads(P, L.dState, nframes, dbg, s);
-  mark();
-  if(stages & SSD_STAGE_INQUAD)
-    launch_inquad(xyz, strideFloats, P, L.dState, L.dGroundImg, L.dTileMasks, h->tileMaskStride, nframes, chunkInquad, depth, s);
-  mark();
-  /* The results leave with the batch, into this enqueue's pinned slot (event for ssd_fetch / ssd_fetch_back).  A few frames:
-   * k_final stores them there itself — a kilobyte per frame of posted writes, visible to the host once the event has
-   * fired — instead of a device-to-host copy command behind the kernel (single frame: one command less in the chain).
-   * Batches go through device memory and one copy: a megabyte of scattered stores over PCIe would hold k_final's blocks. */
   const int slot = static_cast<int>(h->finalCount % static_cast<unsigned long long>(h->nSlots));
   const bool direct = nframes <= kDirectResultFrames && h->hResultsDev != nullptr;
   if((stages & SSD_STAGE_FINAL) && h->depth > 1 && h->resultsLane[slot] != li && h->lane[h->resultsLane[slot]].haveLast)
     HIP_TRY(hipStreamWaitEvent(s, h->lane[h->resultsLane[slot]].done, 0));     /* the slot's previous writer was another lane */
-  if(stages & SSD_STAGE_FINAL)
+
+  /* the kernels of the chosen stages on stream cs, in order */
+  auto chain = [&](hipStream_t cs, bool marks)
   {
-    ssd_frame_result *out = (direct ? h->hResultsDev : h->dResults) + static_cast<size_t>(slot) * h->F;
-    launch_final(P, L.dState, L.dGroundImg, out, nframes, dbg, dbgImg, s);
-    if(P.risers)
-      launch_risers(xyz, strideFloats, P, L.dState, L.dTileMasks, h->tileMaskStride, h->dRisers, nframes, chunk, depth, s);
+    auto mk = [&]() { if(marks) (void)hipEventRecord(h->ev[evi++], cs); };
+    mk();
+    if(stages & SSD_STAGE_HIST)
+      launch_hist(xyz, strideFloats, P, L.dState, L.dTileMasks, h->tileMaskStride, nframes, chunkHist, depth, cs);
+    mk();
+    if(stages & SSD_STAGE_PEAKS)
+      launch_peaks(P, L.dState, nframes, dbg, cs);
+    mk();
+    if(stages & SSD_STAGE_RASTER)
+      launch_raster(xyz, strideFloats, P, L.dState, L.dStepImg, L.dTileMasks, h->tileMaskStride, nframes, chunkRaster, depth, cs);
+    mk();
+    if(stages & SSD_STAGE_OUTLINE)
+      launch_outline(P, L.dState, L.dStepImg, nframes, dbg, dbgImg, cs);
+    mk();
+    if(stages & SSD_STAGE_QUADS)
+      launch_quads(P, L.dState, nframes, dbg, cs);
+    mk();
+    if(stages & SSD_STAGE_INQUAD)
+      launch_inquad(xyz, strideFloats, P, L.dState, L.dGroundImg, L.dTileMasks, h->tileMaskStride, nframes, chunkInquad, depth, cs);
+    mk();
+    /* The results leave with the batch, into this enqueue's pinned slot (event for ssd_fetch / ssd_fetch_back).  A few frames:
+     * k_final stores them there itself — a kilobyte per frame of posted writes, visible to the host once the event has
+     * fired — instead of a device-to-host copy command behind the kernel (single frame: one command less in the chain).
+     * Batches go through device memory and one copy: a megabyte of scattered stores over PCIe would hold k_final's blocks. */
+    if(stages & SSD_STAGE_FINAL)
+    {
+      ssd_frame_result *out = (direct ? h->hResultsDev : h->dResults) + static_cast<size_t>(slot) * h->F;
+      launch_final(P, L.dState, L.dGroundImg, out, nframes, dbg, dbgImg, cs);
+      if(P.risers)
+        launch_risers(xyz, strideFloats, P, L.dState, L.dTileMasks, h->tileMaskStride, h->dRisers, nframes, chunk, depth, cs);
+    }
+    mk();
+  };
+
+  /* A call of a few frames is a chain of seven dependent launches of a few microseconds each.  Replaying it from a HIP graph
+   * captured the first time this (frames pointer, stride, count, input kind, result slot) was seen — ONE submission — was
+   * measured and is NOT in the product: ROCm 7.2's hipGraphLaunch takes longer than the seven launches it replaces (one
+   * resident XGA frame: 100 -> 200 us per ssd_enqueue + ssd_fetch, eight frames 134 -> 158 us; same box, alternating runs,
+   * tools/latency.py).  The code stays for the next runtime: make EXTRA=-DSSD_SMALL_GRAPH. */
+  bool viaGraph = false;
+#ifdef SSD_SMALL_GRAPH
+  if(h->depth == 1 && nframes <= kGraphFrames && stages == SSD_STAGE_ALL && !h->debug && !timing && !P.risers && !h->graphsOff &&
+     !L.imagesDirty && L.dirtyFrames == 0)
+  {
+    ssd_handle::SmallGraph *g = nullptr, *lru = &h->graphs[0];
+    for(ssd_handle::SmallGraph &c : h->graphs)
+    {
+      if(c.exec && c.xyz == d_xyz && c.stride == frame_stride_bytes && c.nframes == nframes && c.slot == slot && c.depthInput == depthInput)
+        g = &c;
+      if(c.lastUse < lru->lastUse)
+        lru = &c;
+    }
+    if(!g)
+    {
+      bool ok = true;
+      if(!h->captureStream)
+        ok = hipStreamCreateWithFlags(&h->captureStream, hipStreamNonBlocking) == hipSuccess;
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      if(ok && hipStreamBeginCapture(h->captureStream, hipStreamCaptureModeThreadLocal) == hipSuccess)
+      {
+        chain(h->captureStream, false);
+        ok = hipStreamEndCapture(h->captureStream, &graph) == hipSuccess && graph != nullptr;
+        ok = ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if(graph) (void)hipGraphDestroy(graph);
+      }
+      else
+        ok = false;
+      (void)hipGetLastError();
+      if(ok)
+      {
+        if(lru->exec) (void)hipGraphExecDestroy(lru->exec);
+        *lru = ssd_handle::SmallGraph{};
+        lru->exec = exec; lru->xyz = d_xyz; lru->stride = frame_stride_bytes; lru->nframes = nframes; lru->slot = slot; lru->depthInput = depthInput;
+        g = lru;
+      }
+      else
+        h->graphsOff = true;                    /* this runtime does not capture the chain: plain launches from now on */
+    }
+    if(g)
+    {
+      g->lastUse = h->enqueueCount + 1;
+      if(hipGraphLaunch(g->exec, s) == hipSuccess)
+        viaGraph = true;
+      else
+      {
+        (void)hipGetLastError();
+        h->graphsOff = true;
+      }
+    }
   }
-  mark();
+#endif
+
+  if(!viaGraph)
+  {
+    if(L.imagesDirty)
+    {
+      HIP_TRY(hipMemsetAsync(L.dStepImg, 0, static_cast<size_t>(h->F) * P.maxStepImages * h->imgWords * 8, s));
+      HIP_TRY(hipMemsetAsync(L.dGroundImg, 0, static_cast<size_t>(h->F) * h->imgWords * 8, s));
+      L.imagesDirty = false;
+    }
+    if(stages & SSD_STAGE_HIST)
+    {
+      /* No memset of the state in front of a call: K1 only needs its accumulators zero, and k_peaks — their one reader —
+       * clears them as it takes them (everything else in FrameState is written before it is read).  Only after a call that
+       * ran K1 without k_peaks (ssd_enqueue_stages), or one that failed half way, the state is zeroed here. */
+      if(L.dirtyFrames > 0)
+        HIP_TRY(hipMemsetAsync(L.dState, 0, sizeof(FrameState) * L.dirtyFrames, s));
+      if(dbg)
+        HIP_TRY(hipMemsetAsync(dbg, 0, sizeof(DebugFrame) * nframes, s));
+    }
+    chain(s, timing);
+  }
+  if(stages & SSD_STAGE_HIST)
+    L.dirtyFrames = nframes;
   if(stages & SSD_STAGE_FINAL)
   {
     if(!direct)
@@ -851,6 +936,7 @@ int ssd_set_intrinsics(ssd_handle *h, const ssd_intrinsics *intr)
   HIP_TRY(hipMemcpy(h->dDepthMaps, maps.data(), maps.size() * 4, hipMemcpyHostToDevice));
   h->intr = *intr;
   h->haveIntr = true;
+  drop_graphs(h);                               /* captured chains hold the old depth scale */
   return SSD_OK;
 }
 
