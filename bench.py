@@ -170,6 +170,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=0, help="bounded CPU-baseline sample in frames (default: ~15 s of CPU work)")
     ap.add_argument("--input", choices=["float3", "depth16"], default="float3",
                     help="float3 = xyz vertices (the metric's input); depth16 = 16-bit depth frames deprojected on the fly (SURVEY 8f rank 1)")
+    ap.add_argument("--batches-in-flight", type=int, default=0,
+                    help="workspaces of the handle (ssd_config::batches_in_flight): 0 = the library's default (3 from 128 frames per batch on); "
+                         "1 = strictly one batch at a time — what the profiling passes use, so that a kernel's traced duration is its own")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-hostfed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg reported beside `value`")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (profiling passes: its 56 one-frame "
@@ -210,7 +213,7 @@ def main():
     else:
         sc_list = scenes.batch_scenes(ssd, W, H, F, base_seed=100000 + lo, rng_seed=1000 + rank)
     trans = ssd.transformation_for_scene(sc_list[0])
-    cfg = ssd.default_config(W, H, max_frames_per_batch=F)
+    cfg = ssd.default_config(W, H, max_frames_per_batch=F, batches_in_flight=args.batches_in_flight)
     depth_in = args.input == "depth16"
     if depth_in:
         frame_bytes = W * H * 2

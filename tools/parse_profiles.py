@@ -17,7 +17,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STREAMING = ("k_hist", "k_raster", "k_inquad")
+STREAMING = ("k_hist", "k_raster", "k_inquad", "k_stream_read")
+NOT_PIPELINE = ("synth", "k_stream_read")          # frame generator; bench.py's plain read stream beside K1
 
 
 def per_kernel(path, counter):
@@ -56,8 +57,8 @@ def main():
                        "hbm_bytes_per_launch_at_1024x768x1024": total,
                        "algorithmic_bytes_per_launch": 12.0 * 1024 * 768 * 1024,
                        "ratio": total / (12.0 * 1024 * 768 * 1024)}, open(os.path.join(dst, "pmc_k_hist.json"), "w"), indent=1)
-    moved_r = sum((v["hbm_read_bytes"] or 0.0) for k, v in out["kernels"].items() if "synth" not in k)
-    moved_w = sum((v["hbm_write_bytes"] or 0.0) for k, v in out["kernels"].items() if "synth" not in k)
+    moved_r = sum((v["hbm_read_bytes"] or 0.0) for k, v in out["kernels"].items() if not any(n in k for n in NOT_PIPELINE))
+    moved_w = sum((v["hbm_write_bytes"] or 0.0) for k, v in out["kernels"].items() if not any(n in k for n in NOT_PIPELINE))
     if moved_r:
         json.dump({"source": "profiles/%s_hbm_traffic.json (all kernels of one pass over 1024 XGA frames; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % tag,
                    "hbm_read_bytes": moved_r, "hbm_write_bytes": moved_w, "algorithmic_bytes": 12.0 * 1024 * 768 * 1024,
@@ -78,7 +79,7 @@ def main():
             per = collections.defaultdict(lambda: collections.defaultdict(list))
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-                if k.startswith("ssd::k_") and "synth" not in k:
+                if k.startswith("ssd::k_") and not any(n in k for n in NOT_PIPELINE):
                     per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             for k in per:
                 for c, v in per[k].items():
