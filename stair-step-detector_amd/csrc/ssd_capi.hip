@@ -374,6 +374,11 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   *out = nullptr;
   if(cfg->max_frames_per_batch < 1 || cfg->max_frames_per_batch > 65535)
     return fail(SSD_E_ARG, "ssd_create: max_frames_per_batch out of range");
+  int depth = cfg->batches_in_flight;
+  if(depth < 0 || depth > kMaxLanes)
+    return fail(SSD_E_ARG, "ssd_create: batches_in_flight must be 0 (automatic) .. " + std::to_string(kMaxLanes));
+  if(depth == 0)
+    depth = cfg->max_frames_per_batch >= kOverlapMinFrames ? kOverlapDepth : 1;
   Params P{};
   const int rc = make_params(*cfg, *cal, P);
   if(rc)
@@ -384,12 +389,6 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   if(device < 0 || device >= nDev)
     return fail(SSD_E_ARG, "ssd_create: device index out of range");
   HIP_TRY(hipSetDevice(device));
-
-  int depth = cfg->batches_in_flight;
-  if(depth < 0 || depth > kMaxLanes)
-    return fail(SSD_E_ARG, "ssd_create: batches_in_flight must be 0 (automatic) .. " + std::to_string(kMaxLanes));
-  if(depth == 0)
-    depth = cfg->max_frames_per_batch >= kOverlapMinFrames ? kOverlapDepth : 1;
 
   ssd_handle *h = new ssd_handle();
   h->device = device;

@@ -115,6 +115,15 @@ def test_create_rejects_bad_arguments(ssd):
     cfg = ssd.default_config(640, 480)
     cfg.max_step_plateaus = 99
     assert L.ssd_create(C.byref(cfg), C.byref(cal), 0, C.byref(h)) == -1
+    # workspaces of the handle: 0 (automatic) .. 4
+    for bad in (-1, 5):
+        cfg = ssd.default_config(640, 480, batches_in_flight=bad)
+        assert L.ssd_create(C.byref(cfg), C.byref(cal), 0, C.byref(h)) == -1 and b"batches_in_flight" in L.ssd_last_error()
+    # a pixel key's row field and the one-subtraction window test of the rasterising kernels: height <= 8064
+    assert L.ssd_create(C.byref(ssd.default_config(640, 8065)), C.byref(cal), 0, C.byref(h)) == -1 and b"8064" in L.ssd_last_error()
+    assert L.ssd_create(C.byref(ssd.default_config(8193, 480)), C.byref(cal), 0, C.byref(h)) == -1
+    assert ssd.default_config(640, 480).batches_in_flight == 0
+    assert L.ssd_stream_wait(None, 0, None) == -1 and L.ssd_batches_in_flight(None) == 0
 
 
 def test_calibration_matches_oracle_bitwise(ssd, oracle):

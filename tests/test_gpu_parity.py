@@ -385,6 +385,38 @@ def test_riser_evidence_matches_the_cpu_statement(ssd, oracle, gpu_device, name)
         assert rep["risers_detected"] == 3
 
 
+def test_risers_of_a_host_fed_batch_cover_every_slice(ssd, oracle, gpu_device):
+    """ssd_process_host cuts a batch into slices of 32 frames; the riser buffer on the device holds one enqueue's.  The
+    library collects the risers slice by slice (before, ssd_fetch_risers silently returned the last slice's):
+    all 70 frames' risers must equal the oracle's, and asking for more frames than the call processed is an error."""
+    n, W, H = 70, 640, 480
+    sc_list = scenes.batch_scenes(ssd, W, H, n, base_seed=33000, rng_seed=6)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    cfg = ssd.default_config(W, H, max_frames_per_batch=64)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    det.set_risers(True, tolerance=0.02, min_support=300)
+    xyz = ssd.synth_host(sc_list)
+    for rep in range(2):
+        res = det.process_host(xyz)
+        rs = det.fetch_risers(n)
+        assert len(res) == n and len(rs) == n
+        ocfg, ocal = ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants)
+        for i in list(range(0, n, 9)) + [31, 32, 63, 64, 69]:
+            parity.compare_risers(rs[i], oracle.risers(ocfg, ocal, xyz[i], 0.02, 300))
+    with pytest.raises(ssd.SsdError, match="exceeds"):
+        det.fetch_risers(n + 1)
+    # a device-resident call afterwards: its own risers again
+    buf = ssd.DeviceBuffer(W * H * 12 * 3, gpu_device)
+    buf.upload(xyz[5:8])
+    det.enqueue(buf.ptr, 3)
+    for i, fr in enumerate(det.fetch_risers(3)):
+        parity.compare_risers(fr, oracle.risers(ocfg, ocal, xyz[5 + i], 0.02, 300))
+    with pytest.raises(ssd.SsdError, match="exceeds"):
+        det.fetch_risers(4)
+    buf.free()
+    det.close()
+
+
 def test_risers_in_a_batch_and_with_depth_input(ssd, oracle, gpu_device):
     sc_list = scenes.batch_scenes(ssd, 640, 480, 6, base_seed=555)
     trans = ssd.transformation_for_scene(sc_list[0])
