@@ -135,15 +135,16 @@ __device__ __forceinline__ int height_bin(const PointParams &P, double wz)
 /* ========================================================================= */
 /* K1: histogram                                                              */
 
-/* k_raster is built for 7 waves per SIMD: 72 VGPRs / 96 SGPRs end its scratch spills (measured: XGA batch 1.015 -> 1.006 ms,
- * FHD stress 1.083 -> 1.037; 6 waves: slower again) */
+/* k_raster is built for 6 waves per SIMD: 75 VGPRs, no scratch spills (round 2: 7 waves, 72 VGPRs, 3 spills).  Measured in
+ * round 3, same box, alternating runs, XGA batch: 8 / 7 / 6 / 5 / 4 waves 0.848 / 0.823 / 0.800 / 0.801 / 0.799 ms; FHD stress:
+ * 7 / 6 / 5 within 1 % — the walk is bound by instruction issue, not by latency: residency beyond four waves buys nothing */
 /* k_inquad: 8 waves per SIMD although that costs it 48 scalar-register spills (v_readlane in the loop): 7 / 6 waves spill
  * 33 / 10 and run 3 % / 10 % slower (measured, XGA batch) */
 #ifndef SSD_K4_WAVES
 #define SSD_K4_WAVES 8
 #endif
 #ifndef SSD_K2_WAVES
-#define SSD_K2_WAVES 7
+#define SSD_K2_WAVES 6
 #endif
 constexpr int kThreads = 256;
 constexpr int kPts = 4;                 /* points per thread per iteration: four CONSECUTIVE points (48 B) */
