@@ -232,6 +232,15 @@ def test_host_fed_ingest_slices_pinned_and_pageable(ssd, oracle, gpu_device):
     for i in range(0, n, 10):
         parity.check_results_only(ssd, oracle, cfg, trans.constants, xyz[i], ref_x[i])
         parity.check_results_only(ssd, oracle, cfg, trans.constants, oracle.deproject(intr, depth[i]), ref_d[i])
+    # the same through a handle with three workspaces: the slices run on the handle's own streams, the staging buffers are
+    # released by the slice's end (ssd_stream_wait inside the library), not by the ingest stream's position
+    det3 = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=128), trans, gpu_device)
+    assert det3.batches_in_flight == 3
+    det3.set_intrinsics(intr)
+    for _ in range(2):
+        assert [bytes(g) for g in det3.process_host(pin_x.array)] == [bytes(r) for r in ref_x]
+        assert [bytes(g) for g in det3.process_depth_host(depth)] == [bytes(r) for r in ref_d]
+    det3.close()
     pin_x.free()
     pin_d.free()
     det.close()
