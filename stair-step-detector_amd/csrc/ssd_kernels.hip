@@ -310,10 +310,8 @@ __device__ __forceinline__ unsigned int row_pk_max_u16(unsigned int v)
  * the list stays on one patch of the top-down image that creeps down row by row — what its LDS write-combining
  * window needs — and jumps only at a column change.  Entries are cell indices relative to the chunk's first cell.
  * wantCell(record) decides from the cell's record (x = mask of the groups of 4 height bins that occur, y = bounding box,
- * see cell_box_pack) whether the cell is walked: false / 0 = no, true / 1 = yes, 3 = yes and the entry carries kCellFlag (k_inquad:
- * "the ground points of this cell all lie inside the ground quadrilateral").
+ * see cell_box_pack) whether the cell is walked.
  * All threads of the block call it; returns the number of entries (block-uniform).  scratch: 2 * kWavesPerBlock words. */
-constexpr int kCellFlag = 0x8000;       /* a list entry = the cell's index in the chunk (< 2048) | this flag */
 template<typename Want>
 __device__ __forceinline__ int cell_list_build(const uint2 *__restrict__ cellInfo, int nCells, int cols, Want wantCell,
                                                unsigned short *list, unsigned int *scratch)
@@ -342,9 +340,7 @@ __device__ __forceinline__ int cell_list_build(const uint2 *__restrict__ cellInf
 #pragma unroll
     for(int p = 0; p < kFastPasses; p++)
     {
-      const int cls = cidx[p] >= 0 ? static_cast<int>(wantCell(rec[p])) : 0;
-      want[p] = cls != 0;
-      cidx[p] |= (cls & 2) ? kCellFlag : 0;
+      want[p] = cidx[p] >= 0 && wantCell(rec[p]);
       const unsigned long long b = __ballot(want[p]);
       pos[p] = __popcll(b & ((1ull << lane) - 1ull));
       if(lane == 0)
@@ -375,8 +371,7 @@ __device__ __forceinline__ int cell_list_build(const uint2 *__restrict__ cellInf
     const int i = i0 + tid;
     const int cx = i / rows, r = i - cx * rows;
     const int c = r * cols + cx;
-    const int cls = cx < cols && c < nCells ? static_cast<int>(wantCell(cellInfo[c])) : 0;
-    const bool want = cls != 0;
+    const bool want = cx < cols && c < nCells && wantCell(cellInfo[c]);
     const unsigned long long b = __ballot(want);
     if(lane == 0)
       scratch[wave] = static_cast<unsigned int>(__popcll(b));
@@ -390,7 +385,7 @@ __device__ __forceinline__ int cell_list_build(const uint2 *__restrict__ cellInf
       total += n;
     }
     if(want)
-      list[before + __popcll(b & ((1ull << lane) - 1ull))] = static_cast<unsigned short>(c | ((cls & 2) ? kCellFlag : 0));
+      list[before + __popcll(b & ((1ull << lane) - 1ull))] = static_cast<unsigned short>(c);
     __syncthreads();
   }
   return total;
@@ -400,19 +395,17 @@ __device__ __forceinline__ int cell_list_build(const uint2 *__restrict__ cellInf
  * its 16 lanes read the cell's 768 bytes contiguously, four consecutive points per lane.  Rows beyond the end of the
  * list get invalid points (z = 0), which every consumer drops first. */
 template<int SRC>
-__device__ __forceinline__ bool load_cell(const float *__restrict__ base, int cell0, const unsigned short *list, int entry, int count,
+__device__ __forceinline__ void load_cell(const float *__restrict__ base, int cell0, const unsigned short *list, int entry, int count,
                                           int lane, int nPoints, F3 (&v)[kPts], const DepthSrc &D)
 {
   if(entry < count)
+    load_points<SRC>(base, (cell0 + static_cast<int>(list[entry])) * kCell + kPts * (lane & 15), nPoints, v, D);
+  else
   {
-    const int e = static_cast<int>(list[entry]);
-    load_points<SRC>(base, (cell0 + (e & (kCellFlag - 1))) * kCell + kPts * (lane & 15), nPoints, v, D);
-    return (e & kCellFlag) != 0;               /* the entry's flag (cell_list_build) */
-  }
 #pragma unroll
-  for(int j = 0; j < kPts; j++)
-    v[j] = F3{ 0.0f, 0.0f, 0.0f };
-  return false;
+    for(int j = 0; j < kPts; j++)
+      v[j] = F3{ 0.0f, 0.0f, 0.0f };
+  }
 }
 
 /* The streaming kernels are written as block bodies over an explicit LDS struct, (frame, chunk) given by the caller:
@@ -2105,28 +2098,22 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
   const unsigned int wantedQuads = fs.wantedQuads;
   const int gSlot = groundSlot;
   const int count = cell_list_build(tileMasks + static_cast<size_t>(frame) * tileMaskStride + cell0, nCells, X.cellCols,
-                                    [&](const uint2 info) -> int
+                                    [&](const uint2 info)
                                     {
                                       if((info.x & wantedQuads) == 0u)
-                                        return 0;
+                                        return false;
                                       /* the box on K1's 256 x 256 grid against each live quadrilateral's thresholds on the
                                        * same grid (liveBox, computed once per block from the doubles,
                                        * margin included) */
                                       const int x0 = info.y & 0xffu, x1 = (info.y >> 8) & 0xffu, y0 = (info.y >> 16) & 0xffu, y1 = info.y >> 24;
-                                      bool need = false, groundInside = false;
+                                      bool need = false;
                                       for(int q = 0; q < nLive; q++)
                                       {
                                         if((info.x & liveGroups[q]) == 0u)
                                           continue;
                                         const int4 b = liveBox[q];
                                         if(q == gSlot)
-                                        {
                                           need = need || !(x1 <= b.x || x0 >= b.y || y1 <= b.z || y0 >= b.w);      /* not wholly outside */
-                                          /* wholly inside all four edges: the walk then takes the cell's ground points without
-                                           * asking the quadrilateral (a third of all walked cells; as for the treads, only where
-                                           * the reference's cell map agrees with the geometry: QuadGridSegs::ok) */
-                                          groundInside = grid_box_inside(segs[q], x0, x1, y0, y1);
-                                        }
                                         else
                                         {
                                           /* wholly inside the constant cell, or inside all four edges (the tread is turned
@@ -2135,7 +2122,7 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
                                           need = need || !in;
                                         }
                                       }
-                                      return need ? (groundInside ? 3 : 1) : 0;
+                                      return need;
                                     }, cellList, listScratch);
   ph.mark(1);                                               /* cell list */
   const int nGroups = (count + 3) >> 2;
@@ -2152,14 +2139,13 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
   };
   int g = grab();
   F3 v[kPts], vn[kPts];
-  bool groundIn = false, groundInNext = false;     /* the lane's cell: its ground points all lie inside the ground quadrilateral */
   if(g < nGroups)
-    groundIn = load_cell<SRC>(base, cell0, cellList, 4 * g + (lane >> 4), count, lane, P.nPoints, v, D);
+    load_cell<SRC>(base, cell0, cellList, 4 * g + (lane >> 4), count, lane, P.nPoints, v, D);
   while(g < nGroups)
   {
     const int gNext = grab();
     if(gNext < nGroups)
-      groundInNext = load_cell<SRC>(base, cell0, cellList, 4 * gNext + (lane >> 4), count, lane, P.nPoints, vn, D);
+      load_cell<SRC>(base, cell0, cellList, 4 * gNext + (lane >> 4), count, lane, P.nPoints, vn, D);
     unsigned int key[kPts];
     #pragma unroll
     for(int j = 0; j < kPts; j++)
@@ -2175,14 +2161,9 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
       {
         /* ground: the points inside its quadrilateral count; treads: the points outside theirs */
         const bool okxy = world_xy(P, v[j], wx, wy);
-        bool in = true;
-        if(!(groundIn && q == gSlot))              /* the cell's classification already answered for its ground points */
-        {
-          const QuadTest &t = qts[q];
-          const bool fast = wx >= t.fx0 && wx < t.fx1 && wy >= t.fy0 && wy < t.fy1;
-          in = fast || quad_test(t, wx, wy);
-        }
-        if(!okxy || (in != (q == gSlot)))
+        const QuadTest &t = qts[q];
+        const bool fast = wx >= t.fx0 && wx < t.fx1 && wy >= t.fy0 && wy < t.fy1;
+        if(!okxy || ((fast || quad_test(t, wx, wy)) != (q == gSlot)))
           continue;
       }
       if(q != curQ)
@@ -2212,7 +2193,6 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
     if(FULL)
       wavewin_emit(ww, wm, win, gimg, imgWords, X.W64, X.winShiftGround, box, key, lane);
     g = gNext;
-    groundIn = groundInNext;
 #pragma unroll
     for(int j = 0; j < kPts; j++)
       v[j] = vn[j];
