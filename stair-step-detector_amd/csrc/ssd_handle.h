@@ -41,7 +41,7 @@ struct ssd_lane
   int dirtyFrames = 0;                      /* leading FrameStates whose K1 accumulators may be non-zero (k_peaks clears them) */
 };
 
-constexpr int kMaxLanes = 4;
+constexpr int kMaxLanes = 8;
 
 struct ssd_handle
 {
@@ -66,9 +66,9 @@ struct ssd_handle
   ssd_frame_result *dResults = nullptr;     /* nSlots x F */
   ssd_frame_result *hResults = nullptr;     /* nSlots x F, pinned */
   ssd_frame_result *hResultsDev = nullptr;  /* the same memory as the kernels address it (small batches write it directly) */
-  hipEvent_t resultsReady[kMaxLanes] = { nullptr, nullptr, nullptr, nullptr };
-  int resultsFrames[kMaxLanes] = { 0, 0, 0, 0 };
-  int resultsLane[kMaxLanes] = { 0, 0, 0, 0 };
+  hipEvent_t resultsReady[kMaxLanes] = {};
+  int resultsFrames[kMaxLanes] = {};
+  int resultsLane[kMaxLanes] = {};
   unsigned long long finalCount = 0;        /* enqueues that produced results */
   ssd_frame_risers *dRisers = nullptr;      /* vertical faces (extension), allocated by ssd_set_risers */
   ssd_frame_risers *hRisers = nullptr;      /* pinned */

@@ -115,8 +115,8 @@ def test_create_rejects_bad_arguments(ssd):
     cfg = ssd.default_config(640, 480)
     cfg.max_step_plateaus = 99
     assert L.ssd_create(C.byref(cfg), C.byref(cal), 0, C.byref(h)) == -1
-    # workspaces of the handle: 0 (automatic) .. 4
-    for bad in (-1, 5):
+    # workspaces of the handle: 0 (automatic) .. 8
+    for bad in (-1, 9):
         cfg = ssd.default_config(640, 480, batches_in_flight=bad)
         assert L.ssd_create(C.byref(cfg), C.byref(cal), 0, C.byref(h)) == -1 and b"batches_in_flight" in L.ssd_last_error()
     # a pixel key's row field and the one-subtraction window test of the rasterising kernels: height <= 8064
