@@ -46,6 +46,11 @@ long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, 
  * After a full enqueue it is all zero (k_final clears what it read); after ssd_enqueue_stages(.. up to SSD_STAGE_INQUAD) it
  * holds what k_inquad rastered: outside image capture only the pixel strips the bottom scan reads */
 int ssd_test_ground_image(ssd_handle *h, int frame, uint8_t *out);
+/* test hooks: the kernels' line helpers compiled for the host (no GPU needed): the line through (pq[0], pq[1]) and (pq[2], pq[3]) in
+ * doubles and in int32 (the coordinates truncated) = LineCoordinates(p, q), types.h:140-158; and Line<double>::intersection
+ * (segmentation.cpp:344-362: LineCoordinates::det / detx / dety and the 60-degree rule): returns 1 + the point, or 0 */
+int ssd_test_line_host(const double pq[4], double abc_d[3], int32_t abc_i[3]);
+int ssd_test_intersect_host(const double l[3], const double o[3], double xy[2]);
 
 /* measurement hook (bench.py, tools/clockstate.py): average milliseconds of `reps` launches of a plain 16-byte-per-lane read
  * stream over `bytes` bytes at d_ptr (tools/loadbench.hip variant C) on `stream` — what the memory system delivers right now */

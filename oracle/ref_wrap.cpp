@@ -5,6 +5,7 @@
  *   /root/reference/quadrilateralTest.cpp (QuadrilateralTest, quadrilateralTest.cpp:275-451)
  *   /root/reference/calibrationTriangle.cpp (CalibrationTriangle::load / isValid, calibrationTriangle.cpp:97-172)
  *   /root/reference/configuration.h       (struct Configuration: the compile-time constants, configuration.h:27-52)
+ *   /root/reference/types.h               (LineCoordinates<T>: the line through two points and its three determinants, types.h:117-163)
  * The reference sources are compiled where they lie (see Makefile target `ref`);
  * nothing of them is copied into this repository.  Output: oracle/_ref/libssd_ref.so.
  * TEST INFRASTRUCTURE ONLY: used to pin oracle/ssd_oracle.cpp's restatement of
@@ -97,4 +98,34 @@ extern "C" void ssdref_configuration(double out[9], int wh[2])
   out[4] = c.measuringRange.z.min; out[5] = c.measuringRange.z.max;
   out[6] = c.heightInterval; out[7] = c.minHeightAboveGround; out[8] = c.minStepDepth;
   wh[0] = c.streams.depth.width; wh[1] = c.streams.depth.height;
+}
+
+/* LineCoordinates<T> (types.h:117-163; included through stairs.h): the base of every line of the path (Line<int>, Line<double>,
+ * segmentation.cpp:321-407; StairsDetector::Line, pointcloud.cpp:514-526).  Its coefficients and determinants are protected:
+ * a derived class opens them. */
+namespace
+{
+template<typename T>
+struct OpenLine : stairs::LineCoordinates<T>
+{
+  struct P { T x, y; };
+  OpenLine(const P &p, const P &q) : stairs::LineCoordinates<T>(p, q) {}
+  OpenLine(T a, T b, T c) : stairs::LineCoordinates<T>(a, b, c) {}
+  void coefficients(T out[3]) const { out[0] = this->_a; out[1] = this->_b; out[2] = this->_c; }
+  void dets(const OpenLine &o, T out[3]) const { out[0] = this->det(o); out[1] = this->detx(o); out[2] = this->dety(o); }
+};
+}
+/* line through p and q: abc[3] */
+extern "C" void ssdref_line_d(const double pq[4], double abc[3])
+{
+  OpenLine<double>(OpenLine<double>::P{ pq[0], pq[1] }, OpenLine<double>::P{ pq[2], pq[3] }).coefficients(abc);
+}
+extern "C" void ssdref_line_i(const int pq[4], int abc[3])
+{
+  OpenLine<int>(OpenLine<int>::P{ pq[0], pq[1] }, OpenLine<int>::P{ pq[2], pq[3] }).coefficients(abc);
+}
+/* det, detx, dety of two lines given by their coefficients */
+extern "C" void ssdref_line_dets_d(const double l[3], const double o[3], double out[3])
+{
+  OpenLine<double>(l[0], l[1], l[2]).dets(OpenLine<double>(o[0], o[1], o[2]), out);
 }

@@ -1601,6 +1601,25 @@ void ssdo_sort_perm(const double *dist, int n, int32_t *perm)
     perm[i] = int32_t(v[size_t(i)].i);
 }
 
+/* the oracle's own line helpers (lineThrough, LineT::det / detx / dety above; types.h:117-163), for the pin against the
+ * reference's LineCoordinates<T> */
+void ssdo_line_d(const double pq[4], double abc[3])
+{
+  const Lined l = lineThrough<double>(P2{ pq[0], pq[1] }, P2{ pq[2], pq[3] });
+  abc[0] = l.a; abc[1] = l.b; abc[2] = l.c;
+}
+void ssdo_line_i(const int32_t pq[4], int32_t abc[3])
+{
+  struct Pi { int x, y; };
+  const Linei l = lineThrough<int>(Pi{ pq[0], pq[1] }, Pi{ pq[2], pq[3] });
+  abc[0] = l.a; abc[1] = l.b; abc[2] = l.c;
+}
+void ssdo_line_dets_d(const double l[3], const double o[3], double out[3])
+{
+  const Lined a{ l[0], l[1], l[2] }, b{ o[0], o[1], o[2] };
+  out[0] = a.det(b); out[1] = a.detx(b); out[2] = a.dety(b);
+}
+
 int ssdo_best_line(const int32_t *pts_xy, int n, int32_t line_out[3])
 {
   if(n < 2)

@@ -165,6 +165,10 @@ int ssdo_serialize(int n_steps, const double *steps_ext /* n x 9 */, char *buf, 
 int ssdo_quad_test(const double quad[8], const double *pts_xy, int n, uint8_t *inside);
 double ssdo_hypot(double a, double b);
 int ssdo_best_line(const int32_t *pts_xy, int n, int32_t line_out[3]);
+/* LineCoordinates<T> (types.h:117-163): the line through two points (pq = x1, y1, x2, y2) and det / detx / dety of two lines */
+void ssdo_line_d(const double pq[4], double abc[3]);
+void ssdo_line_i(const int32_t pq[4], int32_t abc[3]);
+void ssdo_line_dets_d(const double l[3], const double o[3], double out[3]);
 /* the permutation std::sort leaves (keys compared by distance only, as segmentation.cpp:724): perm[k] = original index
  * of the element at sorted position k */
 void ssdo_sort_perm(const double *dist, int n, int32_t *perm);

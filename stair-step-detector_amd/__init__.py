@@ -141,7 +141,7 @@ SOURCE_EXPORTS = [
 ]
 # libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
 HOOK_EXPORTS = [
-    "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_ground_image", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_best_line_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
+    "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_ground_image", "ssd_test_line_host", "ssd_test_intersect_host", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_best_line_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
     "ssd_test_sort_device", "ssd_test_stream_read", "ssd_testhooks_last_error",
 ]
 SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
@@ -256,6 +256,8 @@ def hooks_lib():
     L.ssd_test_frame_state.argtypes = [vp, i32, vp, C.c_size_t, vp]
     L.ssd_test_frame_state.restype = C.c_longlong
     L.ssd_test_ground_image.argtypes = [vp, i32, vp]
+    L.ssd_test_line_host.argtypes = [vp, vp, vp]
+    L.ssd_test_intersect_host.argtypes = [vp, vp, vp]
     L.ssd_test_sort_host.argtypes = [vp, i32, vp]
     L.ssd_test_sort_device.argtypes = [i32, vp, i32, vp]
     L.ssd_test_quad_device.argtypes = [i32, vp, vp, i32, vp, C.POINTER(C.c_int)]
@@ -558,6 +560,21 @@ def stream_read_ms(d_ptr, nbytes, reps=5, device=0, stream=None):
     ms = C.c_float(0.0)
     _check(hooks_lib().ssd_test_stream_read(device, C.c_void_p(d_ptr), nbytes, reps, C.c_void_p(stream), C.byref(ms)), "hooks")
     return float(ms.value)
+
+
+def line_host(pq):
+    """test hook: the kernels' line through two points -> (abc as doubles, abc as int32 from the truncated coordinates)"""
+    a = np.ascontiguousarray(pq, dtype=np.float64).reshape(4)
+    d, i = np.zeros(3), np.zeros(3, dtype=np.int32)
+    _check(hooks_lib().ssd_test_line_host(a.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), i.ctypes.data_as(C.c_void_p)), "hooks")
+    return d, i
+
+
+def intersect_host(l, o):
+    """test hook: the kernels' Line<double>::intersection -> (found, x, y)"""
+    a, b, xy = np.ascontiguousarray(l, dtype=np.float64), np.ascontiguousarray(o, dtype=np.float64), np.zeros(2)
+    rc = _check(hooks_lib().ssd_test_intersect_host(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), xy.ctypes.data_as(C.c_void_p)), "hooks")
+    return bool(rc), float(xy[0]), float(xy[1])
 
 
 def sort_perm(dist, device=None):

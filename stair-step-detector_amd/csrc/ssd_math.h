@@ -80,7 +80,7 @@ __device__ __forceinline__ LineD normalized_line(double a, double b, double c)
   return { a / h, b / h, c / h };
 }
 /* Line<double>::intersection, segmentation.cpp:344-362; returns false for angles <= 60 degrees */
-__device__ __forceinline__ bool intersect60(const LineD &l, const LineD &o, double &x, double &y)
+__host__ __device__ __forceinline__ bool intersect60(const LineD &l, const LineD &o, double &x, double &y)
 {
   const double kTan60 = 1.7320508075688772;       /* std::numbers::sqrt3 */
   const double numerator = l.a * o.b - o.a * l.b;

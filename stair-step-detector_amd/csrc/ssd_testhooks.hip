@@ -179,6 +179,29 @@ long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, 
   return static_cast<long long>(n);
 }
 
+/* the kernels' line helpers (csrc/ssd_math.h: line_through_i / line_through_d = LineCoordinates(p, q), types.h:140-158; intersect60 =
+ * Line<double>::intersection, segmentation.cpp:344-362, whose numerators are LineCoordinates::det / detx / dety) compiled for the host */
+int ssd_test_line_host(const double pq[4], double abc_d[3], int32_t abc_i[3])
+{
+  if(!pq || !abc_d || !abc_i)
+    return fail(SSD_E_ARG, "ssd_test_line_host: null");
+  const LineD d = line_through_d(pq[0], pq[1], pq[2], pq[3]);
+  abc_d[0] = d.a; abc_d[1] = d.b; abc_d[2] = d.c;
+  const LineI i = line_through_i(static_cast<int>(pq[0]), static_cast<int>(pq[1]), static_cast<int>(pq[2]), static_cast<int>(pq[3]));
+  abc_i[0] = i.a; abc_i[1] = i.b; abc_i[2] = i.c;
+  return SSD_OK;
+}
+/* returns 1 and the intersection point when the lines meet at more than 60 degrees, else 0 */
+int ssd_test_intersect_host(const double l[3], const double o[3], double xy[2])
+{
+  if(!l || !o || !xy)
+    return fail(SSD_E_ARG, "ssd_test_intersect_host: null");
+  double x = 0.0, y = 0.0;
+  const bool ok = intersect60(LineD{ l[0], l[1], l[2] }, LineD{ o[0], o[1], o[2] }, x, y);
+  xy[0] = x; xy[1] = y;
+  return ok ? 1 : 0;
+}
+
 int ssd_test_ground_image(ssd_handle *h, int frame, uint8_t *out)
 {
   if(!h || !out || frame < 0 || frame >= h->F)

@@ -1,4 +1,4 @@
-"""Generates tests/golden/ref_serialize.json, ref_quadtest.json, ref_configuration.json and ref_print_stairs.json by running
+"""Generates tests/golden/ref_serialize.json, ref_quadtest.json, ref_configuration.json, ref_lines.json and ref_print_stairs.json by running
 the REAL reference code on seeded inputs: oracle/_ref/libssd_ref.so (= /root/reference/stairs.cpp + quadrilateralTest.cpp +
 configuration.h compiled in place by oracle/Makefile), and /root/reference/print-stairs.py — the reference's own consumer of
 the stdout line — run as a subprocess where it lies, fed the lines of tests/golden/oracle_goldens.json on stdin.
@@ -99,6 +99,28 @@ def main():
     with open(os.path.join(HERE, "ref_configuration.json"), "w") as f:
         json.dump({"what": "stairs::Configuration{} of /root/reference/configuration.h:27-52 (doubles as hex)",
                    "values": {n: float(v).hex() for n, v in zip(names, vals)}, "depth_stream": {"width": wh[0], "height": wh[1]}}, f, indent=1)
+
+    # types.h:117-163 — LineCoordinates<T>: the line through two points (int and double) and det / detx / dety of two lines
+    cases = []
+    specials = [0.0, -0.0, 1.0, -1.0, 0.1, 1e-300, 1e300, float("inf"), float("nan"), 0.17005879162516252, 1023.0, 767.0]
+    for k in range(400):
+        if k < 300:
+            pq = rng.normal(0, [1, 1, 1, 1][k % 4] * 10.0 ** int(rng.integers(-3, 4)), 4)
+        else:
+            pq = rng.choice(specials, 4)
+        cases.append({"pq": hexlist(pq), "abc": hexlist(ref.line(pq))})
+    icases = []
+    for k in range(300):
+        pq = rng.integers(-2 ** (4 + k % 12), 2 ** (4 + k % 12), 4).astype(np.int32)       # up to 2^15: products stay inside int32 as in the path
+        icases.append({"pq": [int(v) for v in pq], "abc": [int(v) for v in ref.line(pq, integer=True)]})
+    dcases = []
+    for k in range(400):
+        l, o = (rng.normal(0, 10.0 ** int(rng.integers(-2, 5)), 3), rng.normal(0, 10.0 ** int(rng.integers(-2, 5)), 3)) if k < 320 else (rng.choice(specials, 3), rng.choice(specials, 3))
+        dcases.append({"l": hexlist(l), "o": hexlist(o), "dets": hexlist(ref.line_dets(l, o))})
+    with open(os.path.join(HERE, "ref_lines.json"), "w") as f:
+        json.dump({"what": "stairs::LineCoordinates<T> of /root/reference/types.h:117-163 (doubles as hex): coefficients of the line through p, q; det / detx / dety of two lines",
+                   "double": cases, "int": icases, "dets": dcases}, f, indent=0)
+    print("lines:", len(cases), len(icases), len(dcases))
 
     # print-stairs.py:53-77 — the reference's terminal consumer of the line: what IT reads out of each golden line
     import subprocess

@@ -89,6 +89,20 @@ class Oracle:
         lib.ssdo_deproject.argtypes = [C.c_float] * 5 + [i32, i32, vp, vp]
         lib.ssdo_sort_perm.argtypes = [vp, i32, vp]
         lib.ssdo_risers.argtypes = [C.POINTER(Config), C.POINTER(Calibration), vp, C.c_double, i32, C.POINTER(Riser)]
+        for f in (lib.ssdo_line_d, lib.ssdo_line_i):
+            f.argtypes, f.restype = [vp, vp], None
+        lib.ssdo_line_dets_d.argtypes, lib.ssdo_line_dets_d.restype = [vp, vp, vp], None
+
+    def line(self, pq, integer=False):
+        dt = np.int32 if integer else np.float64
+        a, out = np.ascontiguousarray(pq, dtype=dt).reshape(4), np.zeros(3, dtype=dt)
+        (self.lib.ssdo_line_i if integer else self.lib.ssdo_line_d)(a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def line_dets(self, l, o):
+        a, b, out = np.ascontiguousarray(l, dtype=np.float64), np.ascontiguousarray(o, dtype=np.float64), np.zeros(3)
+        self.lib.ssdo_line_dets_d(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        return out
 
     def config(self, width, height):
         cfg = Config()
@@ -193,6 +207,22 @@ class Ref:
         lib.ssdref_load_triangle.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(C.c_int)]
         lib.ssdref_configuration.argtypes = [C.c_void_p, C.c_void_p]
         lib.ssdref_configuration.restype = None
+        for f in (lib.ssdref_line_d, lib.ssdref_line_i):
+            f.argtypes, f.restype = [C.c_void_p, C.c_void_p], None
+        lib.ssdref_line_dets_d.argtypes, lib.ssdref_line_dets_d.restype = [C.c_void_p] * 3, None
+
+    def line(self, pq, integer=False):
+        """LineCoordinates<T>(p, q) of the reference (types.h:140-158) -> its three coefficients"""
+        dt = np.int32 if integer else np.float64
+        a, out = np.ascontiguousarray(pq, dtype=dt).reshape(4), np.zeros(3, dtype=dt)
+        (self.lib.ssdref_line_i if integer else self.lib.ssdref_line_d)(a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def line_dets(self, l, o):
+        """LineCoordinates<double>::det / detx / dety (types.h:128-139)"""
+        a, b, out = np.ascontiguousarray(l, dtype=np.float64), np.ascontiguousarray(o, dtype=np.float64), np.zeros(3)
+        self.lib.ssdref_line_dets_d(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        return out
 
     def configuration(self):
         """the reference's default-constructed Configuration (configuration.h:27-52) -> (9 doubles, (width, height))"""

@@ -305,6 +305,51 @@ def test_the_references_own_consumer_reads_the_same_numbers(ssd):
     assert seen_steps > 200
 
 
+def _same(a, b):
+    """bitwise equality of doubles, NaNs of either sign / payload counted equal (a NaN's sign is not specified through arithmetic)"""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return bool(np.all((a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))))
+
+
+def test_lines_are_the_references_line_coordinates(ssd, oracle):
+    """Reference pin of types.h:117-163 (LineCoordinates<T>, the base of every line of the path: Line<int> / Line<double>,
+    segmentation.cpp:321-407; StairsDetector::Line, pointcloud.cpp:514-526): the line through two points in int and in double and
+    the determinants det / detx / dety, as the reference's own header computes them (compiled into oracle/_ref; golden
+    tests/golden/ref_lines.json) against the oracle's lineThrough / LineT and the kernels' line_through_i / line_through_d /
+    intersect60 (csrc/ssd_math.h, host build)."""
+    import json
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_lines.json")))
+    r = ob.load_ref()
+    unhex = lambda xs: np.array([float.fromhex(x) for x in xs])
+    for c in fx["double"]:
+        pq, want = unhex(c["pq"]), unhex(c["abc"])
+        assert _same(oracle.line(pq), want) and _same(ssd.line_host(pq)[0], want), c
+        if r is not None:
+            assert _same(r.line(pq), want)
+    for c in fx["int"]:
+        pq, want = np.array(c["pq"], dtype=np.int32), np.array(c["abc"], dtype=np.int32)
+        assert np.array_equal(oracle.line(pq, integer=True), want) and np.array_equal(ssd.line_host(pq.astype(np.float64))[1], want), c
+        if r is not None:
+            assert np.array_equal(r.line(pq, integer=True), want)
+    kTan60 = 1.7320508075688772
+    met = 0
+    for c in fx["dets"]:
+        l, o, want = unhex(c["l"]), unhex(c["o"]), unhex(c["dets"])
+        assert _same(oracle.line_dets(l, o), want), c
+        if r is not None:
+            assert _same(r.line_dets(l, o), want)
+        # the kernels' intersection = detx / det, dety / det whenever |det| > |dot| tan 60 degrees (segmentation.cpp:350-362)
+        found, x, y = ssd.intersect_host(l, o)
+        with np.errstate(all="ignore"):
+            dot = l[0] * o[0] + l[1] * o[1]
+            expect = bool(abs(want[0]) > abs(dot) * kTan60)
+            assert found == expect, c
+            if found:
+                assert _same([x, y], [want[1] / want[0], want[2] / want[0]]), c
+                met += 1
+    assert met > 100
+
+
 def test_default_config_is_the_references_configuration(ssd, oracle):
     """Reference pin of configuration.h:27-52: ssd_default_config (and the oracle's) against stairs::Configuration{} as the
     reference's own header defines it — compiled into oracle/_ref (live, where that exists) and as the committed golden
