@@ -129,3 +129,20 @@ extern "C" void ssdref_line_dets_d(const double l[3], const double o[3], double 
 {
   OpenLine<double>(l[0], l[1], l[2]).dets(OpenLine<double>(o[0], o[1], o[2]), out);
 }
+
+/* CalibrationTriangle::load() in `dir_in`, then ::save() (calibrationTriangle.cpp:127-146) in `dir_out`: the reference's own
+ * writer of the file the loaders read.  0 = ok, 1 = load failed, 3 = save failed */
+extern "C" int ssdref_resave_triangle(const char *dir_in, const char *dir_out)
+{
+  char cwd[4096];
+  if(!getcwd(cwd, sizeof cwd) || chdir(dir_in) != 0)
+    return -1;
+  stairs::CalibrationTriangle t;
+  const int rc = t.load();
+  int rs = -1;
+  if(rc == 0 && chdir(cwd) == 0 && chdir(dir_out) == 0)
+    rs = t.save();
+  if(chdir(cwd) != 0)
+    return -1;
+  return rc != 0 ? 1 : (rs != 0 ? 3 : 0);
+}

@@ -243,6 +243,11 @@ class Ref:
         rc = self.lib.ssdref_load_triangle(directory.encode(), w.ctypes.data_as(C.c_void_p), C.byref(side))
         return rc, w.reshape(3, 3), side.value
 
+    def resave_triangle(self, dir_in, dir_out):
+        """CalibrationTriangle::load() in dir_in, ::save() in dir_out (the reference's own writer)"""
+        self.lib.ssdref_resave_triangle.argtypes = [C.c_char_p, C.c_char_p]
+        return self.lib.ssdref_resave_triangle(dir_in.encode(), dir_out.encode())
+
     def quad_test(self, quad, pts):
         q = np.ascontiguousarray(quad, dtype=np.float64).reshape(8)
         p = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 2)

@@ -443,6 +443,18 @@ def test_calibration_loader_matches_oracle_and_reference_triangle(ssd, oracle, t
     if ref is not None:                       # the real CalibrationTriangle::load / isValid
         rc3, w_r, side = ref.load_triangle(str(tmp_path))
         assert rc3 == 0 and side == 2 and np.array_equal(w_r, t.world_points)
+        # ... and the real CalibrationTriangle::save (calibrationTriangle.cpp:127-146): the file the reference itself writes
+        # must load here to what the reference loads from it (its default stream precision drops digits: compare after the trip)
+        import shutil
+        out = tmp_path / "resaved"
+        out.mkdir()
+        assert ref.resave_triangle(str(tmp_path), str(out)) == 0
+        shutil.copy(tmp_path / "calibration-points", out / "calibration-points")
+        t2, loaded2 = ssd.GeometricCalibration.load(str(out))
+        rc4, w_r2, side2 = ref.load_triangle(str(out))
+        assert loaded2 and rc4 == 0 and side2 == 2 and np.array_equal(t2.world_points, w_r2)
+        assert np.allclose(t2.world_points, t.world_points, atol=1e-5)
+        assert oracle.calibration_load(str(out))[0] == 0 and np.array_equal(oracle.calibration_load(str(out))[1], w_r2)
 
 
 def test_calibration_loader_falls_back_to_identity_like_the_reference(ssd, oracle, tmp_path):
