@@ -12,7 +12,7 @@ its own F frames on its own GPU (frames are independent: no collective on the da
 value = N * F * K / max-over-ranks time.
 
 The timed steps go through the plain handle API (ssd_enqueue / ssd_fetch_back) of a handle that keeps
-ssd_config::batches_in_flight = 3 batches in flight on its own streams (the default from 128 frames per batch on): the
+ssd_config::batches_in_flight = 3 batches in flight on its own streams (the default from 16 frames per batch on): the
 steps overlap, so an event-bracketed stage inside them is no kernel duration.  `stage_ms` and `roofline` therefore come
 from a few EXTRA steps after the timed region, run one at a time with HIP events between the launches
 ("stage_ms_source": "separate timed steps"), next to a plain read stream over the same buffer (`k1_over_plain_stream`).
@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--input", choices=["float3", "depth16"], default="float3",
                     help="float3 = xyz vertices (the metric's input); depth16 = 16-bit depth frames deprojected on the fly (SURVEY 8f rank 1)")
     ap.add_argument("--batches-in-flight", type=int, default=0,
-                    help="workspaces of the handle (ssd_config::batches_in_flight): 0 = the library's default (3 from 128 frames per batch on); "
+                    help="workspaces of the handle (ssd_config::batches_in_flight): 0 = the library's default (3 from 16 frames per batch on); "
                          "1 = strictly one batch at a time — what the profiling passes use, so that a kernel's traced duration is its own")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-hostfed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg reported beside `value`")

@@ -72,12 +72,13 @@ typedef struct
   double min_step_depth;                             /* 0.1 */
   int32_t max_frames_per_batch;                      /* a workspace is sized for this many frames per call */
   int32_t max_step_plateaus;                         /* <= SSD_MAX_STEP_IMAGES */
-  /* Workspaces of the handle = batches it keeps in flight (1..8; 0 = automatic: 3 when max_frames_per_batch >= 128, else 1).
+  /* Workspaces of the handle = batches it keeps in flight (1..8; 0 = automatic: 3 when max_frames_per_batch >= 16, else 1).
    * 1: every call runs on the caller's stream, strictly in stream order (lowest latency; single frames).
    * > 1: successive ssd_enqueue calls take the workspaces in turn, each on a stream of the handle's own, so that the
    *      launches of one batch fill the gaps the one-block-per-frame kernels of the others leave.  XGA, frames/s with 1 / 2 / 3 /
    *      4 / 6 in flight (profiles/r03_depths.json): 1024 frames per call 272 k / 290 k / 301 k / 294 k / 307 k, 256: 237 k /
-   *      286 k / 306 k / 295 k / 314 k, 64: 188 k / 248 k / 270 k / 251 k / 284 k (3 and 6 sit better than 4 and 5).  Memory = batches_in_flight x 1.75 MB per XGA frame of max_frames_per_batch (1024 frames, 3 in flight: 5.4 GB
+   *      286 k / 306 k / 295 k / 314 k, 64: 188 k / 248 k / 270 k / 251 k / 284 k, 16: 94 k / 165 k / 214 k / 170 k / 228 k
+   *      (3 and 6 sit better than 4 and 5) — provided the caller enqueues ahead of its fetches.  Memory = batches_in_flight x 1.75 MB per XGA frame of max_frames_per_batch (1024 frames, 3 in flight: 5.4 GB
    *      beside 9.7 GB of frames).  Stream contract then: a batch starts behind the work `stream` holds at the time of the
    *      call, but work put on `stream` afterwards is NOT ordered behind the batch — its frames must stay untouched until
    *      its results were fetched, or until a stream was made to wait for it with ssd_stream_wait. */

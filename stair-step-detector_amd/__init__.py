@@ -280,7 +280,7 @@ def device_count():
 
 
 def default_config(width, height, max_frames_per_batch=64, max_step_plateaus=MAX_STEP_IMAGES, batches_in_flight=0):
-    """batches_in_flight: workspaces of the handle (ssd_config); 0 = automatic (3 from 128 frames per batch on, else 1)"""
+    """batches_in_flight: workspaces of the handle (ssd_config); 0 = automatic (3 from 16 frames per batch on, else 1)"""
     cfg = Config()
     _check(lib().ssd_default_config(C.byref(cfg), width, height))
     cfg.max_frames_per_batch = max_frames_per_batch

@@ -60,10 +60,16 @@ void tuning_from_env(ssd_tuning &t)
 }
 #endif
 
-/* ssd_config::batches_in_flight = 0: handles for batches (>= kOverlapMinFrames frames per call) get kOverlapDepth
- * workspaces; measured with ssd_pipeline_* (the same overlap across handles), XGA, depth 1 / 2 / 3 / 4: 64 frames per batch
- * 181 k / 235 k / 248 k / 232 k frames/s, 256: 230 k / 272 k / 282 k / 274 k, 1024: 257 k / 284 k / 304 k / 295 k */
-constexpr int kOverlapMinFrames = 128;
+/* ssd_config::batches_in_flight = 0: handles for batches (>= kOverlapMinFrames frames per call) get kOverlapDepth workspaces.
+ * XGA, frames/s with 1 / 2 / 3 / 4 / 5 / 6 / 8 batches in flight (tools/depths.py, profiles/r03_depths.json: three and six sit
+ * better than four and five; six buys 2-5 % over three for twice the memory):
+ *   1024 frames per call 272 k / 290 k / 301 k / 294 k / 298 k / 307 k / 310 k      256: 237 k / 286 k / 306 k / 295 k / 303 k / 314 k / 306 k
+ *     64: 188 k / 248 k / 270 k / 251 k / 268 k / 284 k / 270 k                      32: 140 k / 225 k / 253 k / 215 k / 244 k / 256 k / 246 k
+ *     16:  94 k / 165 k / 214 k / 170 k / 203 k / 228 k / 206 k                       8:  59 k / 107 k / 140 k / 114 k / 130 k / 144 k / 135 k
+ * The fewer frames a call has, the more of it is the latency of its seven dependent launches, and the more other batches in
+ * flight fill: from 16 frames per call on a handle is taken to be fed for throughput; below, every call runs on the caller's
+ * stream in strict order (the single-frame case: nothing between the call and the first launch). */
+constexpr int kOverlapMinFrames = 16;
 constexpr int kOverlapDepth = 3;
 
 } // namespace

@@ -260,7 +260,7 @@ def test_calls_on_different_streams_are_ordered_by_the_library(ssd, oracle, gpu_
     n, W, H = 24, 640, 480
     sc_list = scenes.batch_scenes(ssd, W, H, 2 * n, base_seed=52000, rng_seed=9)
     trans = ssd.transformation_for_scene(sc_list[0])
-    cfg = ssd.default_config(W, H, max_frames_per_batch=n)
+    cfg = ssd.default_config(W, H, max_frames_per_batch=n, batches_in_flight=1)        # one workspace: strict stream order is the contract
     host = ssd.synth_host(sc_list)
     a = ssd.DeviceBuffer(W * H * 12 * n, gpu_device)
     b = ssd.DeviceBuffer(W * H * 12 * n, gpu_device)
