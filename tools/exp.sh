@@ -1,6 +1,9 @@
 #!/bin/bash
 # tools/exp.sh TAG "ENV=VAL ENV=VAL" ... — one short bench per environment setting (GPU box, via gpurun); prints the stage
 # times.  A setting that contains the word FHD runs the fhd_stress workload.
+# The SSD_* geometry variables are read only by the tools build of the library (the product has no getenv):
+#   make -C stair-step-detector_amd/csrc OUT=../lib_tuning EXTRA=-DSSD_TUNING ../lib_tuning/libssd_hip.so
+export SSD_HIP_LIB=${SSD_HIP_LIB:-$GRAFT_REPO_ROOT/stair-step-detector_amd/lib_tuning/libssd_hip.so}
 TAG=$1; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 i=0

@@ -1,5 +1,8 @@
 #!/bin/bash
 # tools/exp_frames.sh TAG "FRAMES ENV=VAL ..." ... — like tools/exp.sh with --frames as the first word of each setting
+# The SSD_* geometry variables are read only by the tools build of the library (the product has no getenv):
+#   make -C stair-step-detector_amd/csrc OUT=../lib_tuning EXTRA=-DSSD_TUNING ../lib_tuning/libssd_hip.so
+export SSD_HIP_LIB=${SSD_HIP_LIB:-$GRAFT_REPO_ROOT/stair-step-detector_amd/lib_tuning/libssd_hip.so}
 TAG=$1; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 i=0
