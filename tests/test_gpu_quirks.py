@@ -161,3 +161,25 @@ def test_more_step_plateaus_than_image_slots_is_flagged(ssd, gpu_device):
     ok = det.process_host(cloud(planes[:17]))[0]                # ground + 16 step plateaus fit
     det.close()
     assert not (ok.status & ssd.ST_OVERFLOW)
+
+
+@pytest.mark.parametrize("res", [(64, 48), (160, 120), (200, 150), (333, 257), (802, 602), (1282, 722), (2048, 1536)])
+def test_resolutions_off_the_beaten_path(ssd, oracle, gpu_device, res):
+    """Resolutions no camera mode has — tiny, odd, not a multiple of 4 / 64 / 50, larger than FHD: the scan-column strips of
+    the ground raster (W/2 mod 50), the cell columns, the unaligned 12-byte loads and the bit images' ragged last words all
+    depend on them.  A 3-step scene and a bare-ground scene each; every intermediate where the oracle is quick enough, results
+    always; single call and a batch of three."""
+    W, H = res
+    for n_steps in (3, 0):
+        sc = ssd.make_scene(W, H, n_steps=n_steps, seed=4200 + W + n_steps, sigma=0.0015)
+        trans = ssd.transformation_for_scene(sc)
+        cfg = ssd.default_config(W, H, max_frames_per_batch=3)
+        xyz = ssd.synth_host([sc])[0]
+        det = ssd.Detector(cfg, trans, gpu_device)
+        rep = parity.check_frame(ssd, oracle, det, cfg, trans.constants, xyz, images=W * H <= 1300000)
+        assert rep.get("max_height_err", 0.0) <= parity.TOL_HEIGHT and rep.get("max_corner_err", 0.0) == 0.0
+        three = np.stack([xyz, xyz[::-1].copy() * 0.0, xyz])             # the frame, an all-invalid frame, the frame again
+        res3 = det.process_host(three)
+        assert bytes(res3[0]) == bytes(res3[2]) and res3[1].n_steps == 0
+        parity.check_results_only(ssd, oracle, cfg, trans.constants, xyz, res3[0])
+        det.close()
