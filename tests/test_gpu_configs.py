@@ -361,6 +361,25 @@ def test_handle_keeps_three_batches_in_flight(ssd, oracle, gpu_device):
     flat = [r for w in want for r in w]
     for i in range(0, len(flat), 9):
         parity.check_results_only(ssd, oracle, det.cfg, trans.constants, host[i], ssd.FrameResult.from_buffer_copy(flat[i]))
+    # other workspace counts, the largest included: as many batches ahead of the fetches as there are workspaces
+    for depth in (2, 5, 8):
+        d = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=cap, batches_in_flight=depth), trans, gpu_device)
+        assert d.batches_in_flight == depth
+        ahead = depth - 1
+        order = list(range(len(sizes))) * 2
+        got = {}
+        for k, i in enumerate(order):
+            d.enqueue(buf.ptr + starts[i] * fb, sizes[i])
+            if k >= ahead:
+                j = order[k - ahead]
+                got[k - ahead] = (j, [bytes(r) for r in d.fetch(sizes[j], back=ahead)])
+        for back in range(ahead - 1, -1, -1):
+            j = order[len(order) - 1 - back]
+            got[len(order) - 1 - back] = (j, [bytes(r) for r in d.fetch(sizes[j], back=back)])
+        assert len(got) == len(order) and all(res == want[j] for j, res in got.values()), "depth %d" % depth
+        with pytest.raises(ssd.SsdError, match="no enqueue at that position"):
+            d.fetch(1, back=max(2, depth))
+        d.close()
     # a producer that recycles a batch's frame buffer: ordered behind the batch by ssd_stream_wait, no host synchronisation
     hip = C.CDLL("libamdhip64.so")
     st = C.c_void_p()
