@@ -12,9 +12,10 @@ NAMES = {0: ("k_outline", ["fs loads", "init", "closing+extents", "scans+lists",
                            "rank", "ties", "corners+store", "clear"]),
          1: ("k_quads", ["entry", "loads+ballots", "ground quad", "-", "build_quad_test", "table+segs", "lutLive", "wanted+tail"]),
          2: ("k_final", ["entry", "closing+extents", "scan", "BestLine", "surfaces+results", "risers+sync", "clear"])}
-sc = scenes.batch_scenes(ssd, 1024, 768, 1, base_seed=4242)
+FHD = len(sys.argv) > 1 and sys.argv[1] == "fhd"          # python tools/phases.py fhd: one frame of the FHD stress workload (config 5)
+sc = scenes.fhd_stress_scenes(ssd, 1, base_seed=9000) if FHD else scenes.batch_scenes(ssd, 1024, 768, 1, base_seed=4242)
 xyz = ssd.synth_host(sc)
-one = ssd.Detector(ssd.default_config(1024, 768, max_frames_per_batch=1), ssd.transformation_for_scene(sc[0]), 0)
+one = ssd.Detector(ssd.default_config(sc[0].width, sc[0].height, max_frames_per_batch=1), ssd.transformation_for_scene(sc[0]), 0)
 buf = ssd.DeviceBuffer(xyz[0].nbytes, 0)
 buf.upload(xyz[:1])
 L = ssd.lib()
