@@ -152,7 +152,8 @@ int ssd_fetch(ssd_handle *h, ssd_frame_result *results, int nframes, void *strea
  * batches in flight: two enqueues ahead, back = 2.  back = 0 is ssd_fetch.  Waits only for that batch.  A slot is reused by
  * the enqueue max(2, batches_in_flight) calls later: fetch before that. */
 int ssd_fetch_back(ssd_handle *h, ssd_frame_result *results, int nframes, int back);
-/* makes `stream` (a hipStream_t, NULL = default stream) wait for the batch `back` enqueues ago, without blocking the host:
+/* makes `stream` (a hipStream_t, NULL = default stream) wait for the batch `back` enqueues ago (counted like ssd_fetch_back: the
+ * enqueues that produced results; a partial ssd_enqueue_stages run without the last stage is not one), without blocking the host:
  * what a producer that overwrites the batch's frames, or a consumer of device-side state, needs when the handle keeps
  * several batches in flight (with one workspace the caller's stream is already ordered) */
 int ssd_stream_wait(ssd_handle *h, int back, void *stream);
