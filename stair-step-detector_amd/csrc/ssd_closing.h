@@ -190,6 +190,14 @@ __host__ __device__ __forceinline__ void closed_scan_column(const BitImg &im, in
 #pragma unroll
     for(int k = 0; k < kRows; k++)
       h[4 + k] = strip_hdil(c, y0 + 2 + k, yEnd);
+    /* nothing lit within two rows of the step's rows (the common case where a few outlier pixels have stretched the bounding
+     * box over an otherwise empty image): no closed pixel either — a closed pixel needs its own row's dilation lit */
+    unsigned int any = 0u;
+#pragma unroll
+    for(int k = 0; k < kRows + 4; k++)
+      any |= h[k];
+    if(any == 0u)
+      continue;                                          /* (the rows carried over to the next step are zero as well) */
     /* f bit i: the dilated image is lit at every in-image pixel of x-1 .. x+1 in row y0 - 2 + i (rows outside: set) */
     unsigned int f = 0u;
 #pragma unroll
