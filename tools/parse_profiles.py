@@ -72,6 +72,30 @@ def main():
     stats = glob.glob(os.path.join(src, "trace_fhd", "*", "*kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats_fhd_stress.csv"))
+    # BASELINE configs[4]: HBM read traffic and bandwidth fraction of the streaming kernels on the FHD stress batch (256 frames)
+    fetch_fhd = glob.glob(os.path.join(src, "fetch_fhd", "*", "*counter_collection.csv"))
+    if fetch_fhd and stats:
+        ff = per_kernel(fetch_fhd[0], "FETCH_SIZE")
+        avg_ns = {}
+        for r in csv.DictReader(open(stats[0])):
+            avg_ns[r["Name"].split("(")[0].replace("void ", "")] = float(r["AverageNs"])
+        alg = 12.0 * 1920 * 1080 * 256
+        o = {"note": "FHD stress (BASELINE configs[4]): 256 frames of 1920x1080 per launch; FETCH_SIZE KiB x 1024 x 2 for the streaming kernels "
+                     "(MI355X_MICROARCH.md: the counter reads half of a 16-B-per-lane stream); durations from the --stats pass of the same command",
+             "algorithmic_bytes_per_launch": alg, "kernels": {}}
+        for k, v in sorted(ff.items()):
+            if not k.startswith("ssd::") or any(n in k for n in NOT_PIPELINE):
+                continue
+            corr = 2.0 if any(x in k for x in STREAMING) else 1.0
+            rd = v * 1024 * corr
+            e = {"hbm_read_bytes": rd, "avg_ms": None if k not in avg_ns else avg_ns[k] / 1e6}
+            if k in avg_ns and avg_ns[k] > 0:
+                e["hbm_read_GBps"] = rd / (avg_ns[k] * 1e-9) / 1e9
+                e["frac_of_8TBps_peak"] = e["hbm_read_GBps"] / 8000.0
+            if "k_hist" in k and k in avg_ns:
+                e["algorithmic_frac_of_peak"] = alg / (avg_ns[k] * 1e-9) / 1e9 / 8000.0
+            o["kernels"][k] = e
+        json.dump(o, open(os.path.join(dst, tag + "_hbm_traffic_fhd_stress.json"), "w"), indent=1)
     # instruction / issue counters of a tools/pmc.sh run (optional second argument: its tag)
     if len(sys.argv) > 2:
         agg = collections.defaultdict(dict)
