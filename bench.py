@@ -11,8 +11,9 @@ pass of the whole path (K1 hist .. K5 final + results to the host) over the batc
 its own F frames on its own GPU (frames are independent: no collective on the data path; weak scaling) and
 value = N * F * K / max-over-ranks time.
 
-The timed steps go through the plain handle API (ssd_enqueue / ssd_fetch_back) of a handle that keeps
-ssd_config::batches_in_flight = 3 batches in flight on its own streams (the default from 16 frames per batch on): the
+The timed steps go through the plain handle API (ssd_enqueue / ssd_fetch_back) of a handle asked for
+ssd_config::batches_in_flight = 3 (SSD_BATCHES_IN_FLIGHT_THROUGHPUT; opt-in since round 4 — the library's default is one
+workspace in strict stream order): the bench enqueues ahead of its fetches and never touches its frames, so the
 steps overlap, so an event-bracketed stage inside them is no kernel duration.  `stage_ms` and `roofline` therefore come
 from a few EXTRA steps after the timed region, run one at a time with HIP events between the launches
 ("stage_ms_source": "separate timed steps"), next to a plain read stream over the same buffer (`k1_over_plain_stream`).
@@ -27,6 +28,11 @@ spot check, both outside the timed region.
 exits with the child's code.  A world size that differs from --gpus, or fewer visible GPUs than ranks, is an
 error, never a silent 1-GPU run.  BASELINE configs[3] (16384 frames over 8 GPUs): `--gpus 8 --frames 2048`.
 SSD_BENCH_DEVICE=<index> puts every rank on that one device (tests: 2 ranks on a 1-GPU box).
+
+Every rank binds itself to the CPUs of its GPU's NUMA node (ssd_bind_thread_to_device: PCI bus id of the HIP device ->
+/sys/bus/pci/devices/<id>/local_cpulist) as its first GPU-runtime call, before torch initialises the device and before any
+stream, pinned buffer or helper thread of the run exists, and reports the device's PCI bus id / UUID / NUMA node: the line of an
+N-GPU run lists N distinct physical GPUs (`devices`, `distinct_devices`).
 """
 import argparse
 import importlib
@@ -81,6 +87,31 @@ def device_for_rank(local_rank, n_devices, environ=None):
         raise SystemExit("bench.py: rank needs device %d but %d GPU(s) are visible (one GPU per rank; no oversubscription "
                          "unless SSD_BENCH_DEVICE is set)" % (dev, n_devices))
     return dev
+
+
+_AFFINITY_AT_START = None      # the process's CPUs before bind_rank_to_device narrowed them (the all-cores CPU baseline uses them all)
+
+
+def bind_rank_to_device(ssd, device, set_affinity=None):
+    """This process onto the CPUs next to its GPU (the NUMA node the device hangs off), and the device's identity for the report.
+    The library maps HIP device -> PCI bus id -> /sys/bus/pci/devices/<id>/{numa_node,local_cpulist}; the PROCESS affinity is
+    then set to what the calling thread was given, so that threads started later (torch, the HIP runtime's, the oracle pool)
+    stay on that socket.  Where the platform names no local CPUs (numa_node -1, single-socket boxes, containers that hide
+    sysfs) the affinity is left alone and the report says so."""
+    global _AFFINITY_AT_START
+    info = ssd.device_info(device)
+    _AFFINITY_AT_START = os.sched_getaffinity(0)
+    before = len(_AFFINITY_AT_START)
+    bound = ssd.bind_thread_to_device(device)
+    if bound > 0:
+        (set_affinity or os.sched_setaffinity)(0, os.sched_getaffinity(0))      # the thread's new mask for the whole process
+    info.update({"device": device, "cpus_before": before, "cpus_bound": bound, "bound": bound > 0})
+    return info
+
+
+def distinct_devices(reports):
+    """how many different physical GPUs the ranks' reports name (PCI bus id, else UUID, else index)"""
+    return len(set((r.get("pci_bus_id") or r.get("uuid") or str(r.get("device"))) for r in reports))
 
 
 class Ranks:
@@ -170,9 +201,10 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=0, help="bounded CPU-baseline sample in frames (default: ~15 s of CPU work)")
     ap.add_argument("--input", choices=["float3", "depth16"], default="float3",
                     help="float3 = xyz vertices (the metric's input); depth16 = 16-bit depth frames deprojected on the fly (SURVEY 8f rank 1)")
-    ap.add_argument("--batches-in-flight", type=int, default=0,
-                    help="workspaces of the handle (ssd_config::batches_in_flight): 0 = the library's default (3 from 16 frames per batch on); "
-                         "1 = strictly one batch at a time — what the profiling passes use, so that a kernel's traced duration is its own")
+    ap.add_argument("--batches-in-flight", type=int, default=3,
+                    help="workspaces of the handle (ssd_config::batches_in_flight), asked for explicitly: 3 = SSD_BATCHES_IN_FLIGHT_THROUGHPUT "
+                         "(the bench enqueues ahead of its fetches); 1 (or 0, the library's default) = strictly one batch at a time in stream "
+                         "order — what the profiling passes use, so that a kernel's traced duration is its own")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-hostfed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg reported beside `value`")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (profiling passes: its 56 one-frame "
@@ -192,13 +224,17 @@ def main():
     import torch
 
     world, rank, local_rank = world_from_env(args.gpus)
-    if not torch.cuda.is_available():
+    ssd = importlib.import_module("stair-step-detector_amd")
+    n_devices = ssd.device_count()
+    if n_devices < 1:
         raise SystemExit("bench.py: no GPU visible; the HIP path is mandatory (there is no CPU fallback)")
-    device = device_for_rank(local_rank, torch.cuda.device_count())
+    device = device_for_rank(local_rank, n_devices)
+    where = bind_rank_to_device(ssd, device)          # first: the rank onto its GPU's socket, then everything else
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible to torch; the HIP path is mandatory (there is no CPU fallback)")
     torch.cuda.set_device(device)
     ranks = Ranks(world, rank)
 
-    ssd = importlib.import_module("stair-step-detector_amd")
     import scenes
 
     fhd = args.workload == "fhd_stress"
@@ -291,7 +327,7 @@ def main():
     # than one rank every rank also checks a few frames of ITS shard against the CPU oracle (outside the timed region)
     k1_ms = stage["hist"]
     alg_bytes = (2.0 if depth_in else 12.0) * W * H * F    # 12 B per raw point (2 B per depth pixel), read once
-    mine = {"rank": rank, "device": device, "frames": [lo, hi], "seconds": dt, "steps_found": int(sum(r.n_steps for r in res)),
+    mine = {"rank": rank, "device": device, "where": where, "frames": [lo, hi], "seconds": dt, "steps_found": int(sum(r.n_steps for r in res)),
             "stage_ms": stage, "k1_frac_of_hbm_peak": (alg_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k1_ms > 0 else 0.0,
             "one_batch_at_a_time_ms": one_at_a_time_ms}
     if world > 1 and not args.no_cpu:
@@ -362,8 +398,12 @@ def main():
             "pipeline_bytes_moved": pipeline_moved,
             "pipeline_bytes_algorithmic_frac_of_peak": (alg_bytes * args.steps / dt_max / 1e9) / HBM_PEAK_GBS,
         }
+        out["devices"] = [sh["where"] for sh in shards]
+        out["distinct_devices"] = distinct_devices(out["devices"])
         if world > 1:
             out["ranks"] = shards
+            if out["distinct_devices"] != world and not os.environ.get("SSD_BENCH_DEVICE"):
+                raise SystemExit("bench.py: %d ranks on %d distinct GPUs" % (world, out["distinct_devices"]))
         steps_hist = [r.n_steps for r in res]
         out["steps_histogram"] = {str(k): int(sum(1 for n in steps_hist if n == k)) for k in sorted(set(steps_hist))}
 
@@ -396,6 +436,8 @@ def main():
                                                  "oracle/ssd_oracle.cpp (CPU restatement of the reference, one thread as the reference runs), "
                                                  "%.1f s of CPU time" % (n_cpu, F, cdt)}
             # the same port on all host cores, one frame per thread (ctypes drops the GIL)
+            if world == 1 and _AFFINITY_AT_START:
+                os.sched_setaffinity(0, _AFFINITY_AT_START)      # "all host cores": not only the GPU's socket (pool threads inherit this)
             cores = len(os.sched_getaffinity(0))
             if world == 1 and cores > 1 and len(keep) > 1:
                 from concurrent.futures import ThreadPoolExecutor

@@ -47,6 +47,7 @@ extern "C" {
 #define SSD_MAX_SCANS 128
 #define SSD_MAX_EDGE_PTS 256
 #define SSD_LINE_CAP 4096
+#define SSD_BATCHES_IN_FLIGHT_THROUGHPUT 3   /* ssd_config::batches_in_flight of a caller that enqueues ahead of its fetches */
 
 /* error codes */
 #define SSD_OK 0
@@ -72,16 +73,20 @@ typedef struct
   double min_step_depth;                             /* 0.1 */
   int32_t max_frames_per_batch;                      /* a workspace is sized for this many frames per call */
   int32_t max_step_plateaus;                         /* <= SSD_MAX_STEP_IMAGES */
-  /* Workspaces of the handle = batches it keeps in flight (1..8; 0 = automatic: 3 when max_frames_per_batch >= 16, else 1).
-   * 1: every call runs on the caller's stream, strictly in stream order (lowest latency; single frames).
-   * > 1: successive ssd_enqueue calls take the workspaces in turn, each on a stream of the handle's own, so that the
-   *      launches of one batch fill the gaps the one-block-per-frame kernels of the others leave.  XGA, frames/s with 1 / 2 / 3 /
-   *      4 / 6 in flight (profiles/r03_depths.json): 1024 frames per call 272 k / 290 k / 301 k / 294 k / 307 k, 256: 237 k /
-   *      286 k / 306 k / 295 k / 314 k, 64: 188 k / 248 k / 270 k / 251 k / 284 k, 16: 94 k / 165 k / 214 k / 170 k / 228 k
-   *      (3 and 6 sit better than 4 and 5) — provided the caller enqueues ahead of its fetches.  Memory = batches_in_flight x 1.75 MB per XGA frame of max_frames_per_batch (1024 frames, 3 in flight: 5.4 GB
-   *      beside 9.7 GB of frames).  Stream contract then: a batch starts behind the work `stream` holds at the time of the
-   *      call, but work put on `stream` afterwards is NOT ordered behind the batch — its frames must stay untouched until
-   *      its results were fetched, or until a stream was made to wait for it with ssd_stream_wait. */
+  /* Workspaces of the handle = batches it keeps in flight (1..8; 0 = 1).
+   * 1 (the default): every call runs on the caller's stream, strictly in stream order — enqueue, then refill the same frames
+   *      on the same stream (or, on the NULL stream, with a plain hipMemcpy) is ordered, nothing to read further.
+   * > 1 (opt-in; SSD_BATCHES_IN_FLIGHT_THROUGHPUT = 3 is what bench.py and detect-stairs-amd ask for): successive ssd_enqueue
+   *      calls take the workspaces in turn, each on a stream of the handle's own, so that the launches of one batch fill the
+   *      gaps the one-block-per-frame kernels of the others leave.  XGA, frames/s with 1 / 2 / 3 / 4 / 6 in flight
+   *      (profiles/r03_depths.json): 1024 frames per call 272 k / 290 k / 301 k / 294 k / 307 k, 256: 237 k / 286 k / 306 k /
+   *      295 k / 314 k, 64: 188 k / 248 k / 270 k / 251 k / 284 k, 16: 94 k / 165 k / 214 k / 170 k / 228 k (3 and 6 sit better
+   *      than 4 and 5) — provided the caller enqueues ahead of its fetches.  Memory = batches_in_flight x 1.75 MB per XGA frame
+   *      of max_frames_per_batch (1024 frames, 3 in flight: 5.4 GB beside 9.7 GB of frames).  Stream contract then: a batch
+   *      starts behind the work `stream` holds at the time of the call, but work put on `stream` afterwards is NOT ordered
+   *      behind the batch — its frames must stay untouched until its results were fetched, or until a stream was made to wait
+   *      for it with ssd_stream_wait.  ssd_process_host / ssd_process_depth_host gain nothing from it (their slices are
+   *      double-buffered on streams of their own and use the first workspace only). */
   int32_t batches_in_flight;
 } ssd_config;
 
@@ -98,7 +103,8 @@ typedef struct
 /* Stairs::StairStep (stairs.h:32-36), external world coordinates */
 typedef struct
 {
-  double height;
+  double height;    /* mean z of the plateau's points inside its quadrilateral + world_z (pointcloud.cpp:574-581, transformation.cpp:209-211):
+                       summed in 2^-40 m fixed point, order-independent — within 3e-14 m of, not bit-equal to, the reference's running double sum */
   double quad[8];   /* quadrilateral[0..3] as x,y pairs: front-left, front-right, back-left, back-right */
 } ssd_step;
 
@@ -335,6 +341,25 @@ int ssd_device_free(int device, void *d_ptr);
 int ssd_device_upload(int device, void *d_dst, const void *src, size_t bytes);
 int ssd_device_download(int device, void *dst, const void *d_src, size_t bytes);
 int ssd_device_sync(int device);
+
+/* ---- identity and locality of a device (hosts with several GPUs and sockets; SURVEY.md section 8(e): one host thread per GPU) ----
+ * pci_bus_id "dddd:bb:dd.f" and uuid identify the physical GPU (a scaling run proves its N devices distinct with them);
+ * numa_node / cpu_list = the NUMA node the GPU hangs off and that node's CPUs as sysfs names them
+ * (/sys/bus/pci/devices/<id>/numa_node, local_cpulist); -1 / "" where the platform does not say. */
+typedef struct
+{
+  char pci_bus_id[32];
+  char uuid[40];
+  int32_t numa_node;
+  int32_t n_local_cpus;
+  char cpu_list[256];
+} ssd_device_info;
+int ssd_device_info_get(int device, ssd_device_info *out);
+/* Binds the CALLING host thread to the CPUs local to `device` (sched_setaffinity on the thread), so that the thread that feeds
+ * a GPU — and the pinned staging memory it allocates afterwards, placed by first touch — sit on the GPU's socket: what the
+ * host-fed path needs on a two-socket 8-GPU node (frames resident in HBM do not care).  Returns the number of CPUs bound,
+ * 0 when the platform names none (affinity left as it was), or a negative SSD_E_* code. */
+int ssd_bind_thread_to_device(int device);
 
 #ifdef __cplusplus
 }

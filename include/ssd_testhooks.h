@@ -42,6 +42,11 @@ int ssd_test_grid_boxes_device(int device, const double quad[8], double x_min, d
  * sizeof state, offsets of hist, lut, image boxes, plateau table, quadrilateral tests, sums, counts); returns the
  * number of bytes copied or a negative error */
 long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, long long layout[8]);
+/* test hook: rewrites the sums of one surface of frame `frame` in the workspace of the last enqueue as k_inquad would have
+ * left them had the surface's quadrilateral accepted NO point (surface = -1: the ground, else a plateau index: count of the
+ * points outside = all of the plateau's, their sum = the plateau's total).  Between ssd_enqueue_stages(.. up to SSD_STAGE_INQUAD)
+ * and ssd_enqueue_stages(SSD_STAGE_FINAL): the case calcAverageZ divides 0.0 by 0 in (pointcloud.cpp:574-581). */
+int ssd_test_empty_quadrilateral(ssd_handle *h, int frame, int surface);
 /* test hook: the ground bit image of one frame as it lies in the workspace of the last enqueue, as height x width bytes (0 / 0xff).
  * After a full enqueue it is all zero (k_final clears what it read); after ssd_enqueue_stages(.. up to SSD_STAGE_INQUAD) it
  * holds what k_inquad rastered: outside image capture only the pixel strips the bottom scan reads */

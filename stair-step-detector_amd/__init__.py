@@ -35,6 +35,7 @@ STAGE_HIST, STAGE_PEAKS, STAGE_RASTER, STAGE_OUTLINE, STAGE_QUADS, STAGE_INQUAD,
 STAGE_ALL = 127
 STAGE_NAMES = ("hist", "peaks", "raster", "outline", "quads", "inquad", "final")
 E_NODEVICE = -4
+BATCHES_IN_FLIGHT_THROUGHPUT = 3     # SSD_BATCHES_IN_FLIGHT_THROUGHPUT
 
 
 class SsdError(RuntimeError):
@@ -102,6 +103,12 @@ class DebugFrame(C.Structure):
                 ("plateaus", DebugPlateau * MAX_PLATEAUS)]
 
 
+class DeviceInfo(C.Structure):
+    """ssd_device_info: which physical GPU a device index is, and the CPUs next to it"""
+    _fields_ = [("pci_bus_id", C.c_char * 32), ("uuid", C.c_char * 40), ("numa_node", C.c_int32), ("n_local_cpus", C.c_int32),
+                ("cpu_list", C.c_char * 256)]
+
+
 class Intrinsics(C.Structure):
     _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("ppx", C.c_float), ("ppy", C.c_float), ("depth_units", C.c_float)]
 
@@ -130,7 +137,7 @@ EXPORTS = [
     "ssd_fetch_back", "ssd_stream_wait", "ssd_batches_in_flight", "ssd_set_risers", "ssd_fetch_risers", "ssd_set_timing", "ssd_get_stage_times", "ssd_get_stage_times_back", "ssd_serialize",
     "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
     "ssd_device_count", "ssd_device_alloc", "ssd_device_free", "ssd_device_upload", "ssd_device_download",
-    "ssd_device_sync", "ssd_host_alloc", "ssd_host_free",
+    "ssd_device_sync", "ssd_host_alloc", "ssd_host_free", "ssd_device_info_get", "ssd_bind_thread_to_device",
     "ssd_pipeline_create", "ssd_pipeline_destroy", "ssd_pipeline_submit", "ssd_pipeline_submit_after", "ssd_pipeline_next", "ssd_pipeline_pending", "ssd_pipeline_set_timing", "ssd_pipeline_stage_times",
     "ssd_pipeline_last_error",
 ]
@@ -142,7 +149,7 @@ SOURCE_EXPORTS = [
 # libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
 HOOK_EXPORTS = [
     "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_ground_image", "ssd_test_line_host", "ssd_test_intersect_host", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_best_line_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
-    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_testhooks_last_error",
+    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_testhooks_last_error",
 ]
 SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
 HOOKS_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_testhooks.so")
@@ -198,6 +205,8 @@ def lib():
     L.ssd_device_download.argtypes = [i32, vp, vp, sz]
     L.ssd_device_sync.argtypes = [i32]
     L.ssd_host_alloc.argtypes = [sz, C.POINTER(vp)]
+    L.ssd_device_info_get.argtypes = [i32, C.POINTER(DeviceInfo)]
+    L.ssd_bind_thread_to_device.argtypes = [i32]
     L.ssd_host_free.argtypes = [vp]
     L.ssd_pipeline_create.argtypes = [C.POINTER(Config), C.POINTER(Calibration), i32, i32, C.POINTER(vp)]
     L.ssd_pipeline_destroy.argtypes = [vp]
@@ -256,6 +265,7 @@ def hooks_lib():
     L.ssd_test_frame_state.argtypes = [vp, i32, vp, C.c_size_t, vp]
     L.ssd_test_frame_state.restype = C.c_longlong
     L.ssd_test_ground_image.argtypes = [vp, i32, vp]
+    L.ssd_test_empty_quadrilateral.argtypes = [vp, i32, i32]
     L.ssd_test_line_host.argtypes = [vp, vp, vp]
     L.ssd_test_intersect_host.argtypes = [vp, vp, vp]
     L.ssd_test_sort_host.argtypes = [vp, i32, vp]
@@ -275,12 +285,29 @@ def _check(rc, which="hip"):
     return rc
 
 
+def device_info(device):
+    """{'pci_bus_id', 'uuid', 'numa_node', 'n_local_cpus', 'cpu_list'} of a device index (ssd_device_info_get)"""
+    info = DeviceInfo()
+    _check(lib().ssd_device_info_get(device, C.byref(info)))
+    return {"pci_bus_id": info.pci_bus_id.decode(), "uuid": info.uuid.decode(), "numa_node": int(info.numa_node),
+            "n_local_cpus": int(info.n_local_cpus), "cpu_list": info.cpu_list.decode()}
+
+
+def bind_thread_to_device(device):
+    """the calling thread onto the CPUs of the device's NUMA node; returns how many (0 = the platform names none)"""
+    n = lib().ssd_bind_thread_to_device(device)
+    if n < 0:
+        _check(n)
+    return n
+
+
 def device_count():
     return lib().ssd_device_count()
 
 
 def default_config(width, height, max_frames_per_batch=64, max_step_plateaus=MAX_STEP_IMAGES, batches_in_flight=0):
-    """batches_in_flight: workspaces of the handle (ssd_config); 0 = automatic (3 from 16 frames per batch on, else 1)"""
+    """batches_in_flight: workspaces of the handle (ssd_config); 0 = 1 = strict stream order; overlap is opt-in
+    (BATCHES_IN_FLIGHT_THROUGHPUT = 3 for callers that enqueue ahead of their fetches and leave the frames alone meanwhile)"""
     cfg = Config()
     _check(lib().ssd_default_config(C.byref(cfg), width, height))
     cfg.max_frames_per_batch = max_frames_per_batch
@@ -455,6 +482,10 @@ class Detector:
         n = _check(hooks_lib().ssd_test_frame_state(self._h, frame, buf, len(buf), lay), "hooks")
         names = ("size", "hist", "lut", "boxes", "plateaus", "quad_tests", "sum_z", "cnt")
         return buf.raw[:n], dict(zip(names, [int(x) for x in lay]))
+
+    def empty_quadrilateral(self, frame, surface):
+        """test hook: rewrites the sums of a surface (-1 = ground, else plateau index) as if its quadrilateral had accepted no point"""
+        _check(hooks_lib().ssd_test_empty_quadrilateral(self._h, frame, surface), "hooks")
 
     def ground_image_raw(self, frame):
         """test hook: the ground bit image as it lies in the last enqueue's workspace (height x width bytes)"""

@@ -64,6 +64,8 @@ struct ShardReport
   std::string error;
   double seconds = 0.0;       /* the timed region: `passes` passes over the resident frames */
   int frames = 0;
+  int cpusBound = 0;          /* CPUs of the device's NUMA node the shard's thread was bound to */
+  std::string where;          /* PCI bus id, UUID and NUMA node of the device: shards on distinct GPUs show distinct ids */
 };
 
 /* Frames [lo, hi) of the synthetic sequence on one device ("2,048 per GPU, 8 host threads",
@@ -80,9 +82,17 @@ static void runShard(int device, const ssd_calibration &cal, int W, int H, int K
     start.arrive();                                         /* an empty shard (more devices than frames) only keeps the line moving */
     return;
   }
+  /* this thread feeds `device`: onto the CPUs of the GPU's NUMA node before anything is allocated (pinned result slots and
+   * staging buffers are placed by first touch; 0 = the platform names no local CPUs, the affinity stays) */
+  rep.cpusBound = ssd_bind_thread_to_device(device);
+  ssd_device_info info;
+  if(ssd_device_info_get(device, &info) == SSD_OK)
+    rep.where = std::string(info.pci_bus_id) + " uuid " + info.uuid + " numa " + std::to_string(info.numa_node);
   ssd_config cfg;
   ssd_default_config(&cfg, W, H);
   cfg.max_frames_per_batch = hi - lo < kBatch ? hi - lo : kBatch;
+  /* batches are enqueued ahead of their fetches and the frames never change: the overlap across workspaces is ours to ask for */
+  cfg.batches_in_flight = cfg.max_frames_per_batch >= 16 ? SSD_BATCHES_IN_FLIGHT_THROUGHPUT : 1;
   ssd_handle *h = nullptr;
   void *dFrames = nullptr;
   const size_t frameBytes = static_cast<size_t>(W) * H * 12;
@@ -240,7 +250,7 @@ int main(int argc, char **argv)
     }
     for(int d = 0; d < D; d++)
       if(reports[d].frames > 0)
-        std::cerr << "  shard " << d << " on device " << devices[d] << ": " << reports[d].frames << " resident frames x " << passes << " pass(es) in "
+        std::cerr << "  shard " << d << " on device " << devices[d] << " [" << reports[d].where << ", thread on " << reports[d].cpusBound << " local CPUs]: " << reports[d].frames << " resident frames x " << passes << " pass(es) in "
                   << reports[d].seconds << " s = " << static_cast<double>(reports[d].frames) * passes / reports[d].seconds << " frames/s" << std::endl;
     std::cerr << frames << " frames on " << D << " device shard(s), " << passes << " pass(es): "
               << (slowest > 0.0 ? static_cast<double>(frames) * passes / slowest : 0.0)

@@ -17,6 +17,7 @@
 #include <fstream>
 #include <string>
 #include <vector>
+#include <sched.h>
 
 using namespace ssd;
 
@@ -60,17 +61,17 @@ void tuning_from_env(ssd_tuning &t)
 }
 #endif
 
-/* ssd_config::batches_in_flight = 0: handles for batches (>= kOverlapMinFrames frames per call) get kOverlapDepth workspaces.
+/* ssd_config::batches_in_flight = 0 resolves to ONE workspace: every call on the caller's stream, in stream order — the contract
+ * every caller may rely on without reading further (enqueue, then refill the frames on the same stream: ordered).  Overlap is
+ * opt-in (round 4; round 3 resolved 0 to three workspaces for batches, which silently took that order away): a caller that
+ * enqueues ahead of its fetches asks for kOverlapDepth and keeps its frames untouched until their results were fetched.
  * XGA, frames/s with 1 / 2 / 3 / 4 / 5 / 6 / 8 batches in flight (tools/depths.py, profiles/r03_depths.json: three and six sit
  * better than four and five; six buys 2-5 % over three for twice the memory):
  *   1024 frames per call 272 k / 290 k / 301 k / 294 k / 298 k / 307 k / 310 k      256: 237 k / 286 k / 306 k / 295 k / 303 k / 314 k / 306 k
  *     64: 188 k / 248 k / 270 k / 251 k / 268 k / 284 k / 270 k                      32: 140 k / 225 k / 253 k / 215 k / 244 k / 256 k / 246 k
  *     16:  94 k / 165 k / 214 k / 170 k / 203 k / 228 k / 206 k                       8:  59 k / 107 k / 140 k / 114 k / 130 k / 144 k / 135 k
- * The fewer frames a call has, the more of it is the latency of its seven dependent launches, and the more other batches in
- * flight fill: from 16 frames per call on a handle is taken to be fed for throughput; below, every call runs on the caller's
- * stream in strict order (the single-frame case: nothing between the call and the first launch). */
-constexpr int kOverlapMinFrames = 16;
-constexpr int kOverlapDepth = 3;
+ * bench.py and detect-stairs-amd ask for SSD_BATCHES_IN_FLIGHT_THROUGHPUT (ssd_hip.h) explicitly. */
+constexpr int kOverlapDepth = SSD_BATCHES_IN_FLIGHT_THROUGHPUT;
 
 } // namespace
 
@@ -182,24 +183,24 @@ extern "C++"
 namespace
 {
 
-/* readValue, calibrationTriangle.cpp:48-68: skip tokens until `name`, expect "=", read the value */
+/* What the reference's readValue (calibrationTriangle.cpp:48-68) accepts, stated on the token stream: the file from the
+ * current position on is a sequence of whitespace-separated tokens; the first occurrence of the token `name` that is directly
+ * followed by the token "=" selects the value, which is then extracted from the SAME stream with operator>> for T (so
+ * "x1 = 0.5," yields 0.5 and leaves the comma, a string value takes the next token).  An occurrence of `name` not followed by
+ * "=" consumes both tokens and the search goes on behind them.  False when the stream ends first or the extraction fails. */
 template<typename T>
 bool read_named_value(std::ifstream &file, const std::string &name, T &value)
 {
-  while(file)
+  for(std::string token; file >> token; )
   {
-    std::string chars;
-    file >> chars;
-    if(chars == name)
-    {
-      std::string sign;
-      file >> sign;
-      if(sign == "=")
-      {
-        file >> value;
-        return static_cast<bool>(file);
-      }
-    }
+    if(token != name)
+      continue;
+    std::string next;
+    if(!(file >> next))
+      break;
+    if(next != "=")
+      continue;
+    return static_cast<bool>(file >> value);
   }
   return false;
 }
@@ -384,7 +385,8 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   if(depth < 0 || depth > kMaxLanes)
     return fail(SSD_E_ARG, "ssd_create: batches_in_flight must be 0 (automatic) .. " + std::to_string(kMaxLanes));
   if(depth == 0)
-    depth = cfg->max_frames_per_batch >= kOverlapMinFrames ? kOverlapDepth : 1;
+    depth = 1;                                  /* strict stream order unless the caller asks for overlap (see above) */
+  static_assert(kOverlapDepth >= 2 && kOverlapDepth <= kMaxLanes, "SSD_BATCHES_IN_FLIGHT_THROUGHPUT out of range");
   Params P{};
   const int rc = make_params(*cfg, *cal, P);
   if(rc)
@@ -471,9 +473,6 @@ int ssd_destroy(ssd_handle *h)
     if(L.done) (void)hipEventDestroy(L.done);
     if(L.stream) (void)hipStreamDestroy(L.stream);
   }
-  for(ssd_handle::SmallGraph &g : h->graphs)
-    if(g.exec) (void)hipGraphExecDestroy(g.exec);
-  if(h->captureStream) (void)hipStreamDestroy(h->captureStream);
   if(h->dDepthMaps) (void)hipFree(h->dDepthMaps);
   if(h->dResults) (void)hipFree(h->dResults);
   if(h->hResults) (void)hipHostFree(h->hResults);
@@ -508,22 +507,31 @@ int ssd_set_debug(ssd_handle *h, int enable)
   if(!h)
     return fail(SSD_E_ARG, "ssd_set_debug: null handle");
   HIP_TRY(hipSetDevice(h->device));
-  if(enable && (!h->dDebug || !h->dDebugImg))
+  const bool wantImages = enable != 0 && enable != 2;
+  if(enable && (!h->dDebug || (wantImages && !h->dDebugImg)))
   {
-    /* both buffers or neither: a failed second allocation must not leave the first behind as "debug is set up" */
+    /* the records always; the image buffer (F x (images + 1) x 2 whole images) only for capture WITH images — and then both
+     * or neither: a failed second allocation must not leave the first behind as "debug is set up" */
     const size_t imgBytes = static_cast<size_t>(h->F) * (h->P.maxStepImages + 1) * 2 * h->imgWords * 8;
-    DebugFrame *d = nullptr;
-    unsigned long long *di = nullptr;
-    HIP_TRY(hipMalloc(&d, sizeof(DebugFrame) * h->F));
-    const hipError_t e = hipMalloc(&di, imgBytes);
-    if(e != hipSuccess)
+    DebugFrame *d = h->dDebug;
+    unsigned long long *di = h->dDebugImg;
+    if(!d)
+      HIP_TRY(hipMalloc(&d, sizeof(DebugFrame) * h->F));
+    if(wantImages && !di)
     {
-      (void)hipFree(d);
-      return fail(e == hipErrorOutOfMemory ? SSD_E_NOMEM : SSD_E_HIP, std::string("ssd_set_debug: ") + hipGetErrorString(e));
+      const hipError_t e = hipMalloc(&di, imgBytes);
+      if(e != hipSuccess)
+      {
+        if(!h->dDebug)
+          (void)hipFree(d);
+        return fail(e == hipErrorOutOfMemory ? SSD_E_NOMEM : SSD_E_HIP, std::string("ssd_set_debug: ") + hipGetErrorString(e));
+      }
+      h->bytes += imgBytes;
     }
+    if(!h->dDebug)
+      h->bytes += sizeof(DebugFrame) * h->F;
     h->dDebug = d;
     h->dDebugImg = di;
-    h->bytes += sizeof(DebugFrame) * h->F + imgBytes;
   }
   h->debug = enable == 0 ? 0 : enable == 2 ? 2 : 1;
   return SSD_OK;
@@ -647,19 +655,6 @@ static int choose_chunk(const ssd_tuning &tune, int nPoints, int nframes)
 }
 
 static constexpr int kDirectResultFrames = 64;
-#ifdef SSD_SMALL_GRAPH
-static constexpr int kGraphFrames = 8;       /* calls of up to this many frames are replayed from a captured graph */
-#endif
-
-static void drop_graphs(ssd_handle *h)
-{
-  for(ssd_handle::SmallGraph &g : h->graphs)
-  {
-    if(g.exec) (void)hipGraphExecDestroy(g.exec);
-    g = ssd_handle::SmallGraph{};
-  }
-}
-
 static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_bytes, int nframes, void *stream, int stages, bool depthInput)
 {
   if(!h || !d_xyz)
@@ -797,72 +792,21 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
     mk();
   };
 
-  /* A call of a few frames is a chain of seven dependent launches of a few microseconds each.  Replaying it from a HIP graph
-   * captured the first time this (frames pointer, stride, count, input kind, result slot) was seen — ONE submission — was
-   * measured and is NOT in the product: ROCm 7.2's hipGraphLaunch takes longer than the seven launches it replaces (one
-   * resident XGA frame: 100 -> 200 us per ssd_enqueue + ssd_fetch, eight frames 134 -> 158 us; same box, alternating runs,
-   * tools/latency.py).  The code stays for the next runtime: make EXTRA=-DSSD_SMALL_GRAPH. */
-  bool viaGraph = false;
-#ifdef SSD_SMALL_GRAPH
-  if(h->depth == 1 && nframes <= kGraphFrames && stages == SSD_STAGE_ALL && !h->debug && !timing && !P.risers && !h->graphsOff &&
-     !L.imagesDirty && L.dirtyFrames == 0)
+  /* (A call of a few frames replayed from a captured HIP graph — one submission instead of seven launches — was measured in
+   * round 3 and is slower on ROCm 7.2: one resident XGA frame 100 -> 200 us per ssd_enqueue + ssd_fetch, eight frames 134 ->
+   * 158 us.  The code left the product in round 4; git history of this file has it.) */
   {
-    ssd_handle::SmallGraph *g = nullptr, *lru = &h->graphs[0];
-    for(ssd_handle::SmallGraph &c : h->graphs)
-    {
-      if(c.exec && c.xyz == d_xyz && c.stride == frame_stride_bytes && c.nframes == nframes && c.slot == slot && c.depthInput == depthInput)
-        g = &c;
-      if(c.lastUse < lru->lastUse)
-        lru = &c;
-    }
-    if(!g)
-    {
-      bool ok = true;
-      if(!h->captureStream)
-        ok = hipStreamCreateWithFlags(&h->captureStream, hipStreamNonBlocking) == hipSuccess;
-      hipGraph_t graph = nullptr;
-      hipGraphExec_t exec = nullptr;
-      if(ok && hipStreamBeginCapture(h->captureStream, hipStreamCaptureModeThreadLocal) == hipSuccess)
-      {
-        chain(h->captureStream, false);
-        ok = hipStreamEndCapture(h->captureStream, &graph) == hipSuccess && graph != nullptr;
-        ok = ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
-        if(graph) (void)hipGraphDestroy(graph);
-      }
-      else
-        ok = false;
-      (void)hipGetLastError();
-      if(ok)
-      {
-        if(lru->exec) (void)hipGraphExecDestroy(lru->exec);
-        *lru = ssd_handle::SmallGraph{};
-        lru->exec = exec; lru->xyz = d_xyz; lru->stride = frame_stride_bytes; lru->nframes = nframes; lru->slot = slot; lru->depthInput = depthInput;
-        g = lru;
-      }
-      else
-        h->graphsOff = true;                    /* this runtime does not capture the chain: plain launches from now on */
-    }
-    if(g)
-    {
-      g->lastUse = h->enqueueCount + 1;
-      if(hipGraphLaunch(g->exec, s) == hipSuccess)
-        viaGraph = true;
-      else
-      {
-        (void)hipGetLastError();
-        h->graphsOff = true;
-      }
-    }
-  }
-#endif
-
-  if(!viaGraph)
-  {
-    if(L.imagesDirty)
+    /* bits a partial run (ssd_enqueue_stages) left behind: wiped before the stage that would raster on top of them — not
+     * before a call that only CONSUMES them (the continuation of that partial run: k_outline / k_final read and clear) */
+    if(L.stepImagesDirty && (stages & SSD_STAGE_RASTER))
     {
       HIP_TRY(hipMemsetAsync(L.dStepImg, 0, static_cast<size_t>(h->F) * P.maxStepImages * h->imgWords * 8, s));
+      L.stepImagesDirty = false;
+    }
+    if(L.groundImageDirty && (stages & SSD_STAGE_INQUAD))
+    {
       HIP_TRY(hipMemsetAsync(L.dGroundImg, 0, static_cast<size_t>(h->F) * h->imgWords * 8, s));
-      L.imagesDirty = false;
+      L.groundImageDirty = false;
     }
     if(stages & SSD_STAGE_HIST)
     {
@@ -894,9 +838,11 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
     L.dirtyFrames = 0;
   L.lastStream = s;
   L.haveLast = true;
-  /* a raster without its consumer leaves bits behind */
-  if(((stages & SSD_STAGE_RASTER) && !(stages & SSD_STAGE_OUTLINE)) || ((stages & SSD_STAGE_INQUAD) && !(stages & SSD_STAGE_FINAL)))
-    L.imagesDirty = true;
+  /* a raster without its consumer leaves bits behind; the consumer clears what it read */
+  if(stages & SSD_STAGE_RASTER) L.stepImagesDirty = true;
+  if(stages & SSD_STAGE_OUTLINE) L.stepImagesDirty = false;
+  if(stages & SSD_STAGE_INQUAD) L.groundImageDirty = true;
+  if(stages & SSD_STAGE_FINAL) L.groundImageDirty = false;
   h->lastFrames = nframes;
   h->lastLane = li;
   h->hRisersBatchFrames = 0;
@@ -938,10 +884,14 @@ int ssd_set_intrinsics(ssd_handle *h, const ssd_intrinsics *intr)
   depth_maps(*intr, h->P.W, h->P.H, maps);
   if(!h->dDepthMaps)
     HIP_TRY(hipMalloc(&h->dDepthMaps, maps.size() * 4));
+  /* depth batches still running (on the lanes' non-blocking streams, which a null-stream copy does not wait for) read the maps
+   * in K1, K2 and K4: let every lane finish before they change */
+  for(int k = 0; k < h->depth; k++)
+    if(h->lane[k].haveLast)
+      HIP_TRY(hipEventSynchronize(h->lane[k].done));
   HIP_TRY(hipMemcpy(h->dDepthMaps, maps.data(), maps.size() * 4, hipMemcpyHostToDevice));
   h->intr = *intr;
   h->haveIntr = true;
-  drop_graphs(h);                               /* captured chains hold the old depth scale */
   return SSD_OK;
 }
 
@@ -1096,12 +1046,19 @@ static int process_host_impl(ssd_handle *h, const void *src, size_t srcFrameByte
     HIP_TRY(hipStreamWaitEvent(h->ingestCompute, h->ingestCopied[k], 0));
     rc = enqueue_impl(h, h->ingestBuf[k], devFrameBytes, n, h->ingestCompute, SSD_STAGE_ALL, depthInput);
     if(rc) return rc;
-    /* with several workspaces the slice runs on its lane's stream: "consumed" is its end, not this stream's position */
-    rc = ssd_stream_wait(h, 0, h->ingestCompute);
-    if(rc) return rc;
+    /* "Consumed" is the end of the slice's kernels — on the stream they ran on (with several workspaces the lane's own; the
+     * compute stream itself only orders a slice behind its copy, so the slices of a handle with several workspaces overlap
+     * like any other batches: making the compute stream wait for every slice — round 3 — had serialised them). */
     if(risers)
+    {
+      /* the riser buffer is single (enqueues with risers on all run in the first workspace): its copy follows the slice */
+      rc = ssd_stream_wait(h, 0, h->ingestCompute);
+      if(rc) return rc;
       HIP_TRY(hipMemcpyAsync(h->hRisersBatch + done, h->dRisers, sizeof(ssd_frame_risers) * n, hipMemcpyDeviceToHost, h->ingestCompute));
-    HIP_TRY(hipEventRecord(h->ingestConsumed[k], h->ingestCompute));
+      HIP_TRY(hipEventRecord(h->ingestConsumed[k], h->ingestCompute));
+    }
+    else
+      HIP_TRY(hipEventRecord(h->ingestConsumed[k], h->lane[h->lastLane].lastStream));
     if(prevFrames)
     {
       rc = ssd_fetch_back(h, results + prevAt, prevFrames, 1);
@@ -1278,6 +1235,123 @@ int ssd_device_sync(int device)
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipDeviceSynchronize());
   return SSD_OK;
+}
+
+extern "C++"
+{
+namespace
+{
+/* first line of a sysfs attribute, without the newline; empty when it cannot be read */
+std::string sysfs_line(const std::string &path)
+{
+  std::ifstream f(path);
+  std::string s;
+  if(f)
+    std::getline(f, s);
+  return s;
+}
+/* "0-15,128-143" -> CPU numbers; anything malformed ends the list there */
+std::vector<int> parse_cpu_list(const std::string &list)
+{
+  std::vector<int> cpus;
+  const char *p = list.c_str();
+  while(*p)
+  {
+    char *end = nullptr;
+    const long a = std::strtol(p, &end, 10);
+    if(end == p || a < 0)
+      break;
+    long b = a;
+    p = end;
+    if(*p == '-')
+    {
+      b = std::strtol(p + 1, &end, 10);
+      if(end == p + 1 || b < a)
+        break;
+      p = end;
+    }
+    for(long c = a; c <= b && cpus.size() < 4096; c++)
+      cpus.push_back(static_cast<int>(c));
+    if(*p == ',')
+      p++;
+    else
+      break;
+  }
+  return cpus;
+}
+} // namespace
+} // extern "C++"
+
+int ssd_device_info_get(int device, ssd_device_info *out)
+{
+  if(!out)
+    return fail(SSD_E_ARG, "ssd_device_info_get: null");
+  const int n = ssd_device_count();
+  if(n <= 0)
+    return fail(SSD_E_NODEVICE, "ssd_device_info_get: no HIP device");
+  if(device < 0 || device >= n)
+    return fail(SSD_E_ARG, "ssd_device_info_get: device index out of range");
+  std::memset(out, 0, sizeof(*out));
+  out->numa_node = -1;
+  HIP_TRY(hipDeviceGetPCIBusId(out->pci_bus_id, static_cast<int>(sizeof(out->pci_bus_id)), device));
+  for(char *c = out->pci_bus_id; *c; c++)
+    if(*c >= 'A' && *c <= 'F')
+      *c = static_cast<char>(*c - 'A' + 'a');                 /* sysfs spells bus ids in lower case */
+  hipUUID uuid;
+  hipDevice_t dev;
+  if(hipDeviceGet(&dev, device) == hipSuccess && hipDeviceGetUuid(&uuid, dev) == hipSuccess)
+  {
+    static const char hex[] = "0123456789abcdef";
+    for(int i = 0; i < 16; i++)
+    {
+      const unsigned char b = static_cast<unsigned char>(uuid.bytes[i]);
+      out->uuid[2 * i] = hex[b >> 4];
+      out->uuid[2 * i + 1] = hex[b & 15];
+    }
+  }
+  else
+    (void)hipGetLastError();
+  const std::string dir = std::string("/sys/bus/pci/devices/") + out->pci_bus_id + "/";
+  const std::string node = sysfs_line(dir + "numa_node");
+  if(!node.empty())
+    out->numa_node = std::atoi(node.c_str());
+  const std::string cpus = sysfs_line(dir + "local_cpulist");
+  std::snprintf(out->cpu_list, sizeof(out->cpu_list), "%s", cpus.c_str());
+  out->n_local_cpus = static_cast<int32_t>(parse_cpu_list(cpus).size());
+  return SSD_OK;
+}
+
+int ssd_bind_thread_to_device(int device)
+{
+  ssd_device_info info;
+  const int rc = ssd_device_info_get(device, &info);
+  if(rc != SSD_OK)
+    return rc;
+  const std::vector<int> cpus = parse_cpu_list(info.cpu_list);
+  if(cpus.empty())
+    return 0;
+  cpu_set_t *set = CPU_ALLOC(4096);
+  if(!set)
+    return fail(SSD_E_NOMEM, "ssd_bind_thread_to_device: CPU_ALLOC");
+  const size_t bytes = CPU_ALLOC_SIZE(4096);
+  /* only CPUs this thread may run on (a container's cpuset can be narrower than the node): an empty intersection changes nothing */
+  cpu_set_t *allowed = CPU_ALLOC(4096);
+  int bound = 0;
+  if(allowed && sched_getaffinity(0, bytes, allowed) == 0)
+  {
+    CPU_ZERO_S(bytes, set);
+    for(int c : cpus)
+      if(c < 4096 && CPU_ISSET_S(c, bytes, allowed))
+      {
+        CPU_SET_S(c, bytes, set);
+        bound++;
+      }
+    if(bound > 0 && sched_setaffinity(0, bytes, set) != 0)
+      bound = 0;
+  }
+  if(allowed) CPU_FREE(allowed);
+  CPU_FREE(set);
+  return bound;
 }
 
 } // extern "C"

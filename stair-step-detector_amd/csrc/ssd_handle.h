@@ -37,7 +37,7 @@ struct ssd_lane
   hipEvent_t done = nullptr;                /* recorded behind the lane's last enqueue */
   hipStream_t lastStream = nullptr;         /* depth 1: the stream of the previous call (a switch is ordered by `done`) */
   bool haveLast = false;
-  bool imagesDirty = false;
+  bool stepImagesDirty = false, groundImageDirty = false;   /* a partial run rastered without the stage that consumes (and clears) the bits */
   int dirtyFrames = 0;                      /* leading FrameStates whose K1 accumulators may be non-zero (k_peaks clears them) */
 };
 
@@ -80,20 +80,6 @@ struct ssd_handle
   /* risers of a host-fed batch, slice by slice (the device buffer holds one enqueue's) */
   ssd_frame_risers *hRisersBatch = nullptr; /* pinned */
   int hRisersBatchCap = 0, hRisersBatchFrames = 0;
-  /* Calls of a few frames (single-frame latency): the chain of launches captured once as a HIP graph per (frames pointer,
-   * stride, frame count, input kind, result slot) and replayed — one submission instead of seven (ssd_capi.hip, small_graph) */
-  struct SmallGraph
-  {
-    hipGraphExec_t exec = nullptr;
-    const void *xyz = nullptr;
-    size_t stride = 0;
-    int nframes = 0, slot = 0;
-    bool depthInput = false, risers = false;
-    unsigned long long lastUse = 0;
-  };
-  SmallGraph graphs[4];
-  hipStream_t captureStream = nullptr;
-  bool graphsOff = false;                   /* capture failed once: plain launches from then on */
   ssd::DebugFrame *dDebug = nullptr;
   unsigned long long *dDebugImg = nullptr;
   int debug = 0;                  /* 0 off, 1 records + images (the whole ground image is rastered for it), 2 records only */

@@ -271,38 +271,42 @@ __device__ __forceinline__ unsigned int row_or_u32(unsigned int v)
 /* K1 also leaves, per cell, the bounding box of its in-range points in world x / y on a 256 x 256 grid over the measuring
  * range (one byte per bound: x0, x1, y0, y1; a cell with no in-range point has an empty mask and a meaningless box).
  * k_inquad decides from it, without loading the cell, that all its points lie outside the ground quadrilateral, or all
- * inside a tread's (its thresholds on this grid carry a margin far above any rounding: InquadLds::liveBox). */
-__device__ __forceinline__ unsigned int cell_box_pack(unsigned int mn, unsigned int mx)
+ * inside a tread's (its thresholds on this grid carry a margin far above any rounding: InquadLds::liveBox).
+ *
+ * Round 4: the extremes are tracked per point on the HIGH dwords of d = w - min (doubles, d > 0 for a point in range): for
+ * positive doubles the high dword (exponent + 20 mantissa bits) orders like an unsigned integer, so a point costs two
+ * subtractions and four 32-bit min / max (round 3: two subtractions, two multiplications, two conversions, a pack and two
+ * packed min / max), and the reduction over the 16 lanes of a DPP row is one v_min_u32_dpp / v_max_u32_dpp per step and
+ * value.  Only the cell's four results are turned into grid cells (lanes 0, 16, 32, 48): the minimum with the low dword 0
+ * (rounded down), the maximum with the high dword + 1 (rounded up) - the box can only grow by that, never lose a point:
+ * "a cell's box [x0, x1] x [y0, y1] holds points with xMin + x0 / boxX <= x < xMin + (x1 + 1) / boxX" (live_box_thresholds)
+ * stays true. */
+__device__ __forceinline__ unsigned int row_min_u32(unsigned int v)
 {
-  const unsigned int x0 = min(mn & 0xffffu, 255u), y0 = min(mn >> 16, 255u), x1 = min(mx & 0xffffu, 255u), y1 = min(mx >> 16, 255u);
-  return x0 | (x1 << 8) | (y0 << 16) | (y1 << 24);
-}
-/* component-wise min / max of two u16 pairs packed in 32 bits (v_pk_min_u16 / v_pk_max_u16) */
-typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned int pk_min_u16(unsigned int a, unsigned int b)
-{
-  return __builtin_bit_cast(unsigned int, __builtin_elementwise_min(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
-}
-__device__ __forceinline__ unsigned int pk_max_u16(unsigned int a, unsigned int b)
-{
-  return __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
-}
-/* the same over the 16 lanes of a DPP row */
-__device__ __forceinline__ unsigned int row_pk_min_u16(unsigned int v)
-{
-  v = pk_min_u16(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x128, 0xf, 0xf, false)));
-  v = pk_min_u16(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x124, 0xf, 0xf, false)));
-  v = pk_min_u16(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x122, 0xf, 0xf, false)));
-  v = pk_min_u16(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x121, 0xf, 0xf, false)));
+  v = min(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x128, 0xf, 0xf, false)));
+  v = min(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x124, 0xf, 0xf, false)));
+  v = min(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x122, 0xf, 0xf, false)));
+  v = min(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x121, 0xf, 0xf, false)));
   return v;
 }
-__device__ __forceinline__ unsigned int row_pk_max_u16(unsigned int v)
+__device__ __forceinline__ unsigned int row_max_u32(unsigned int v)
 {
-  v = pk_max_u16(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x128, 0xf, 0xf, false)));
-  v = pk_max_u16(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x124, 0xf, 0xf, false)));
-  v = pk_max_u16(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x122, 0xf, 0xf, false)));
-  v = pk_max_u16(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x121, 0xf, 0xf, false)));
+  v = max(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x128, 0xf, 0xf, false)));
+  v = max(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x124, 0xf, 0xf, false)));
+  v = max(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x122, 0xf, 0xf, false)));
+  v = max(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x121, 0xf, 0xf, false)));
   return v;
+}
+/* the grid cell of a distance given by its high dword: lowest possible (low dword 0) / highest possible (next high dword) */
+__device__ __forceinline__ unsigned int box_cell_low(unsigned int hi, double scale)
+{
+  const double d = __hiloint2double(static_cast<int>(hi), 0);
+  return min(static_cast<unsigned int>(d * scale), 255u);
+}
+__device__ __forceinline__ unsigned int box_cell_high(unsigned int hi, double scale)
+{
+  const double d = __hiloint2double(static_cast<int>(hi + 1u), 0);
+  return min(static_cast<unsigned int>(d * scale), 255u);
 }
 
 /* The list of the cells of a block's chunk whose mask meets `wanted`, in LDS, COLUMN-major: the cells of one
@@ -310,7 +314,7 @@ __device__ __forceinline__ unsigned int row_pk_max_u16(unsigned int v)
  * the list stays on one patch of the top-down image that creeps down row by row — what its LDS write-combining
  * window needs — and jumps only at a column change.  Entries are cell indices relative to the chunk's first cell.
  * wantCell(record) decides from the cell's record (x = mask of the groups of 4 height bins that occur, y = bounding box,
- * see cell_box_pack) whether the cell is walked.
+ * x0 | x1 << 8 | y0 << 16 | y1 << 24 on the 256 x 256 grid) whether the cell is walked.
  * All threads of the block call it; returns the number of entries (block-uniform).  scratch: 2 * kWavesPerBlock words. */
 template<typename Want>
 __device__ __forceinline__ int cell_list_build(const uint2 *__restrict__ cellInfo, int nCells, int cols, Want wantCell,
@@ -443,41 +447,41 @@ __device__ __forceinline__ void hist_block(HistLds &L, const float *__restrict__
   __syncthreads();
 
   unsigned int *mine = lh + (lane & (kHistCopies - 1));
-  unsigned int nz = 0;
+  unsigned int nz = 0;                                               /* wave-uniform: the count of the whole wave (scalar popcounts) */
   int it = 0;
   auto tileBody = [&](const F3 (&v)[kPts])
   {
     unsigned int groups = 0u;
-    unsigned int boxMin = 0xffffffffu, boxMax = 0u;                     /* (x, y) of the in-range points on a 256 x 256 grid, packed u16 pairs */
+    /* extremes of (x - xMin, y - yMin) over the lane's in-range points, as the high dwords of the doubles (see row_min_u32) */
+    unsigned int x0 = 0xffffffffu, x1 = 0u, y0 = 0xffffffffu, y1 = 0u;
 #pragma unroll
     for(int j = 0; j < kPts; j++)
     {
       double wx, wy, wz;
-      nz += v[j].z > 0.0f ? 1u : 0u;
+      nz += static_cast<unsigned int>(__popcll(__ballot(v[j].z > 0.0f)));    /* pointcloud.cpp:143-146, counted per wave on the scalar unit */
       if(world_point_flat(P, v[j], wx, wy, wz))
       {
         const unsigned int b = static_cast<unsigned int>(height_bin(P, wz));     /* in [0, nBins) for a point in range */
         atomicAdd(mine + b * kHistCopies, 1u);                          /* ++hist[bin], pointcloud.cpp:199-202 */
         groups |= 1u << (b / static_cast<unsigned int>(kBinsPerGroup));
-        const unsigned int qx = static_cast<unsigned int>((wx - P.xMin) * P.boxX), qy = static_cast<unsigned int>((wy - P.yMin) * P.boxY);
-        const unsigned int q = qx | (qy << 16);
-        boxMin = pk_min_u16(boxMin, q);
-        boxMax = pk_max_u16(boxMax, q);
+        const unsigned int hx = static_cast<unsigned int>(__double2hiint(wx - P.xMin)), hy = static_cast<unsigned int>(__double2hiint(wy - P.yMin));
+        x0 = min(x0, hx); x1 = max(x1, hx);
+        y0 = min(y0, hy); y1 = max(y1, hy);
       }
     }
     groups = row_or_u32(groups);
-    boxMin = row_pk_min_u16(boxMin);
-    boxMax = row_pk_max_u16(boxMax);
+    x0 = row_min_u32(x0); x1 = row_max_u32(x1);
+    y0 = row_min_u32(y0); y1 = row_max_u32(y1);
     if((lane & 15) == 0)                                         /* cell = 64 consecutive points = lanes 16q .. 16q+15 */
-      lInfo[it * kCellsPerTile + (tid >> 4)] = make_uint2(groups, cell_box_pack(boxMin, boxMax));
+    {
+      const unsigned int box = groups == 0u ? 0u
+        : box_cell_low(x0, P.boxX) | (box_cell_high(x1, P.boxX) << 8) | (box_cell_low(y0, P.boxY) << 16) | (box_cell_high(y1, P.boxY) << 24);
+      lInfo[it * kCellsPerTile + (tid >> 4)] = make_uint2(groups, box);
+    }
     it++;
   };
   SSD_STREAM_LOOP(tileBody)
 
-  /* wave-reduce the non-zero count */
-#pragma unroll
-  for(int o = 32; o > 0; o >>= 1)
-    nz += __shfl_down(nz, o);
   if(lane == 0 && nz)
     atomicAdd(&lNonZero, nz);
   __syncthreads();
@@ -1930,11 +1934,22 @@ constexpr int kGroundScanStep = 50;
 __device__ __forceinline__ int ground_scan_x0(int W) { return (W / 2) % kGroundScanStep; }
 __device__ __forceinline__ int ground_strip_row0(int H) { return H / 2 - 1; }
 /* is pixel column ix within two of a scan column x_j = x0 + 50 j, j any integer (also j = -1 and beyond the last scanned
- * column: k_final clears those strips with the others)?  u / 50 by multiply-high: exact for u < 2^17 */
+ * column: k_final clears those strips with the others)?  u / 50 by multiply-high with a constant that IS exact over the whole
+ * range a pixel column can take (ix < 8192: u < 8300; proven at compile time below — round 3's 1311 >> 16 was off by one from
+ * u = 4699 on and only the predicate happened to survive it). */
+constexpr unsigned int strip_div50(unsigned int u) { return (u * 5243u) >> 18; }
+constexpr bool strip_div50_exact()
+{
+  for(unsigned int u = 0; u < 16384u; u++)
+    if(strip_div50(u) != u / 50u)
+      return false;
+  return true;
+}
+static_assert(strip_div50_exact(), "strip_div50 must equal u / 50 for every pixel column of an image up to 8192 wide");
 __device__ __forceinline__ bool ground_strip_column(int ix, int x0)
 {
   const unsigned int u = static_cast<unsigned int>(ix + 2 - x0 + kGroundScanStep);       /* >= 3 */
-  const unsigned int r = u - kGroundScanStep * ((u * 1311u) >> 16);
+  const unsigned int r = u - kGroundScanStep * strip_div50(u);
   return r <= 4u;
 }
 
@@ -2268,6 +2283,16 @@ __global__ __launch_bounds__(kThreads, SSD_K4_WAVES) void k_inquad(const float *
 /* ========================================================================= */
 /* K5: ground front edge and the per-frame result — one workgroup per frame     */
 
+/* calcAverageZ (pointcloud.cpp:574-581): sum / points.size().  A quadrilateral that accepted no point makes that 0.0 / 0.0,
+ * which on the reference's x86 is the DEFAULT NaN with the sign bit SET (0xfff8...): the line then reads "-nan"
+ * (stairs.cpp:43 through operator<<).  This GPU's 0.0 / 0.0 is the positive quiet NaN — so the empty case is stated, not divided. */
+__device__ __forceinline__ double mean_of_fixed(long long sumFixed, unsigned int n)
+{
+  if(n == 0u)
+    return __longlong_as_double(static_cast<long long>(0xfff8000000000000ull));
+  return (static_cast<double>(sumFixed) / static_cast<double>(1ll << kZFixShift)) / n;
+}
+
 struct FinalShared
 {
   int yEdge[kMaxCols];
@@ -2459,7 +2484,7 @@ __global__ __launch_bounds__(T) void k_final(Params P, FrameState *__restrict__ 
       /* "return {}" when no front edge is found (quirk Q6): the ground stays all zero */
       const bool valid = S.n >= 2;
       fs.groundFrontValid = valid ? 1 : 0;
-      const double meanZ = (static_cast<double>(fs.sumZ[kGroundAcc]) / static_cast<double>(1ll << kZFixShift)) / fs.cnt[kGroundAcc];
+      const double meanZ = mean_of_fixed(fs.sumZ[kGroundAcc], fs.cnt[kGroundAcc]);
       double fimg[4] = { 0, 0, 0, 0 };
       if(valid)
       {
@@ -2508,7 +2533,7 @@ __global__ __launch_bounds__(T) void k_final(Params P, FrameState *__restrict__ 
        * count) minus the ones outside (k_inquad's sum and count) */
       const long long inZ = fs.totZ[k - firstStep] - fs.sumZ[k];
       const unsigned int inN = static_cast<unsigned int>(fs.pl[k].nPoints) - fs.cnt[k];
-      const double meanZ = (static_cast<double>(inZ) / static_cast<double>(1ll << kZFixShift)) / inN;
+      const double meanZ = mean_of_fixed(inZ, inN);
       sW[0] = meanZ;
 #pragma unroll
       for(int c = 0; c < 8; c++)
@@ -2526,7 +2551,8 @@ __global__ __launch_bounds__(T) void k_final(Params P, FrameState *__restrict__ 
     const int n = min(__popcll(emitted), SSD_MAX_STEPS);
     if((groundLane || stepLane) && place < SSD_MAX_STEPS)
     {
-      res.steps[place].height = P.worldZ + sW[0];
+      /* transformation.cpp:209-211; a NaN mean keeps its sign through the sum on x86 (the operand NaN is propagated) */
+      res.steps[place].height = sW[0] != sW[0] ? sW[0] : P.worldZ + sW[0];
 #pragma unroll
       for(int c = 0; c < 4; c++)
       {

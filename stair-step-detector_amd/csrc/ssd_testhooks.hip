@@ -179,6 +179,34 @@ long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, 
   return static_cast<long long>(n);
 }
 
+int ssd_test_empty_quadrilateral(ssd_handle *h, int frame, int surface)
+{
+  if(!h || frame < 0 || frame >= h->F || surface < -1 || surface >= kMaxPlateaus)
+    return fail(SSD_E_ARG, "ssd_test_empty_quadrilateral: bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  FrameState *d = h->lane[h->lastLane].dState + frame;
+  FrameState fs;
+  HIP_TRY(hipMemcpy(&fs, d, sizeof(fs), hipMemcpyDeviceToHost));
+  const int acc = surface < 0 ? kGroundAcc : surface;
+  if(surface < 0)
+  {
+    fs.sumZ[acc] = 0;
+    fs.cnt[acc] = 0u;
+  }
+  else
+  {
+    const int slot = surface - fs.firstStep;
+    if(surface >= fs.nPlateaus || slot < 0 || slot >= fs.nStepImages)
+      return fail(SSD_E_ARG, "ssd_test_empty_quadrilateral: not a step plateau of this frame");
+    fs.sumZ[acc] = fs.totZ[slot];
+    fs.cnt[acc] = static_cast<unsigned int>(fs.pl[surface].nPoints);
+  }
+  HIP_TRY(hipMemcpy(&d->sumZ[acc], &fs.sumZ[acc], sizeof(fs.sumZ[acc]), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(&d->cnt[acc], &fs.cnt[acc], sizeof(fs.cnt[acc]), hipMemcpyHostToDevice));
+  return SSD_OK;
+}
+
 /* the kernels' line helpers (csrc/ssd_math.h: line_through_i / line_through_d = LineCoordinates(p, q), types.h:140-158; intersect60 =
  * Line<double>::intersection, segmentation.cpp:344-362, whose numerators are LineCoordinates::det / detx / dety) compiled for the host */
 int ssd_test_line_host(const double pq[4], double abc_d[3], int32_t abc_i[3])

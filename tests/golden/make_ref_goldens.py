@@ -21,7 +21,8 @@ import oracle_binding as ob  # noqa: E402
 
 
 def hexlist(a):
-    return [float(x).hex() for x in np.asarray(a, dtype=np.float64).reshape(-1)]
+    # float.hex() drops a NaN's sign; float.fromhex("-nan") restores it (the sign is what "-nan" vs "nan" in a line depends on)
+    return [("-nan" if np.signbit(x) else "nan") if np.isnan(x) else float(x).hex() for x in np.asarray(a, dtype=np.float64).reshape(-1)]
 
 
 def random_quad(rng, kind):
@@ -61,6 +62,9 @@ def main():
     ser.append(sp)
     ser.append(rng.choice(specials, (3, 9)))
     ser.append(np.round(rng.normal(0, 2, (5, 9)), 3) + 0.0005)     # ties of the 3-decimal rounding
+    # round 4: the x86 default NaN (sign bit set) — what calcAverageZ's 0.0 / 0 leaves in a height — prints "-nan"; drawn from no rng
+    neg_nan = np.frombuffer(np.array([0xfff8000000000000], np.uint64).tobytes(), np.float64)[0]
+    ser.append(np.array([[neg_nan, -0.4, 0.45, 0.4, 0.45, -0.4, 0.73, 0.4, 0.73], [0.17, neg_nan, float("nan"), -neg_nan, 0.0, 1.0, 2.0, 3.0, 4.0]]))
     out_ser = [{"n": int(len(s)), "steps": hexlist(s), "line": ref.serialize(s)} for s in ser]
     with open(os.path.join(HERE, "ref_serialize.json"), "w") as f:
         json.dump(out_ser, f, indent=0)

@@ -162,9 +162,14 @@ def check_frame(ssd, oracle, det, cfg, cal, xyz, images=True, report=None, depth
 
 def check_results_only(ssd, oracle, cfg, cal, xyz, fr, report=None):
     """Compares a FrameResult obtained elsewhere (batch path) with the oracle's lean run."""
-    report = {} if report is None else report
     ocfg, ocal = ob.to_oracle_config(cfg), ob.to_oracle_calibration(cal)
-    n, steps, status = oracle.process_lean(ocfg, ocal, xyz)
+    return compare_results_only(ssd, oracle, fr, oracle.process_lean(ocfg, ocal, xyz), report)
+
+
+def compare_results_only(ssd, oracle, fr, lean, report=None):
+    """a FrameResult against what oracle.process_lean returned for the same frame: (n, steps, status)"""
+    report = {} if report is None else report
+    n, steps, status = lean
     _eq("status", fr.status, status)
     _eq("n_steps", fr.n_steps, n)
     for i in range(n):                       # corners first: a moved corner also moves the height, not the other way round
@@ -176,6 +181,30 @@ def check_results_only(ssd, oracle, cfg, cal, xyz, fr, report=None):
     if not (status & ob.ST_THROW):
         _eq("line", ssd.Stairs(fr).serialize(), oracle.serialize(steps) if n else '["stairs",["stairSteps",0]]')
     return report
+
+
+def check_batch_against_oracle(ssd, oracle, cfg, cal, buf, frame_bytes, results, width, height, workers=None, chunk=64, report=None):
+    """EVERY frame of a batch resident in device memory (frame i at buf.ptr + i * frame_bytes, float xyz) against the oracle:
+    the frames come back from the device `chunk` at a time, the oracle runs on a pool of threads (re-entrant; ctypes drops the
+    GIL: 11 ms per XGA frame and core), the comparisons in the calling thread.  Returns the number of frames checked."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    report = {} if report is None else report
+    ocfg, ocal = ob.to_oracle_config(cfg), ob.to_oracle_calibration(cal)
+    workers = workers or max(1, min(16, len(os.sched_getaffinity(0))))
+    checked = 0
+    with ThreadPoolExecutor(workers) as pool:
+        for at in range(0, len(results), chunk):
+            n = min(chunk, len(results) - at)
+            host = buf.download(frame_bytes * n, offset=frame_bytes * at, dtype=np.float32).reshape(n, height * width, 3)
+            for k, lean in enumerate(pool.map(lambda x: oracle.process_lean(ocfg, ocal, x), [host[k] for k in range(n)])):
+                try:
+                    compare_results_only(ssd, oracle, results[at + k], lean, report)
+                except Mismatch as e:
+                    raise Mismatch("frame %d: %s" % (at + k, e))
+                checked += 1
+    report["frames_checked"] = checked
+    return checked
 
 
 def compare_risers(dev, ora, report=None):

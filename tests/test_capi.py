@@ -92,6 +92,12 @@ def test_compute_entry_points_fail_loudly_without_gpu(ssd):
         ssd.PinnedArray((4, 4), np.float32)                       # ssd_host_alloc
     with pytest.raises(ssd.SsdError, match="no HIP device"):
         ssd.DeviceBuffer(1024)                                    # ssd_device_alloc
+    with pytest.raises(ssd.SsdError, match="no HIP device"):
+        ssd.device_info(0)                                        # ssd_device_info_get
+    before = os.sched_getaffinity(0)
+    with pytest.raises(ssd.SsdError, match="no HIP device"):
+        ssd.bind_thread_to_device(0)                              # ... and nothing was bound
+    assert os.sched_getaffinity(0) == before
     sc = ssd.make_scene(64, 48)
     with pytest.raises(ssd.SsdError, match="no HIP device"):
         ssd.synth_device([sc], 4096)                              # the frame source's device generator (libssd_source.so)

@@ -1,4 +1,4 @@
-"""The N > 1 path of bench.py on CPU (world_size-2 `gloo`): frames are sharded by contiguous ranges with no data-path
+"""The N > 1 path of bench.py on CPU (world_size-2 and world_size-8 `gloo`): frames are sharded by contiguous ranges with no data-path
 collective; the only communication is bench.Ranks — a barrier, the max-over-ranks of the elapsed time and the gather
 of the per-rank shard reports — and it is exercised here exactly as bench.main() uses it.  The launcher logic (who
 spawns the ranks, what a world-size mismatch does) is tested without a GPU as well."""
@@ -46,6 +46,71 @@ def test_frame_sharding_and_max_time_over_two_ranks(total):
     assert dt0 == dt1 == 0.75                                    # max over ranks
     assert sh1 is None                                           # only rank 0 receives the reports
     assert [s["rank"] for s in sh0] == [0, 1] and sh0[0]["frames"] == [lo0, hi0] and sh0[1]["frames"] == [lo1, hi1]
+
+
+def test_eight_ranks_shard_configs3_and_gather_their_reports():
+    """BASELINE configs[3] as the driver launches it — 8 ranks — on CPU: 16384 frames in 8 shards of 2048, the barrier, the
+    max over 8 ranks and the gather of 8 shard reports (each with its device's identity) on rank 0, whose count of distinct
+    devices is what lets a SCALE line prove 8 physical GPUs."""
+    import bench
+    import torch.multiprocessing as mp
+    world, total = 8, 16384
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 7
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [g[1:3] for g in got] == [(2048 * r, 2048 * (r + 1)) for r in range(world)]
+    assert all(g[3] == 0.5 + 0.25 * 7 for g in got)                      # every rank holds the slowest rank's time
+    assert all(g[4] is None for g in got[1:])
+    reports = got[0][4]
+    assert [s["rank"] for s in reports] == list(range(world)) and [s["frames"] for s in reports] == [[2048 * r, 2048 * (r + 1)] for r in range(world)]
+    assert bench.distinct_devices([s["where"] for s in reports]) == 8
+    assert bench.distinct_devices([reports[0]["where"]] * 8) == 1        # eight ranks on one GPU would show
+
+
+def _worker8(rank, world, port, total_frames, q):
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    w, r, lr = bench.world_from_env(world, {"WORLD_SIZE": str(world), "RANK": str(rank), "LOCAL_RANK": str(rank)})
+    ranks = bench.Ranks(w, r)
+    lo, hi = bench.shard(total_frames, world, rank)
+    ranks.barrier()
+    dt_max = ranks.max(0.5 + 0.25 * rank)
+    where = {"device": lr, "pci_bus_id": "0000:%02x:00.0" % (0x10 + 0x10 * lr), "uuid": "%032x" % lr, "numa_node": lr // 4}
+    shards = ranks.gather({"rank": rank, "frames": [lo, hi], "where": where})
+    q.put((rank, lo, hi, dt_max, shards))
+    ranks.close()
+
+
+def test_a_rank_binds_itself_next_to_its_gpu():
+    """bench.bind_rank_to_device: the library binds the calling thread (ssd_bind_thread_to_device), the process mask follows;
+    where the platform names no local CPUs nothing is touched.  The library is played by a stand-in (no GPU here)."""
+    import bench
+
+    class FakeSsd:
+        def __init__(self, bound):
+            self.bound = bound
+
+        def device_info(self, device):
+            return {"pci_bus_id": "0000:c5:00.0", "uuid": "ab" * 16, "numa_node": 1, "n_local_cpus": self.bound, "cpu_list": "64-127"}
+
+        def bind_thread_to_device(self, device):
+            return self.bound
+
+    calls = []
+    info = bench.bind_rank_to_device(FakeSsd(64), 3, set_affinity=lambda pid, cpus: calls.append((pid, set(cpus))))
+    assert info["device"] == 3 and info["bound"] and info["cpus_bound"] == 64 and info["pci_bus_id"] == "0000:c5:00.0"
+    assert calls == [(0, set(os.sched_getaffinity(0)))]
+    calls.clear()
+    info = bench.bind_rank_to_device(FakeSsd(0), 0, set_affinity=lambda pid, cpus: calls.append(1))
+    assert not info["bound"] and calls == []
 
 
 def test_shard_covers_everything_for_any_world():

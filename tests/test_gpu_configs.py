@@ -23,17 +23,18 @@ def _state_counts(ssd, det, frame):
 
 def test_config3_full_batch(ssd, oracle, gpu_device):
     """BASELINE configs[2] (SURVEY.md section 8(d) "config 3") at its full size: 1024 XGA frames resident in HBM (9.66 GB),
-    one batch (grid.x = 1024, ~25 k blocks per streaming kernel).  Every 64th frame against the oracle; the second run
+    one batch (grid.x = 1024, ~25 k blocks per streaming kernel).  EVERY frame against the oracle (round 4: the oracle on a pool
+    of threads, parity.check_batch_against_oracle; round 3 sampled every 64th); the second run
     bitwise equal (workspace left clean by 1024 frames' worth of consumers); histogram mass = in-range count <= non-zero
     count <= W H for all 1024 frames."""
     n, W, H = 1024, 1024, 768
     sc_list = scenes.batch_scenes(ssd, W, H, n, base_seed=100000, rng_seed=1000)      # the frames bench.py times on rank 0
     trans = ssd.transformation_for_scene(sc_list[0])
-    cfg = ssd.default_config(W, H, max_frames_per_batch=n)
+    cfg = ssd.default_config(W, H, max_frames_per_batch=n, batches_in_flight=ssd.BATCHES_IN_FLIGHT_THROUGHPUT)
     buf = ssd.DeviceBuffer(W * H * 12 * n, gpu_device)
     ssd.synth_device(sc_list, buf.ptr, device=gpu_device)
     det = ssd.Detector(cfg, trans, gpu_device)
-    assert det.batches_in_flight == 3                  # the default for batches: three workspaces used in turn
+    assert det.batches_in_flight == 3                  # asked for (what bench.py runs): three workspaces used in turn
     det.enqueue(buf.ptr, n)
     r1 = det.fetch_list(n)
     for i in range(n):
@@ -45,8 +46,8 @@ def test_config3_full_batch(ssd, oracle, gpu_device):
         r2 = det.fetch_list(n)
         assert [bytes(x) for x in r1] == [bytes(x) for x in r2]
     rep = {}
-    for i in range(0, n, 64):
-        parity.check_results_only(ssd, oracle, cfg, trans.constants, ssd.synth_host([sc_list[i]])[0], r1[i], rep)
+    assert parity.check_batch_against_oracle(ssd, oracle, cfg, trans.constants, buf, W * H * 12, r1, W, H, report=rep) == 1024
+    assert rep["frames_checked"] == 1024
     assert rep.get("max_corner_err", 0.0) == 0.0 and rep.get("max_height_err", 0.0) <= parity.TOL_HEIGHT
     assert sum(1 for r in r1 if r.n_steps >= 3) >= n * 9 // 10
     det.close()
@@ -56,13 +57,13 @@ def test_config3_full_batch(ssd, oracle, gpu_device):
 def test_config4_rank_share(ssd, oracle, gpu_device):
     """BASELINE configs[3] (SURVEY.md section 8(d) "config 4": 16,384 frames over 8 GPUs) at the size ONE rank gets: 2048 XGA
     frames resident in HBM (19.3 GB), max_frames_per_batch = 2048, one batch per call (grid.x = 2048, ~49 k blocks per streaming
-    kernel, 3.6 GB per workspace).  The frames are rank 0's of that run (bench.py --gpus 8 --frames 2048).  Every 128th frame
-    against the oracle; four calls (every workspace, the first one twice) bitwise equal; histogram mass = in-range count
+    kernel, 3.6 GB per workspace).  The frames are rank 0's of that run (bench.py --gpus 8 --frames 2048).  EVERY frame
+    against the oracle (round 4; round 3: every 128th); four calls (every workspace, the first one twice) bitwise equal; histogram mass = in-range count
     <= non-zero count <= W H for all 2048 frames."""
     n, W, H = 2048, 1024, 768
     sc_list = scenes.batch_scenes(ssd, W, H, n, base_seed=100000, rng_seed=1000)
     trans = ssd.transformation_for_scene(sc_list[0])
-    cfg = ssd.default_config(W, H, max_frames_per_batch=n)
+    cfg = ssd.default_config(W, H, max_frames_per_batch=n, batches_in_flight=ssd.BATCHES_IN_FLIGHT_THROUGHPUT)
     buf = ssd.DeviceBuffer(W * H * 12 * n, gpu_device)
     ssd.synth_device(sc_list, buf.ptr, device=gpu_device)
     det = ssd.Detector(cfg, trans, gpu_device)
@@ -78,8 +79,8 @@ def test_config4_rank_share(ssd, oracle, gpu_device):
         r2 = det.fetch_list(n)
         assert [bytes(x) for x in r1] == [bytes(x) for x in r2]
     rep = {}
-    for i in range(0, n, 128):
-        parity.check_results_only(ssd, oracle, cfg, trans.constants, ssd.synth_host([sc_list[i]])[0], r1[i], rep)
+    assert parity.check_batch_against_oracle(ssd, oracle, cfg, trans.constants, buf, W * H * 12, r1, W, H, report=rep) == 2048
+    assert rep["frames_checked"] == 2048
     assert rep.get("max_corner_err", 0.0) == 0.0 and rep.get("max_height_err", 0.0) <= parity.TOL_HEIGHT
     assert sum(1 for r in r1 if r.n_steps >= 3) >= n * 9 // 10
     det.close()
@@ -87,8 +88,8 @@ def test_config4_rank_share(ssd, oracle, gpu_device):
 
 
 def test_config5_batch(ssd, oracle, gpu_device):
-    """BASELINE configs[4] (SURVEY.md "config 5"): a batch of 64 FHD stress frames (8 noisy steps, 5 % outliers) in HBM; every
-    16th frame against the oracle, second run bitwise equal, histogram mass = in-range count."""
+    """BASELINE configs[4] (SURVEY.md "config 5"): a batch of 64 FHD stress frames (8 noisy steps, 5 % outliers) in HBM; EVERY
+    frame against the oracle (round 4; round 3: every 16th), second run bitwise equal, histogram mass = in-range count."""
     n, W, H = 64, 1920, 1080
     sc_list = scenes.fhd_stress_scenes(ssd, n, base_seed=9000)
     trans = ssd.transformation_for_scene(sc_list[0])
@@ -105,8 +106,8 @@ def test_config5_batch(ssd, oracle, gpu_device):
     r2 = det.fetch_list(n)
     assert [bytes(x) for x in r1] == [bytes(x) for x in r2]
     rep = {}
-    for i in range(0, n, 16):
-        parity.check_results_only(ssd, oracle, cfg, trans.constants, ssd.synth_host([sc_list[i]])[0], r1[i], rep)
+    assert parity.check_batch_against_oracle(ssd, oracle, cfg, trans.constants, buf, W * H * 12, r1, W, H, chunk=16, report=rep) == 64
+    assert rep["frames_checked"] == 64
     assert rep.get("max_corner_err", 0.0) == 0.0 and rep.get("max_height_err", 0.0) <= parity.TOL_HEIGHT
     assert all(5 <= r.n_steps <= 9 for r in r1)      # the reference reports fewer than the 8 built steps (SURVEY.md 8(a) probe note)
     det.close()
@@ -232,9 +233,9 @@ def test_host_fed_ingest_slices_pinned_and_pageable(ssd, oracle, gpu_device):
     for i in range(0, n, 10):
         parity.check_results_only(ssd, oracle, cfg, trans.constants, xyz[i], ref_x[i])
         parity.check_results_only(ssd, oracle, cfg, trans.constants, oracle.deproject(intr, depth[i]), ref_d[i])
-    # the same through a handle with three workspaces: the slices run on the handle's own streams, the staging buffers are
-    # released by the slice's end (ssd_stream_wait inside the library), not by the ingest stream's position
-    det3 = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=128), trans, gpu_device)
+    # the same through a handle with three workspaces: the slices run on the handle's own streams and overlap, a staging buffer
+    # is released by the end of the slice that read it (an event on that slice's stream), not by the ingest stream's position
+    det3 = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=128, batches_in_flight=3), trans, gpu_device)
     assert det3.batches_in_flight == 3
     det3.set_intrinsics(intr)
     for _ in range(2):
@@ -285,6 +286,51 @@ def test_calls_on_different_streams_are_ordered_by_the_library(ssd, oracle, gpu_
     b.free()
     for st in streams:
         hip.hipStreamDestroy(st)
+
+
+def test_default_handle_orders_a_refill_of_its_frames_behind_the_batch(ssd, oracle, gpu_device):
+    """a handle created with the DEFAULT configuration (ssd_default_config: batches_in_flight = 0)
+    has one workspace and runs in strict stream order, whatever its batch size — so `enqueue, then overwrite the same frame
+    buffer on the same stream` (here the NULL stream: ssd_device_upload is a plain hipMemcpy) needs no fetch in between.
+    Round 3 resolved 0 to three workspaces on streams of the handle's own for batches of >= 16 frames, and exactly this
+    raced.  Every result must be the FIRST contents' (oracle), five refills in a row."""
+    n, W, H = 32, 640, 480
+    sc_list = scenes.batch_scenes(ssd, W, H, 6 * n, base_seed=77000, rng_seed=3)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    cfg = ssd.default_config(W, H)                      # as ssd_default_config leaves it
+    assert cfg.batches_in_flight == 0 and cfg.max_frames_per_batch >= n
+    det = ssd.Detector(cfg, trans, gpu_device)
+    assert det.batches_in_flight == 1
+    host = ssd.synth_host(sc_list)
+    buf = ssd.DeviceBuffer(W * H * 12 * n, gpu_device)
+    buf.upload(host[:n])
+    for r in range(5):
+        det.enqueue(buf.ptr, n)                         # NULL stream
+        buf.upload(host[(r + 1) * n:(r + 2) * n])       # refill at once: ordered behind the batch by the stream
+        got = det.fetch_list(n)
+        for i in range(n):
+            parity.check_results_only(ssd, oracle, cfg, trans.constants, host[r * n + i], got[i])
+    det.close()
+    buf.free()
+
+
+def test_device_identity_and_local_cpus(ssd, gpu_device):
+    """ssd_device_info_get / ssd_bind_thread_to_device (8-GPU readiness): the PCI bus id has sysfs's
+    spelling, the UUID is there, and binding leaves the thread on a non-empty subset of the CPUs it had."""
+    import re
+    info = ssd.device_info(gpu_device)
+    assert re.fullmatch(r"[0-9a-f]{4}:[0-9a-f]{2}:[0-9a-f]{2}\.[0-9a-f]", info["pci_bus_id"]), info
+    assert len(info["uuid"]) in (0, 32)
+    before = os.sched_getaffinity(0)
+    try:
+        bound = ssd.bind_thread_to_device(gpu_device)
+        after = os.sched_getaffinity(0)
+        assert after and after <= before
+        assert bound == 0 and after == before or bound == len(after)
+        if info["n_local_cpus"] > 0 and info["numa_node"] >= 0:
+            assert os.path.isdir("/sys/devices/system/node/node%d" % info["numa_node"])
+    finally:
+        os.sched_setaffinity(0, before)
 
 
 def test_handle_keeps_three_batches_in_flight(ssd, oracle, gpu_device):

@@ -183,3 +183,75 @@ def test_resolutions_off_the_beaten_path(ssd, oracle, gpu_device, res):
         assert bytes(res3[0]) == bytes(res3[2]) and res3[1].n_steps == 0
         parity.check_results_only(ssd, oracle, cfg, trans.constants, xyz, res3[0])
         det.close()
+
+
+def _ring_cloud(copies=3):
+    """A 512 x 512 frame over a measuring range of exactly one metre each way (pixel borders = multiples of 1/512 m, exact in
+    float32): a dense ground plane and ONE step plateau that consists only of the outline of a rectangle, its points lying
+    exactly on pixel corners.  The outline the reference finds passes through those very coordinates, and its point test is
+    strict (quadrilateralTest.cpp:58-61, :145-166) — so the step is valid, convex, and accepts none of its own points."""
+    n = 512
+    px = lambda c: -0.5 + c / 512.0
+    py = lambda r: 1.25 - r / 512.0
+    gx, gy = np.meshgrid(np.arange(60, 450), np.arange(400, 500))
+    pts = [np.stack([px(gx.ravel() + 0.5), py(gy.ravel() + 0.5), np.full(gx.size, 0.005)], 1)]
+    r0, r1, c0, c1 = 200, 330, 100, 410
+    ring = [(c, r) for c in range(c0, c1 + 1) for r in (r0, r1)] + [(c, r) for r in range(r0 + 1, r1) for c in (c0, c1)]
+    ring = np.array(ring)
+    for _ in range(copies):                              # 880 ring points x 3: above filterPeaks' 2000
+        pts.append(np.stack([px(ring[:, 0]), py(ring[:, 1]), np.full(len(ring), 0.1755)], 1))
+    p = np.concatenate(pts)
+    p[:, 2] += Z_SHIFT
+    out = np.zeros((n * n, 3), dtype=np.float32)
+    out[:len(p)] = p.astype(np.float32)
+    return out.reshape(n, n, 3)
+
+
+def test_step_whose_quadrilateral_accepts_no_point_reads_minus_nan(ssd, oracle, gpu_device):
+    """VERDICT round 3, item 3.  calcAverageZ divides 0.0 by 0 for a quadrilateral without points (pointcloud.cpp:574-581):
+    on the reference's x86 that is the default NaN with the sign bit set, and the line reads "-nan" (stairs.cpp:43).  The
+    GPU's own 0.0 / 0.0 is the positive NaN ("nan"): k_final states the empty case instead of dividing.  A hand-built cloud
+    reaches it: every intermediate, the result's sign bit and the line's bytes against the oracle."""
+    xyz = _ring_cloud()
+    trans = calibration(ssd)
+    cfg = ssd.default_config(512, 512, max_frames_per_batch=1)
+    cfg.x_min, cfg.x_max, cfg.y_min, cfg.y_max = -0.5, 0.5, 0.25, 1.25
+    det = ssd.Detector(cfg, trans, gpu_device)
+    rep = parity.check_frame(ssd, oracle, det, cfg, trans.constants, xyz, images=True)
+    fr = det.process_host(xyz)[0]
+    det.close()
+    assert rep["n_steps"] == 2 and fr.n_steps == 2
+    h = fr.steps[1].height
+    assert np.isnan(h) and np.signbit(h), "the empty quadrilateral's mean must be x86's default NaN (sign bit set)"
+    n, steps, status = oracle.process_lean(ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants), xyz)
+    assert n == 2 and np.isnan(steps[1][0]) and np.signbit(steps[1][0])
+    line = ssd.Stairs(fr).serialize()
+    assert line == oracle.serialize(steps) and '["height",-nan]' in line and line.count("nan") == 1
+
+
+def test_ground_quadrilateral_without_points_reads_minus_nan(ssd, oracle, gpu_device):
+    """The same for the ground's sum (calcGround, pointcloud.cpp:528-547), which no cloud was found to empty: the state is
+    rewritten between k_inquad and k_final (test hook) as if the ground quadrilateral had accepted nothing.  The frame's other
+    numbers must not move, the ground's height must read -nan."""
+    W_, H_ = 640, 480
+    sc = ssd.make_scene(W_, H_, n_steps=3, seed=515, sigma=0.001)
+    trans = ssd.transformation_for_scene(sc)
+    cfg = ssd.default_config(W_, H_, max_frames_per_batch=1)
+    xyz = ssd.synth_host([sc])[0]
+    det = ssd.Detector(cfg, trans, gpu_device)
+    good = det.process_host(xyz)[0]
+    assert good.n_steps == 4
+    buf = ssd.DeviceBuffer(W_ * H_ * 12, gpu_device)
+    buf.upload(xyz)
+    det.enqueue(buf.ptr, 1, stages=ssd.STAGE_ALL & ~ssd.STAGE_FINAL)
+    det.empty_quadrilateral(0, -1)
+    det.enqueue(buf.ptr, 1, stages=ssd.STAGE_FINAL)
+    fr = det.fetch_list(1)[0]
+    det.close()
+    buf.free()
+    assert fr.n_steps == 4 and np.isnan(fr.steps[0].height) and np.signbit(fr.steps[0].height)
+    assert [list(fr.steps[i].quad) for i in range(4)] == [list(good.steps[i].quad) for i in range(4)]
+    assert [fr.steps[i].height for i in range(1, 4)] == [good.steps[i].height for i in range(1, 4)]
+    want = ssd.Stairs(good).serialize()
+    cut = want.index('["height",') + len('["height",')
+    assert ssd.Stairs(fr).serialize() == want[:cut] + "-nan" + want[want.index("]", cut):]

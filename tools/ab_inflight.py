@@ -11,7 +11,7 @@ ssd = importlib.import_module("stair-step-detector_amd")
 import scenes
 W, H, F = 1024, 768, 1024
 sc = scenes.batch_scenes(ssd, W, H, F, base_seed=100000, rng_seed=1000)
-det = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=F), ssd.transformation_for_scene(sc[0]), 0)
+det = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=F, batches_in_flight=3), ssd.transformation_for_scene(sc[0]), 0)
 buf = ssd.DeviceBuffer(W * H * 12 * F, 0)
 ssd.synth_device(sc, buf.ptr, device=0)
 def run(n, ahead=2):

@@ -49,7 +49,7 @@ def main():
         scenes = [ssd.make_scene(W, H, **kw) for kw in kws]
         trans = ssd.transformation_for_scene(scenes[0])
         # workspaces of the handle: the library's choice (3 from 128 frames on), or one (every call in the same workspace)
-        cfg = ssd.default_config(W, H, max_frames_per_batch=F, batches_in_flight=int(rng.choice([0, 1])))
+        cfg = ssd.default_config(W, H, max_frames_per_batch=F, batches_in_flight=int(rng.choice([1, 3])))
         depth_in = False
         if mixed:
             depth_in = W % 4 == 0 and rng.random() < 0.4
