@@ -708,7 +708,7 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   h->lastPinned = pinned;
   const float *xyz = static_cast<const float *>(d_xyz);
   const size_t strideFloats = depthInput ? frame_stride_bytes / 2 : frame_stride_bytes / 4;    /* elements of the source type */
-  const DepthSrc depthSrc{ h->dDepthMaps, h->dDepthMaps ? h->dDepthMaps + P.W : nullptr, h->intr.depth_units, P.W, P.H };
+  const DepthSrc depthSrc{ h->dDepthMaps, h->dDepthMaps ? h->dDepthMaps + P.W : nullptr, h->intr.depth_units, P.W, P.H, depth_row_magic(P.W, P.H) };
   const DepthSrc *depth = depthInput ? &depthSrc : nullptr;
   const int chunk = choose_chunk(h->tune, P.nPoints, nframes);
   /* K2 and K4 walk cell columns: the taller a block's chunk, the fewer window flushes and block starts per cell (below) */

@@ -61,7 +61,19 @@ struct DepthSrc
   const float *xmap, *ymap;
   float depthUnits;
   int W, H;
+  /* row of a point index without an integer division (about twenty instructions on this ISA): row = mulhi(idx, rowMagic) >> 7
+   * with rowMagic = ceil(2^39 / W) — exact for idx * W < 2^39 (idx < W * H <= 2^26, W <= 2^13), fits 32 bits for W > 128;
+   * 0 = divide (small images) */
+  unsigned int rowMagic;
 };
+
+/* host + device: the magic of DepthSrc::rowMagic, or 0 when the shortcut does not apply */
+__host__ __device__ inline unsigned int depth_row_magic(int W, int H)
+{
+  if(W <= 128 || W > 8192 || static_cast<long long>(W) * H > (1ll << 26))
+    return 0u;
+  return static_cast<unsigned int>(((1ull << 39) + static_cast<unsigned long long>(W) - 1ull) / static_cast<unsigned long long>(W));
+}
 
 /* all constants of one handle */
 struct Params

@@ -162,34 +162,38 @@ constexpr int kSrcDepth16 = 2;     /* 16-bit depth image + intrinsics: deproject
  * tail of a frame whose point count is not a multiple of 4): 12-byte loads.  kSrcDepth16: four 16-bit depth
  * values (one 8-byte load) turned into points exactly as librealsense's pointcloud block does in float:
  * d = raw * depth_units; point = (d * xmap[u], d * ymap[v], d); raw = 0 gives the invalid point (0,0,0). */
+/* kSrcDepth16: the lane's four depth pixels and the maps' values for them -> four points, in float as librealsense does
+ * (d = raw * depth_units; point = (d * xmap[u], d * ymap[v], d); raw = 0 gives the invalid point (0,0,0)) */
+__device__ __forceinline__ void deproject4(const uint2 raw, const float4 xm, const float ym, const float units, F3 (&v)[kPts])
+{
+  const float d0 = static_cast<float>(raw.x & 0xffffu) * units, d1 = static_cast<float>(raw.x >> 16) * units;
+  const float d2 = static_cast<float>(raw.y & 0xffffu) * units, d3 = static_cast<float>(raw.y >> 16) * units;
+  v[0] = F3{ d0 * xm.x, d0 * ym, d0 };
+  v[1] = F3{ d1 * xm.y, d1 * ym, d1 };
+  v[2] = F3{ d2 * xm.z, d2 * ym, d2 };
+  v[3] = F3{ d3 * xm.w, d3 * ym, d3 };
+}
+/* image row of point index idx (DepthSrc::rowMagic) */
+__device__ __forceinline__ int depth_row(const DepthSrc &D, int idx)
+{
+  return D.rowMagic ? static_cast<int>(__umulhi(static_cast<unsigned int>(idx), D.rowMagic) >> 7) : idx / D.W;
+}
+
 template<int SRC>
 __device__ __forceinline__ void load_points(const float *__restrict__ base, int idx0, int end, F3 (&v)[kPts], const DepthSrc &D)
 {
   if(SRC == kSrcDepth16)
   {
+    /* width % 4 == 0 and idx0 % 4 == 0 (ssd_enqueue_depth checks the first, every caller provides the second): the four
+     * pixels share the image row, lie wholly inside or wholly outside the frame, and their x-map entries are one aligned
+     * 16-byte load (round 3: four dependent 4-byte loads and a division per call) */
     const unsigned short *depth = reinterpret_cast<const unsigned short *>(base);
-    unsigned short raw[kPts] = { 0, 0, 0, 0 };
-    if(idx0 + kPts <= end)
-    {
-      const ushort4 q = *reinterpret_cast<const ushort4 *>(depth + idx0);
-      raw[0] = q.x; raw[1] = q.y; raw[2] = q.z; raw[3] = q.w;
-    }
-    else
-    {
-#pragma unroll
-      for(int j = 0; j < kPts; j++)
-        if(idx0 + j < end)
-          raw[j] = depth[idx0 + j];
-    }
-    const int row = idx0 / D.W, col = idx0 - row * D.W;      /* W % 4 == 0: the four points share the row */
+    const bool inside = idx0 + kPts <= end;
+    const uint2 raw = inside ? *reinterpret_cast<const uint2 *>(depth + idx0) : make_uint2(0u, 0u);
+    const int row = depth_row(D, idx0), col = idx0 - row * D.W;
     const float ym = D.ymap[min(row, D.H - 1)];               /* lanes past the end of the frame (raw = 0) stay inside the map */
-#pragma unroll
-    for(int j = 0; j < kPts; j++)
-    {
-      const float d = static_cast<float>(raw[j]) * D.depthUnits;
-      const float xm = D.xmap[col + j < D.W ? col + j : 0];
-      v[j] = F3{ d * xm, d * ym, d };
-    }
+    const float4 xm = *reinterpret_cast<const float4 *>(D.xmap + col);
+    deproject4(raw, xm, ym, D.depthUnits, v);
     return;
   }
   if(SRC == kSrcF3Aligned && idx0 + kPts <= end)
@@ -297,16 +301,16 @@ __device__ __forceinline__ unsigned int row_max_u32(unsigned int v)
   v = max(v, static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x121, 0xf, 0xf, false)));
   return v;
 }
-/* the grid cell of a distance given by its high dword: lowest possible (low dword 0) / highest possible (next high dword) */
-__device__ __forceinline__ unsigned int box_cell_low(unsigned int hi, double scale)
+/* The box of a cell from the four extremes' high dwords: a minimum with the low dword 0 is the lowest the distance can have
+ * been (its cell is below 256: the distance is below the range), a maximum with the NEXT high dword the highest (clamped). */
+__device__ __forceinline__ unsigned int cell_box_from_high_dwords(unsigned int x0, unsigned int x1, unsigned int y0, unsigned int y1,
+                                                                  double boxX, double boxY)
 {
-  const double d = __hiloint2double(static_cast<int>(hi), 0);
-  return min(static_cast<unsigned int>(d * scale), 255u);
-}
-__device__ __forceinline__ unsigned int box_cell_high(unsigned int hi, double scale)
-{
-  const double d = __hiloint2double(static_cast<int>(hi + 1u), 0);
-  return min(static_cast<unsigned int>(d * scale), 255u);
+  const unsigned int cx0 = static_cast<unsigned int>(__hiloint2double(static_cast<int>(x0), 0) * boxX);
+  const unsigned int cy0 = static_cast<unsigned int>(__hiloint2double(static_cast<int>(y0), 0) * boxY);
+  const unsigned int cx1 = min(static_cast<unsigned int>(__hiloint2double(static_cast<int>(x1 + 1u), 0) * boxX), 255u);
+  const unsigned int cy1 = min(static_cast<unsigned int>(__hiloint2double(static_cast<int>(y1 + 1u), 0) * boxY), 255u);
+  return (cx0 | (cx1 << 8)) | ((cy0 | (cy1 << 8)) << 16);
 }
 
 /* The list of the cells of a block's chunk whose mask meets `wanted`, in LDS, COLUMN-major: the cells of one
@@ -472,15 +476,55 @@ __device__ __forceinline__ void hist_block(HistLds &L, const float *__restrict__
     groups = row_or_u32(groups);
     x0 = row_min_u32(x0); x1 = row_max_u32(x1);
     y0 = row_min_u32(y0); y1 = row_max_u32(y1);
+    /* the reductions end here, in all lanes: left to itself the compiler moves their last step into the branch below, where a
+     * DPP operand cannot be folded into the min / max (ten instructions instead of five per tile) */
+    asm volatile("" : "+v"(groups), "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
     if((lane & 15) == 0)                                         /* cell = 64 consecutive points = lanes 16q .. 16q+15 */
-    {
-      const unsigned int box = groups == 0u ? 0u
-        : box_cell_low(x0, P.boxX) | (box_cell_high(x1, P.boxX) << 8) | (box_cell_low(y0, P.boxY) << 16) | (box_cell_high(y1, P.boxY) << 24);
-      lInfo[it * kCellsPerTile + (tid >> 4)] = make_uint2(groups, box);
-    }
+      lInfo[it * kCellsPerTile + (tid >> 4)] = make_uint2(groups, cell_box_from_high_dwords(x0, x1, y0, y1, P.boxX, P.boxY));
     it++;
   };
-  SSD_STREAM_LOOP(tileBody)
+  if(SRC == kSrcDepth16)
+  {
+    /* The depth stream: 8 bytes per lane and tile, and the maps.  A tile is 1024 consecutive pixels, so from tile to tile a
+     * lane's row advances by 1024 / W and its column by 1024 % W (wrapping once at most): no division in the loop, and when
+     * 1024 % W == 0 (XGA: a tile is one image row) the lane's four x-map entries never change - loaded once per block.  The
+     * next tile's pixels and map values are requested before the current tile is processed, as in SSD_STREAM_LOOP.
+     * (Round 3 went through load_points: per tile a division, five dependent map loads, ~90 instructions; K1 on depth input is
+     * bound by instruction issue, not by its 2 bytes per point.) */
+    const unsigned short *depth = reinterpret_cast<const unsigned short *>(base);
+    const int dRow = kTile / D.W, dCol = kTile - dRow * D.W;
+    int idx = begin + kPts * tid;
+    int row = depth_row(D, idx), col = idx - row * D.W;
+    float4 xm = *reinterpret_cast<const float4 *>(D.xmap + col);
+    float ym = D.ymap[min(row, D.H - 1)];
+    uint2 raw = idx < end ? *reinterpret_cast<const uint2 *>(depth + idx) : make_uint2(0u, 0u);
+    while(true)
+    {
+      const bool more = idx - kPts * tid + kTile < end;                    /* block-uniform */
+      uint2 rawN = make_uint2(0u, 0u);
+      float4 xmN = xm;
+      float ymN = ym;
+      if(more)
+      {
+        idx += kTile;
+        row += dRow; col += dCol;
+        if(col >= D.W) { col -= D.W; row++; }
+        if(idx < end)
+          rawN = *reinterpret_cast<const uint2 *>(depth + idx);
+        ymN = D.ymap[min(row, D.H - 1)];
+        if(dCol != 0)
+          xmN = *reinterpret_cast<const float4 *>(D.xmap + col);
+      }
+      F3 v[kPts];
+      deproject4(raw, xm, ym, D.depthUnits, v);
+      tileBody(v);
+      if(!more)
+        break;
+      raw = rawN; xm = xmN; ym = ymN;
+    }
+  }
+  else
+    SSD_STREAM_LOOP(tileBody)
 
   if(lane == 0 && nz)
     atomicAdd(&lNonZero, nz);
@@ -925,7 +969,8 @@ __device__ __forceinline__ bool image_pixel(const PointParams &P, const PixelPar
 {
   ix = static_cast<int>((wx - P.xMin) * X.xToImage);
   iy = static_cast<int>((P.yMax - wy) * X.yToImage);
-  return ix >= 0 && ix < X.W && iy >= 0 && iy < X.H;
+  /* two unsigned compares: a negative coordinate is a huge unsigned one */
+  return (static_cast<unsigned int>(ix) < static_cast<unsigned int>(X.W)) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(X.H));
 }
 
 /* round(z * 2^40) without a double->int64 conversion (a long software sequence on this ISA): adding
