@@ -149,7 +149,7 @@ SOURCE_EXPORTS = [
 # libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
 HOOK_EXPORTS = [
     "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_ground_image", "ssd_test_line_host", "ssd_test_intersect_host", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_best_line_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
-    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_testhooks_last_error",
+    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_test_record_offset", "ssd_test_record_realloc", "ssd_test_record_realloc_sized", "ssd_test_record_release", "ssd_testhooks_last_error",
 ]
 SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
 HOOKS_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_testhooks.so")
@@ -266,6 +266,11 @@ def hooks_lib():
     L.ssd_test_frame_state.restype = C.c_longlong
     L.ssd_test_ground_image.argtypes = [vp, i32, vp]
     L.ssd_test_empty_quadrilateral.argtypes = [vp, i32, i32]
+    L.ssd_test_record_offset.argtypes = [vp, C.c_size_t]
+    L.ssd_test_record_realloc.argtypes = [vp]
+    L.ssd_test_record_realloc.restype = C.c_ulonglong
+    L.ssd_test_record_realloc_sized.argtypes = [vp, C.c_size_t, C.c_size_t]
+    L.ssd_test_record_realloc_sized.restype = C.c_ulonglong
     L.ssd_test_line_host.argtypes = [vp, vp, vp]
     L.ssd_test_intersect_host.argtypes = [vp, vp, vp]
     L.ssd_test_sort_host.argtypes = [vp, i32, vp]
@@ -486,6 +491,15 @@ class Detector:
     def empty_quadrilateral(self, frame, surface):
         """test hook: rewrites the sums of a surface (-1 = ground, else plateau index) as if its quadrilateral had accepted no point"""
         _check(hooks_lib().ssd_test_empty_quadrilateral(self._h, frame, surface), "hooks")
+
+    def record_offset(self, offset_bytes):
+        """tools hook: where the first workspace's cell records lie inside their allocation"""
+        _check(hooks_lib().ssd_test_record_offset(self._h, offset_bytes), "hooks")
+
+    def record_realloc(self, extra_bytes=0, offset_bytes=0):
+        """tools hook: a newly allocated array for the first workspace's cell records (optionally inside a larger allocation);
+        returns its device address"""
+        return int(hooks_lib().ssd_test_record_realloc_sized(self._h, extra_bytes, offset_bytes))
 
     def ground_image_raw(self, frame):
         """test hook: the ground bit image as it lies in the last enqueue's workspace (height x width bytes)"""

@@ -58,6 +58,7 @@ void tuning_from_env(ssd_tuning &t)
   t.k4ChunkTiles = env_int("SSD_K4_CHUNK_TILES", t.k4ChunkTiles);
   t.winShift = env_int("SSD_WIN_SHIFT", 0);
   t.winShiftGround = env_int("SSD_WIN_SHIFT_G", 0);
+  t.recordPad = env_int("SSD_RECORD_PAD", t.recordPad);
 }
 #endif
 
@@ -425,15 +426,18 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
       return fail(e_ == hipErrorOutOfMemory ? SSD_E_NOMEM : SSD_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     }                                                                                                   \
   } while(0)
-  h->tileMaskStride = (static_cast<size_t>(P.nPoints) + kTileHost - 1) / kTileHost * (kTileHost / kCellHost);   /* cell records per frame */
+  h->tileMaskStride = (static_cast<size_t>(P.nPoints) + kTileHost - 1) / kTileHost * (kTileHost / kCellHost)      /* cell records per frame */
+                      + static_cast<size_t>(h->tune.recordPad);
   const size_t maskBytes = h->tileMaskStride * sizeof(uint2) * h->F;
+  h->recordBytes = maskBytes;
   for(int k = 0; k < depth; k++)
   {
     ssd_lane &L = h->lane[k];
     HIP_TRY_H(hipMalloc(&L.dState, sizeof(FrameState) * h->F));
     HIP_TRY_H(hipMalloc(&L.dStepImg, stepBytes));
     HIP_TRY_H(hipMalloc(&L.dGroundImg, groundBytes));
-    HIP_TRY_H(hipMalloc(&L.dTileMasks, maskBytes));
+    HIP_TRY_H(hipMalloc(&L.dTileMasksBase, maskBytes + kRecordSlackBytes));
+    L.dTileMasks = L.dTileMasksBase;
     HIP_TRY_H(hipEventCreateWithFlags(&L.in, hipEventDisableTiming));
     HIP_TRY_H(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
     if(depth > 1)
@@ -468,7 +472,7 @@ int ssd_destroy(ssd_handle *h)
     if(L.dState) (void)hipFree(L.dState);
     if(L.dStepImg) (void)hipFree(L.dStepImg);
     if(L.dGroundImg) (void)hipFree(L.dGroundImg);
-    if(L.dTileMasks) (void)hipFree(L.dTileMasks);
+    if(L.dTileMasksBase) (void)hipFree(L.dTileMasksBase);
     if(L.in) (void)hipEventDestroy(L.in);
     if(L.done) (void)hipEventDestroy(L.done);
     if(L.stream) (void)hipStreamDestroy(L.stream);

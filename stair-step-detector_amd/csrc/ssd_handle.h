@@ -21,6 +21,7 @@ struct ssd_tuning
   int k24MinBlocks = 1536, k24TallBlocks = 6144;
   int k2ChunkTiles = 32, k4ChunkTiles = 16;
   int winShift = 0, winShiftGround = 0;     /* > 0: shape of the waves' LDS image windows, forced */
+  int recordPad = 0;              /* cell records per frame added to the stride between the frames' record arrays */
 };
 
 /* One complete workspace of a handle: everything a batch in flight owns on the device.  A handle has `depth` of them
@@ -32,6 +33,7 @@ struct ssd_lane
   unsigned long long *dStepImg = nullptr;
   unsigned long long *dGroundImg = nullptr;
   uint2 *dTileMasks = nullptr;             /* per cell (64 points): which groups of 4 height bins occur; K1 -> K2, K4, K6 */
+  uint2 *dTileMasksBase = nullptr;         /* the allocation dTileMasks lies in (kRecordSlackBytes longer than the records: ssd_capi.hip) */
   hipStream_t stream = nullptr;             /* the lane's own stream (depth > 1 only; depth 1 runs on the caller's stream) */
   hipEvent_t in = nullptr;                  /* recorded on the caller's stream at the enqueue: the lane's work starts behind it */
   hipEvent_t done = nullptr;                /* recorded behind the lane's last enqueue */
@@ -42,6 +44,7 @@ struct ssd_lane
 };
 
 constexpr int kMaxLanes = 8;
+constexpr size_t kRecordSlackBytes = 8u << 20;   /* room to place a lane's cell records inside their allocation */
 
 struct ssd_handle
 {
@@ -56,7 +59,8 @@ struct ssd_handle
   int lastLane = 0;               /* the lane of the last enqueue (debug capture, test hooks, riser fetch read it) */
   unsigned long long laneTurn = 0;
   bool lastPinned = false;        /* the last enqueue was held in lane 0 (debug capture, risers, partial stages) */
-  size_t tileMaskStride = 0;
+  size_t tileMaskStride = 0;      /* cell records per frame */
+  size_t recordBytes = 0;         /* one workspace's cell records */
   float *dDepthMaps = nullptr;              /* xmap[W] then ymap[H] (ssd_set_intrinsics) */
   ssd_intrinsics intr{};
   bool haveIntr = false;

@@ -910,9 +910,13 @@ __device__ __forceinline__ unsigned int window_base(const WaveWindow &w)
 {
   return w.slot < 0 ? kNoWindow : pixel_key(w.slot, w.row0, w.col0 << 6);
 }
+/* rows (kWinWords >> winShift) and pixel columns (64 << winShift) of a window are powers of two, so "row offset below the
+ * rows and column offset below the columns" is "d has no bit outside the two offset fields": one AND and one compare with
+ * zero (round 3: two shifts / masks and two compares) */
 __device__ __forceinline__ bool window_hit(unsigned int d, int winShift)
 {
-  return (d >> 13) < (static_cast<unsigned int>(kWinWords) >> winShift) && (d & 0x1fffu) < (64u << winShift);
+  const unsigned int inside = (((static_cast<unsigned int>(kWinWords) >> winShift) - 1u) << 13) | ((64u << winShift) - 1u);
+  return (d & ~inside) == 0u;
 }
 
 /* Before a tile's pixels go out, all 64 lanes; `first` = the lane's lowest pixel_key of this tile (kNoPixel: none).
@@ -1247,8 +1251,14 @@ __device__ LineI wave_best_line(const int *px, const int *py, int m, int lane, b
  * barrier and every per-wave preamble is paid per wave: measured on 1024 XGA frames, K3 takes 0.106 / 0.146 / 0.307 ms with
  * 256 / 512 / 1024 threads, on a single frame 30 / 26.5 / 28 us.  Hence two instantiations: 256 for batches, 512 for a few
  * frames. */
-constexpr int kImgThreadsBatch = 256, kImgThreadsFew = 512;   /* chosen per launch (launch_outline / launch_final) */
-constexpr int kMaxImgWaves = kImgThreadsFew / 64;
+/* (round 4, FHD stress batch of 256 frames, same box, alternating: k_outline with 256 / 512 / 1024 threads per image 0.310 / 0.363 /
+ * 0.438 ms — the batch is bound by the images' total work, which more threads do not shrink; tools/mkvariant.sh with
+ * -DSSD_IMG_THREADS_BATCH=..) */
+#ifndef SSD_IMG_THREADS_BATCH
+#define SSD_IMG_THREADS_BATCH 256
+#endif
+constexpr int kImgThreadsBatch = SSD_IMG_THREADS_BATCH, kImgThreadsFew = 512;   /* chosen per launch (launch_outline / launch_final) */
+constexpr int kMaxImgWaves = (kImgThreadsBatch > kImgThreadsFew ? kImgThreadsBatch : kImgThreadsFew) / 64;
 constexpr int kImgFewFrames = 64;
 constexpr int kMaxCols = SSD_MAX_SCANS;      /* scan columns per image (W/25 + 1 <= 128) */
 constexpr int kMaxProbe = SSD_MAX_EDGE_PTS;  /* probe rows per vertical edge (H/10 + 1 <= 256) */

@@ -179,6 +179,45 @@ long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, 
   return static_cast<long long>(n);
 }
 
+int ssd_test_record_offset(ssd_handle *h, size_t offset_bytes)
+{
+  if(!h || offset_bytes % 8 != 0 || offset_bytes > kRecordSlackBytes)
+    return fail(SSD_E_ARG, "ssd_test_record_offset: bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  h->lane[0].dTileMasks = h->lane[0].dTileMasksBase + offset_bytes / 8;
+  return SSD_OK;
+}
+
+static std::vector<void *> g_recordKeep;
+unsigned long long ssd_test_record_realloc_sized(ssd_handle *h, size_t extra_bytes, size_t offset_bytes);
+unsigned long long ssd_test_record_realloc(ssd_handle *h)
+{
+  return ssd_test_record_realloc_sized(h, 0, 0);
+}
+unsigned long long ssd_test_record_realloc_sized(ssd_handle *h, size_t extra_bytes, size_t offset_bytes)
+{
+  if(!h || offset_bytes % 8 != 0 || offset_bytes > extra_bytes)
+    return 0ull;
+  if(hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+    return 0ull;
+  const size_t bytes = h->recordBytes + kRecordSlackBytes + extra_bytes;
+  void *p = nullptr;
+  if(hipMalloc(&p, bytes) != hipSuccess)
+    return 0ull;
+  g_recordKeep.push_back(h->lane[0].dTileMasksBase);        /* the old one stays allocated: the next hipMalloc cannot reuse its place */
+  h->lane[0].dTileMasksBase = static_cast<uint2 *>(p);
+  h->lane[0].dTileMasks = h->lane[0].dTileMasksBase + offset_bytes / 8;
+  return reinterpret_cast<unsigned long long>(p) + offset_bytes;
+}
+int ssd_test_record_release(void)
+{
+  for(void *p : g_recordKeep)
+    (void)hipFree(p);
+  g_recordKeep.clear();
+  return SSD_OK;
+}
+
 int ssd_test_empty_quadrilateral(ssd_handle *h, int frame, int surface)
 {
   if(!h || frame < 0 || frame >= h->F || surface < -1 || surface >= kMaxPlateaus)

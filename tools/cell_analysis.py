@@ -25,7 +25,7 @@ trans = ssd.transformation_for_scene(sc_list[0])
 cfg = ssd.default_config(W, H)
 ocfg, ocal = ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants)
 A, b = np.array(trans.constants.a).reshape(3, 3), np.array(trans.constants.b)
-acc = {k: 0.0 for k in ("k2_tiles", "k2_cells", "k2_use_tiles", "k2_use_cells", "k4_tiles", "k4_cells", "k4_walked")}
+acc = {k: 0.0 for k in ("k2_tiles", "k2_cells", "k2_use_tiles", "k2_use_cells", "k4_tiles", "k4_cells", "k4_walked", "k4_ground", "k4_tread", "k4_both")}
 for sc in sc_list:
     xyz = ssd.synth_host([sc])[0].reshape(-1, 3)
     res, *_ = oracle.process(ocfg, ocal, xyz)
@@ -74,19 +74,22 @@ for sc in sc_list:
     Y0, Y1 = 0.1 + y0 * (1.2 / 256) - 1e-9, 0.1 + (y1 + 1) * (1.2 / 256) + 1e-9
     grp = np.where(bins >= 0, bins // 4, -1).reshape(nc, 64)
     need = np.zeros(nc, bool)
+    need_g = np.zeros(nc, bool); need_t = np.zeros(nc, bool)
     for i, q in quads.items():
         has = np.zeros(nc, bool)
         for gg in set(bb // 4 for bb in range(128) if lut[bb] == i):
             has |= (grp == gg).any(1)
         xs, ys = np.sort(q[:, 0]), np.sort(q[:, 1])
         if i == g:
-            need |= has & ~((X1 <= xs[0]) | (X0 >= xs[3]) | (Y1 <= ys[0]) | (Y0 >= ys[3]))
+            need_g |= has & ~((X1 <= xs[0]) | (X0 >= xs[3]) | (Y1 <= ys[0]) | (Y0 >= ys[3]))
         else:
-            need |= has & ~((X0 >= xs[1]) & (X1 < xs[2]) & (Y0 >= ys[1]) & (Y1 < ys[2]))
-    acc["k4_walked"] += need.mean()
+            need_t |= has & ~((X0 >= xs[1]) & (X1 < xs[2]) & (Y0 >= ys[1]) & (Y1 < ys[2]))
+    need = need_g | need_t
+    acc["k4_walked"] += need.mean(); acc["k4_ground"] += need_g.mean(); acc["k4_tread"] += need_t.mean(); acc["k4_both"] += (need_g & need_t).mean()
 for k in acc:
     acc[k] /= n
 print("K2: %.0f %% of the wave tiles at %.0f %% lane use  ->  %.0f %% of the cells at %.0f %%" %
       (100 * acc["k2_tiles"], 100 * acc["k2_use_tiles"], 100 * acc["k2_cells"], 100 * acc["k2_use_cells"]))
+print("K4 walked cells: ground %.1f %%, tread %.1f %% (constant cell only; the edge test removes more), both %.1f %%" % (100 * acc["k4_ground"], 100 * acc["k4_tread"], 100 * acc["k4_both"]))
 print("K4: %.0f %% of the wave tiles  ->  %.0f %% of the cells  ->  %.0f %% with the boxes" %
       (100 * acc["k4_tiles"], 100 * acc["k4_cells"], 100 * acc["k4_walked"]))
