@@ -369,6 +369,27 @@ def main():
                                   "source": "profiles/pmc_pipeline.json (PMC passes of this command, committed; not re-measured in this run)"}
             except Exception:
                 pipeline_moved = None
+        # The two-sided floor of the whole pass, from the committed counters of this command (profiles/pmc_issue.json: vector
+        # instructions per launch and kernel; profiles/pmc_pipeline.json: HBM bytes): every vector instruction occupies one of the
+        # chip's 1024 SIMDs for 4 cycles (tools/instr_rate.hip: fp64, conversions, compares, integer ops alike), every byte
+        # crosses HBM at the plain stream's rate at best.  The pass cannot be shorter than either; how far above both it is says
+        # what the overlap of the kernels leaves on the table.
+        floors = None
+        pi = os.path.join(ROOT, "profiles", "pmc_issue.json")
+        if os.path.exists(pi) and pipeline_moved is not None:
+            try:
+                kernels = json.load(open(pi))["kernels"]
+                valu = sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in kernels.items() if "k_stream_read" not in k and "synth" not in k)
+                simds, clock_hz = 1024, 2.4e9
+                floors = {"valu_instructions_per_launch": valu, "valu_floor_ms": valu * 4.0 / (simds * clock_hz) * 1e3,
+                          "hbm_floor_ms": None if plain_ms is None else (pipeline_moved["hbm_read_bytes"] + pipeline_moved["hbm_write_bytes"]) / (alg_bytes / plain_ms),
+                          "hbm_floor_ms_at_peak": (pipeline_moved["hbm_read_bytes"] + pipeline_moved["hbm_write_bytes"]) / (HBM_PEAK_GBS * 1e9) * 1e3,
+                          "measured_ms": dt_max / args.steps * 1e3,
+                          "note": "valu floor = vector instructions x 4 cycles / (1024 SIMDs x 2.4 GHz); hbm floor = HBM bytes of the pass / "
+                                  "the plain read stream's rate measured in this run; counters: profiles/pmc_issue.json, profiles/pmc_pipeline.json "
+                                  "(committed rocprofv3 --pmc passes of this command, not re-measured here)"}
+            except Exception:
+                floors = None
         out = {
             "metric": METRIC_FHD if fhd else METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
@@ -390,6 +411,7 @@ def main():
                          "k1_over_plain_stream": None if plain_ms is None or k1_ms <= 0 else plain_ms / k1_ms,
                          "plain_stream_note": "ssd_test_stream_read (tools/loadbench.hip variant C: 16-byte loads, wave-contiguous) over the "
                                               "same buffer, 5 launches before and 5 after the separate timed steps"},
+            "floors": floors,
             "stage_ms": stage,
             "stage_ms_source": "separate timed steps: %d extra passes after the timed region, one batch at a time (enqueue, fetch), HIP events "
                                "between the launches on the kernels' stream; the timed region itself keeps %d batches in flight" % (n_extra, depth),
@@ -398,6 +420,10 @@ def main():
             "pipeline_bytes_moved": pipeline_moved,
             "pipeline_bytes_algorithmic_frac_of_peak": (alg_bytes * args.steps / dt_max / 1e9) / HBM_PEAK_GBS,
         }
+        if floors is not None:           # the whole pass's floors beside the dominant kernel's roofline
+            out["roofline"]["valu_floor_ms"] = floors["valu_floor_ms"]
+            out["roofline"]["hbm_floor_ms"] = floors["hbm_floor_ms"]
+            out["roofline"]["pass_ms"] = floors["measured_ms"]
         out["devices"] = [sh["where"] for sh in shards]
         out["distinct_devices"] = distinct_devices(out["devices"])
         if world > 1:

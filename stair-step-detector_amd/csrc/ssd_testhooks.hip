@@ -208,6 +208,16 @@ unsigned long long ssd_test_record_realloc_sized(ssd_handle *h, size_t extra_byt
   g_recordKeep.push_back(h->lane[0].dTileMasksBase);        /* the old one stays allocated: the next hipMalloc cannot reuse its place */
   h->lane[0].dTileMasksBase = static_cast<uint2 *>(p);
   h->lane[0].dTileMasks = h->lane[0].dTileMasksBase + offset_bytes / 8;
+  /* the other workspaces of the handle likewise (plain allocations) */
+  for(int k = 1; k < h->depth; k++)
+  {
+    void *q = nullptr;
+    if(hipMalloc(&q, h->recordBytes + kRecordSlackBytes) != hipSuccess)
+      return 0ull;
+    g_recordKeep.push_back(h->lane[k].dTileMasksBase);
+    h->lane[k].dTileMasksBase = static_cast<uint2 *>(q);
+    h->lane[k].dTileMasks = h->lane[k].dTileMasksBase;
+  }
   return reinterpret_cast<unsigned long long>(p) + offset_bytes;
 }
 int ssd_test_record_release(void)

@@ -108,9 +108,11 @@ def main():
             for k in per:
                 for c, v in per[k].items():
                     agg[k][c] = round(sum(v) / len(v), 3)
-        json.dump({"note": "rocprofv3 --kernel-trace --pmc <set> -- python3 bench.py --steps 2 --warmup 1 --no-cpu (one pass per counter set, "
-                           "tools/pmc.sh); per launch = 1024 XGA frames", "kernels": {k: dict(sorted(v.items())) for k, v in sorted(agg.items())}},
-                  open(os.path.join(dst, tag + "_pmc_issue.json"), "w"), indent=1)
+        issue = {"note": "rocprofv3 --kernel-trace --pmc <set> -- python3 bench.py --steps 2 --warmup 1 --no-cpu (one pass per counter set, "
+                         "tools/pmc.sh); per launch = 1024 XGA frames", "kernels": {k: dict(sorted(v.items())) for k, v in sorted(agg.items())}}
+        json.dump(issue, open(os.path.join(dst, tag + "_pmc_issue.json"), "w"), indent=1)
+        issue["source"] = "profiles/%s_pmc_issue.json" % tag
+        json.dump(issue, open(os.path.join(dst, "pmc_issue.json"), "w"), indent=1)      # what bench.py reads for `floors`
     print(open(os.path.join(dst, tag + "_hbm_traffic.json")).read()[:1500])
 
 
