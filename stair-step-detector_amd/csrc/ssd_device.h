@@ -25,6 +25,7 @@ constexpr int kGroundAcc = kMaxPlateaus;          /* accumulator slot of the gro
 constexpr int kMaxRisers = SSD_MAX_RISERS;
 constexpr int kMaxLive = kMaxStepImages + 1;      /* quadrilaterals a frame can have points tested against: one per step image + the ground */
 constexpr int kZFixShift = 40;                    /* mean z accumulates round(z * 2^40) in int64 */
+constexpr int kMaxGroundStrips = 168;              /* pixel strips of the ground image the bottom scan reads: one per 50 columns (+ 2), width <= 8192 */
 
 /* the four horizontal edges of a plateau outline, in this order everywhere (segmentation.cpp:585-589) */
 enum { kFL = 0, kFR = 1, kBL = 2, kBR = 3 };
@@ -175,6 +176,9 @@ struct FrameState
   long long sumZ[kMaxPlateaus + 1];
   unsigned int cnt[kMaxPlateaus + 1];
   long long totZ[kMaxStepImages];
+  /* k_inquad's strip raster: per strip, the bottom-most row (largest) in which a ground point fell on the strip's CENTRE column
+   * so far (-1: none; k_quads resets it) - pixels more than two rows above it cannot reach k_final's bottom scan */
+  int groundStripMax[kMaxGroundStrips];
   /* vertical faces (extension): written by k_final, accumulated by k_risers */
   int nRisers;
   unsigned int wantedRisers;

@@ -1848,6 +1848,8 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
     fs.sumZ[lane] = 0;
     fs.cnt[lane] = 0;
   }
+  for(int i = lane; i < kMaxGroundStrips; i += 64)
+    fs.groundStripMax[i] = -1;
   const int first = fs.firstStep, last = fs.firstStep + fs.nStepImages;
   const int groundInd = fs.groundInd;
   const bool mine = lane >= first && lane < last && lane < kMaxPlateaus;
@@ -2007,6 +2009,17 @@ __device__ __forceinline__ bool ground_strip_column(int ix, int x0)
   const unsigned int r = u - kGroundScanStep * strip_div50(u);
   return r <= 4u;
 }
+/* the same with the strip's number (0 = the strip left of the first scan column; below kMaxGroundStrips for any width up to
+ * 8192) and whether ix is the strip's CENTRE column, i.e. a scan column itself */
+__device__ __forceinline__ bool ground_strip_of(int ix, int x0, int &strip, bool &centre)
+{
+  const unsigned int u = static_cast<unsigned int>(ix + 2 - x0 + kGroundScanStep);
+  const unsigned int q = strip_div50(u), r = u - kGroundScanStep * q;
+  strip = static_cast<int>(q);
+  centre = r == 2u;
+  return r <= 4u;
+}
+static_assert((8191 + 2 + kGroundScanStep) / kGroundScanStep < kMaxGroundStrips, "a strip number for every pixel column");
 
 template<bool FULL>
 struct InquadLds
@@ -2027,6 +2040,7 @@ struct InquadLds
   unsigned char liveAcc[kMaxLive];
   int nLive, groundSlot;
   int nextGroup;                                /* the walk's groups of four cells are dealt out to the waves as they come free */
+  int stripMax[kMaxGroundStrips];               /* FrameState::groundStripMax as the block found it, raised by its own centre-column pixels */
 };
 
 template<int SRC, bool FULL>
@@ -2061,6 +2075,7 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
   const unsigned char lutMine = tid < kMaxBins ? fs.lutLive[tid] : static_cast<unsigned char>(0xff);
   const unsigned char accMine = tid < kMaxLive ? fs.liveAcc[tid] : static_cast<unsigned char>(0);
   const unsigned int groupsMine = tid < kMaxLive ? fs.liveGroups[tid] : 0u;
+  const int stripMaxMine = (!FULL && tid < kMaxGroundStrips) ? fs.groundStripMax[tid] : -1;
   const int4 boxMine = tid < kMaxLive ? fs.liveBox[tid] : make_int4(0, 0, 0, 0);
   const int nLiveG = fs.nLive;
   const unsigned char groundActive = fs.accActive[kGroundAcc];
@@ -2092,6 +2107,8 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
   }
   if(tid < kMaxBins)
     lut[tid] = lutMine;                         /* bin -> slot of the live table, 0xff = nothing to do for this bin */
+  if(!FULL && tid < kMaxGroundStrips)
+    L.stripMax[tid] = stripMaxMine;
   if(tid < kMaxLive)
   {
     liveAcc[tid] = accMine;
@@ -2251,12 +2268,27 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
         oob += inside ? 0u : 1u;                              /* quirk Q5 */
         if(FULL)
           key[j] = inside ? pixel_key(0, iy, ix) : kNoPixel;
-        else if(inside && iy >= stripRow0 && ground_strip_column(ix, stripX0))
+        else if(inside && iy >= stripRow0)
         {
-          /* one of the few pixels the bottom scan can see: straight to memory */
-          atomicOr(gimg32 + (static_cast<unsigned int>(iy) * (2u * X.W64) + (static_cast<unsigned int>(ix) >> 5)), 1u << (ix & 31));
-          gy0 = min(gy0, iy);
-          gy1 = max(gy1, iy);
+          int strip;
+          bool centre;
+          if(ground_strip_of(ix, stripX0, strip, centre))
+          {
+            /* One of the few pixels the bottom scan can see.  It looks, per scan column, for the BOTTOM-most lit pixel of the
+             * closed image, which lies at or below the bottom-most raw pixel of the column itself (closing only adds) and is a
+             * function of the raw rows within two of it: a pixel more than two rows above a centre-column pixel already seen
+             * in its strip cannot matter and stays unwritten (round 4: the blocks run from the bottom of the camera image up,
+             * so after a frame's first blocks nearly nothing is written: 4.5 k -> a few hundred global atomics per frame). */
+            const int seen = L.stripMax[strip];
+            if(iy >= seen - 2)
+            {
+              atomicOr(gimg32 + (static_cast<unsigned int>(iy) * (2u * X.W64) + (static_cast<unsigned int>(ix) >> 5)), 1u << (ix & 31));
+              gy0 = min(gy0, iy);
+              gy1 = max(gy1, iy);
+              if(centre && iy > seen)
+                atomicMax(&L.stripMax[strip], iy);
+            }
+          }
         }
       }
     }
@@ -2291,6 +2323,8 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
   if(oob)
     atomicAdd(&lOob, oob);
   __syncthreads();
+  if(!FULL && tid < kMaxGroundStrips && L.stripMax[tid] > stripMaxMine)
+    atomicMax(&fs.groundStripMax[tid], L.stripMax[tid]);       /* for the frame's blocks still to come */
   ph.mark(3);                                               /* waiting for the block's other waves */
   if(tid < nLive)
   {
@@ -2332,7 +2366,8 @@ __global__ __launch_bounds__(kThreads, SSD_K4_WAVES) void k_inquad(const float *
                                                         const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
   __shared__ InquadLds<FULL> L;
-  inquad_block<SRC, FULL>(L, xyz, strideFloats, P, X, st, groundImg, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
+  /* chunks from the bottom of the camera image up: the ground nearest to the camera comes first (see the strip raster) */
+  inquad_block<SRC, FULL>(L, xyz, strideFloats, P, X, st, groundImg, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, static_cast<int>(gridDim.y - 1u - blockIdx.y));
 }
 
 /* ========================================================================= */

@@ -51,9 +51,11 @@ def test_frame_results_without_debug_capture(ssd, oracle, gpu_device, name):
 def test_ground_raster_is_the_strips_the_bottom_scan_reads(ssd, oracle, gpu_device, name):
     """Outside image capture k_inquad sets, of the ground points inside the ground quadrilateral (pointcloud.cpp:530-531), only the
     pixels detectFrontEdge can see: the columns within two of a scan column W/2 + 50 k (BottomScanner, segmentation.cpp:159-241;
-    the closing reaches two pixels) and the rows from H/2 - 1 down.  The workspace image after ssd_enqueue_stages(.. INQUAD) must
-    be exactly the oracle's raw ground image restricted to those pixels; with image capture on it must be the whole image; and
-    after a full run it must be zero again (k_final clears what k_inquad set)."""
+    the closing reaches two pixels) and the rows from H/2 - 1 down — and of those (round 4) only what the scan's bottom-most lit
+    pixel can depend on: per strip, the rows from two above the bottom-most pixel of the strip's CENTRE column down (which pixels
+    above that line are written is a matter of the blocks' timing).  The workspace image after ssd_enqueue_stages(.. INQUAD) must
+    lie inside the oracle's raw ground image restricted to the strips and contain all of it from that line down; with image capture
+    on it must be the whole image; and after a full run it must be zero again (k_final clears what k_inquad set)."""
     sc, trans, cfg = _setup(ssd, name)
     W, H = sc.width, sc.height
     xyz = ssd.synth_host([sc])[0]
@@ -71,8 +73,18 @@ def test_ground_raster_is_the_strips_the_bottom_scan_reads(ssd, oracle, gpu_devi
     det.enqueue(buf.ptr, 1, stages=upto_inquad)
     got = det.ground_image_raw(0)
     want = np.where(mask, graw, 0).astype(np.uint8)
-    assert np.array_equal(got, want), "%d pixels differ" % int((got != want).sum())
-    assert 0 < int((want != 0).sum()) < int((graw != 0).sum()) // 4
+    assert not (got & ~want).any(), "%d pixels set that are not ground pixels of a strip" % int(((got != 0) & (want == 0)).sum())
+    must = np.zeros((H, W), dtype=bool)                     # what the bottom scan can depend on
+    for xj in range(x0 - 50, W + 50, 50):
+        cols = [c for c in range(xj - 2, xj + 3) if 0 <= c < W]
+        if not cols:
+            continue
+        centre = np.nonzero(want[:, xj])[0] if 0 <= xj < W else np.array([], dtype=int)
+        first = max(int(centre.max()) - 2, 0) if centre.size else 0          # no centre pixel: nothing may be left out
+        must[first:, cols] = True
+    missing = (want != 0) & must & (got == 0)
+    assert not missing.any(), "%d pixels the bottom scan can depend on are missing" % int(missing.sum())
+    assert 0 < int((got != 0).sum()) <= int((want != 0).sum()) < int((graw != 0).sum()) // 4
     det.enqueue(buf.ptr, 1)                                   # the partial run left bits behind: the library clears them first
     fr = det.fetch_list(1)[0]
     assert not det.ground_image_raw(0).any()
