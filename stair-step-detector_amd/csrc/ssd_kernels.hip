@@ -2366,8 +2366,12 @@ __global__ __launch_bounds__(kThreads, SSD_K4_WAVES) void k_inquad(const float *
                                                         const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
   __shared__ InquadLds<FULL> L;
-  /* chunks from the bottom of the camera image up: the ground nearest to the camera comes first (see the strip raster) */
-  inquad_block<SRC, FULL>(L, xyz, strideFloats, P, X, st, groundImg, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, static_cast<int>(gridDim.y - 1u - blockIdx.y));
+  /* The chunks at the bottom of the camera image first (an eighth of them, bottom-most first): the ground nearest to the camera,
+   * whose pixels decide what the strip raster may leave out (see there); then the others top-down as ever.  (All chunks
+   * bottom-up: XGA 0.79 -> 0.73 ms like this order, FHD stress 0.55 -> 0.59 — its eight treads, the heavy blocks, came last.) */
+  const int nChunks = static_cast<int>(gridDim.y), first = max(1, nChunks / 8), by = static_cast<int>(blockIdx.y);
+  const int chunkIdx = by < first ? nChunks - 1 - by : by - first;
+  inquad_block<SRC, FULL>(L, xyz, strideFloats, P, X, st, groundImg, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, chunkIdx);
 }
 
 /* ========================================================================= */
