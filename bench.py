@@ -205,6 +205,8 @@ def main():
                     help="workspaces of the handle (ssd_config::batches_in_flight), asked for explicitly: 3 = SSD_BATCHES_IN_FLIGHT_THROUGHPUT "
                          "(the bench enqueues ahead of its fetches); 1 (or 0, the library's default) = strictly one batch at a time in stream "
                          "order — what the profiling passes use, so that a kernel's traced duration is its own")
+    ap.add_argument("--prewarm-seconds", type=float, default=0.5,
+                    help="untimed load in front of the W warm-up steps (an idle device needs more than a few steps to reach its clocks)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-hostfed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg reported beside `value`")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (profiling passes: its 56 one-frame "
@@ -286,6 +288,16 @@ def main():
         for back in range(min(ahead, n_steps) - 1, -1, -1):
             res = det.fetch(F, back=back)
         return res
+
+    # Before the W warm-up steps of the contract: load until the device has been busy for a while.  The first process on an idle
+    # box measured 227 k frames/s over its 10 timed steps (34 ms) after 2 warm-up steps, the same command seconds later 291-300 k
+    # (profiles/r04_cold_start.txt): clocks and memory ramp up over more than a few milliseconds.  Untimed; reported as `prewarm`.
+    c0 = time.perf_counter()
+    prewarm_steps = 0
+    while time.perf_counter() - c0 < args.prewarm_seconds:
+        run(4)
+        prewarm_steps += 4
+    prewarm = {"seconds": time.perf_counter() - c0, "steps": prewarm_steps}
 
     res = run(args.warmup)
 
@@ -412,6 +424,7 @@ def main():
                          "plain_stream_note": "ssd_test_stream_read (tools/loadbench.hip variant C: 16-byte loads, wave-contiguous) over the "
                                               "same buffer, 5 launches before and 5 after the separate timed steps"},
             "floors": floors,
+            "prewarm": prewarm,
             "stage_ms": stage,
             "stage_ms_source": "separate timed steps: %d extra passes after the timed region, one batch at a time (enqueue, fetch), HIP events "
                                "between the launches on the kernels' stream; the timed region itself keeps %d batches in flight" % (n_extra, depth),
