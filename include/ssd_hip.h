@@ -330,7 +330,9 @@ int ssd_get_debug(ssd_handle *h, int frame, ssd_debug_frame *out);
  * Only valid when capture with images (ssd_set_debug(h, 1)) was on for the batch. */
 int ssd_get_debug_image(ssd_handle *h, int frame, int step_slot, int closed, uint8_t *out);
 
-/* pinned (page-locked) host memory for frames handed to ssd_process_host / ssd_process_depth_host */
+/* pinned (page-locked) host memory for frames handed to ssd_process_host / ssd_process_depth_host.  hipHostMalloc places it on the
+ * NUMA node nearest to the calling thread's current device (the runtime's default policy), so on a two-socket node allocate it from
+ * the thread that feeds that GPU, after ssd_bind_thread_to_device. */
 int ssd_host_alloc(size_t bytes, void **ptr);
 int ssd_host_free(void *ptr);
 
