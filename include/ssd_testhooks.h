@@ -47,8 +47,9 @@ long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, 
  * points outside = all of the plateau's, their sum = the plateau's total).  Between ssd_enqueue_stages(.. up to SSD_STAGE_INQUAD)
  * and ssd_enqueue_stages(SSD_STAGE_FINAL): the case calcAverageZ divides 0.0 by 0 in (pointcloud.cpp:574-581). */
 int ssd_test_empty_quadrilateral(ssd_handle *h, int frame, int surface);
-/* tools hook (tools/k1place.py): places the first workspace's cell records `offset_bytes` (a multiple of 8, below the slack
- * of the allocation) into their allocation; the records' content is undefined afterwards until the next full enqueue */
+/* tools hook (tools/k1place.py): places the first workspace's cell records `offset_bytes` (a multiple of 8, within the extra bytes a
+ * preceding ssd_test_record_realloc_sized asked for) into their allocation; the records' content is undefined afterwards until the
+ * next full enqueue */
 int ssd_test_record_offset(ssd_handle *h, size_t offset_bytes);
 /* tools hook (tools/k1place.py): gives the first workspace a NEWLY allocated array for its cell records (the previous ones stay
  * allocated until ssd_test_record_release, so that every call lands somewhere else); returns the device address */

@@ -436,7 +436,7 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
     HIP_TRY_H(hipMalloc(&L.dState, sizeof(FrameState) * h->F));
     HIP_TRY_H(hipMalloc(&L.dStepImg, stepBytes));
     HIP_TRY_H(hipMalloc(&L.dGroundImg, groundBytes));
-    HIP_TRY_H(hipMalloc(&L.dTileMasksBase, maskBytes + kRecordSlackBytes));
+    HIP_TRY_H(hipMalloc(&L.dTileMasksBase, maskBytes));
     L.dTileMasks = L.dTileMasksBase;
     HIP_TRY_H(hipEventCreateWithFlags(&L.in, hipEventDisableTiming));
     HIP_TRY_H(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));

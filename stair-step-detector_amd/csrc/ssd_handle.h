@@ -33,7 +33,8 @@ struct ssd_lane
   unsigned long long *dStepImg = nullptr;
   unsigned long long *dGroundImg = nullptr;
   uint2 *dTileMasks = nullptr;             /* per cell (64 points): which groups of 4 height bins occur; K1 -> K2, K4, K6 */
-  uint2 *dTileMasksBase = nullptr;         /* the allocation dTileMasks lies in (kRecordSlackBytes longer than the records: ssd_capi.hip) */
+  uint2 *dTileMasksBase = nullptr;         /* the allocation dTileMasks lies in (the tools' placement hooks put the records elsewhere in a larger one) */
+  size_t recordSlack = 0;                   /* bytes of that allocation beyond the records (0 unless a tools hook allocated it) */
   hipStream_t stream = nullptr;             /* the lane's own stream (depth > 1 only; depth 1 runs on the caller's stream) */
   hipEvent_t in = nullptr;                  /* recorded on the caller's stream at the enqueue: the lane's work starts behind it */
   hipEvent_t done = nullptr;                /* recorded behind the lane's last enqueue */
@@ -44,7 +45,6 @@ struct ssd_lane
 };
 
 constexpr int kMaxLanes = 8;
-constexpr size_t kRecordSlackBytes = 8u << 20;   /* room to place a lane's cell records inside their allocation */
 
 struct ssd_handle
 {

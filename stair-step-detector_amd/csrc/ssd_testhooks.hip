@@ -181,8 +181,8 @@ long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, 
 
 int ssd_test_record_offset(ssd_handle *h, size_t offset_bytes)
 {
-  if(!h || offset_bytes % 8 != 0 || offset_bytes > kRecordSlackBytes)
-    return fail(SSD_E_ARG, "ssd_test_record_offset: bad argument");
+  if(!h || offset_bytes % 8 != 0 || offset_bytes > h->lane[0].recordSlack)
+    return fail(SSD_E_ARG, "ssd_test_record_offset: bad argument (the offset must lie within the extra bytes of ssd_test_record_realloc_sized)");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
   h->lane[0].dTileMasks = h->lane[0].dTileMasksBase + offset_bytes / 8;
@@ -201,18 +201,19 @@ unsigned long long ssd_test_record_realloc_sized(ssd_handle *h, size_t extra_byt
     return 0ull;
   if(hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
     return 0ull;
-  const size_t bytes = h->recordBytes + kRecordSlackBytes + extra_bytes;
+  const size_t bytes = h->recordBytes + extra_bytes;
   void *p = nullptr;
   if(hipMalloc(&p, bytes) != hipSuccess)
     return 0ull;
   g_recordKeep.push_back(h->lane[0].dTileMasksBase);        /* the old one stays allocated: the next hipMalloc cannot reuse its place */
   h->lane[0].dTileMasksBase = static_cast<uint2 *>(p);
+  h->lane[0].recordSlack = extra_bytes;
   h->lane[0].dTileMasks = h->lane[0].dTileMasksBase + offset_bytes / 8;
   /* the other workspaces of the handle likewise (plain allocations) */
   for(int k = 1; k < h->depth; k++)
   {
     void *q = nullptr;
-    if(hipMalloc(&q, h->recordBytes + kRecordSlackBytes) != hipSuccess)
+    if(hipMalloc(&q, h->recordBytes) != hipSuccess)
       return 0ull;
     g_recordKeep.push_back(h->lane[k].dTileMasksBase);
     h->lane[k].dTileMasksBase = static_cast<uint2 *>(q);

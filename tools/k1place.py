@@ -14,6 +14,7 @@ for b in range(2):
     ssd.synth_device(sc, buf.ptr, device=0)
     det = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=F, batches_in_flight=1), trans, 0)
     det.set_timing(True)
+    det.record_realloc(max(offsets), 0)                   # an allocation with room for the largest offset
     for rnd in range(2):
         row = []
         for off in offsets:
