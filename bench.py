@@ -89,22 +89,20 @@ def device_for_rank(local_rank, n_devices, environ=None):
     return dev
 
 
-_AFFINITY_AT_START = None      # the process's CPUs before bind_rank_to_device narrowed them (the all-cores CPU baseline uses them all)
+_AFFINITY_AT_START = None      # the main thread's CPUs before bind_rank_to_device narrowed them (the all-cores CPU baseline uses them all)
 
 
-def bind_rank_to_device(ssd, device, set_affinity=None):
-    """This process onto the CPUs next to its GPU (the NUMA node the device hangs off), and the device's identity for the report.
-    The library maps HIP device -> PCI bus id -> /sys/bus/pci/devices/<id>/{numa_node,local_cpulist}; the PROCESS affinity is
-    then set to what the calling thread was given, so that threads started later (torch, the HIP runtime's, the oracle pool)
-    stay on that socket.  Where the platform names no local CPUs (numa_node -1, single-socket boxes, containers that hide
+def bind_rank_to_device(ssd, device):
+    """This rank onto the CPUs next to its GPU (the NUMA node the device hangs off), and the device's identity for the report.
+    The library maps HIP device -> PCI bus id -> /sys/bus/pci/devices/<id>/{numa_node,local_cpulist} and binds the CALLING
+    thread — the rank's main thread, which every thread it starts afterwards inherits from (torch's, the oracle pool's, the HIP
+    runtime's later ones).  Where the platform names no local CPUs (numa_node -1, single-socket boxes, containers that hide
     sysfs) the affinity is left alone and the report says so."""
     global _AFFINITY_AT_START
     info = ssd.device_info(device)
     _AFFINITY_AT_START = os.sched_getaffinity(0)
     before = len(_AFFINITY_AT_START)
     bound = ssd.bind_thread_to_device(device)
-    if bound > 0:
-        (set_affinity or os.sched_setaffinity)(0, os.sched_getaffinity(0))      # the thread's new mask for the whole process
     info.update({"device": device, "cpus_before": before, "cpus_bound": bound, "bound": bound > 0})
     return info
 

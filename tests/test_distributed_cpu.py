@@ -90,8 +90,9 @@ def _worker8(rank, world, port, total_frames, q):
 
 
 def test_a_rank_binds_itself_next_to_its_gpu():
-    """bench.bind_rank_to_device: the library binds the calling thread (ssd_bind_thread_to_device), the process mask follows;
-    where the platform names no local CPUs nothing is touched.  The library is played by a stand-in (no GPU here)."""
+    """bench.bind_rank_to_device: the library binds the calling thread (ssd_bind_thread_to_device: threads started afterwards
+    inherit its mask), bench reports what happened and remembers the mask it started with (the all-cores CPU baseline restores
+    it).  The library is played by a stand-in (no GPU here)."""
     import bench
 
     class FakeSsd:
@@ -104,13 +105,13 @@ def test_a_rank_binds_itself_next_to_its_gpu():
         def bind_thread_to_device(self, device):
             return self.bound
 
-    calls = []
-    info = bench.bind_rank_to_device(FakeSsd(64), 3, set_affinity=lambda pid, cpus: calls.append((pid, set(cpus))))
+    before = os.sched_getaffinity(0)
+    info = bench.bind_rank_to_device(FakeSsd(64), 3)
     assert info["device"] == 3 and info["bound"] and info["cpus_bound"] == 64 and info["pci_bus_id"] == "0000:c5:00.0"
-    assert calls == [(0, set(os.sched_getaffinity(0)))]
-    calls.clear()
-    info = bench.bind_rank_to_device(FakeSsd(0), 0, set_affinity=lambda pid, cpus: calls.append(1))
-    assert not info["bound"] and calls == []
+    assert info["cpus_before"] == len(before) and bench._AFFINITY_AT_START == before
+    info = bench.bind_rank_to_device(FakeSsd(0), 0)
+    assert not info["bound"] and info["cpus_bound"] == 0
+    assert os.sched_getaffinity(0) == before              # the stand-in binds nothing; bench itself never touches the mask
 
 
 def test_shard_covers_everything_for_any_world():
