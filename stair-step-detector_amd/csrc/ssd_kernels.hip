@@ -2431,6 +2431,10 @@ __global__ __launch_bounds__(T) void k_final(Params P, FrameState *__restrict__ 
     S.yEdge[j] = -1;
   if(tid == 0)
     S.n = 0;
+  /* k_inquad's record of the strips' bottom-most centre pixels has served (this frame's strip raster is complete): left at
+   * "none" for whichever k_inquad comes next, also one of a partial run that k_quads — its other resetter — does not precede */
+  for(int j = tid; j < kMaxGroundStrips; j += T)
+    fs.groundStripMax[j] = -1;
   __syncthreads();
 
   if(haveGround)
