@@ -263,6 +263,41 @@ def test_depth_input_parity_all_intermediates(ssd, oracle, gpu_device, name):
     assert rep.get("max_height_err", 0.0) <= parity.TOL_HEIGHT
 
 
+def test_new_intrinsics_wait_for_the_depth_batches_in_flight(ssd, gpu_device):
+    """ssd_set_intrinsics rewrites the deprojection maps the kernels of depth batches read; with several
+    workspaces those batches run on streams of the handle's own, which a copy on the default stream does not wait for.  Three
+    batches enqueued, other intrinsics set at once, then the fetches: every batch must be what the FIRST intrinsics give (the
+    call waits for the lanes), and a batch after the call what the SECOND give."""
+    import ctypes as C
+    n, W, H = 48, 640, 480
+    sc_list = scenes.batch_scenes(ssd, W, H, n, base_seed=654, rng_seed=2)
+    trans = ssd.transformation_for_scene(sc_list[0])
+    intr = ssd.intrinsics_for_scene(sc_list[0])
+    other = ssd.Intrinsics(intr.fx * 1.25, intr.fy * 0.8, intr.ppx + 7.0, intr.ppy - 5.0, intr.depth_units)
+    buf = ssd.DeviceBuffer(n * W * H * 2, gpu_device)
+    ssd.synth_depth_device(sc_list, buf.ptr, device=gpu_device)
+    one = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=n), trans, gpu_device)
+    want = {}
+    for key, it in (("first", intr), ("second", other)):
+        one.set_intrinsics(it)
+        one.enqueue_depth(buf.ptr, n)
+        want[key] = [bytes(x) for x in one.fetch_list(n)]
+    one.close()
+    assert want["first"] != want["second"]
+    det = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=n, batches_in_flight=3), trans, gpu_device)
+    for rep in range(3):
+        det.set_intrinsics(intr)
+        for _ in range(3):
+            det.enqueue_depth(buf.ptr, n)
+        det.set_intrinsics(other)                      # while the three batches are still running
+        got = [[bytes(x) for x in det.fetch(n, back=b)] for b in (2, 1, 0)]
+        assert all(g == want["first"] for g in got), "a batch in flight saw the new maps (round %d)" % rep
+        det.enqueue_depth(buf.ptr, n)
+        assert [bytes(x) for x in det.fetch_list(n)] == want["second"]
+    det.close()
+    buf.free()
+
+
 def test_depth_path_equals_float_path_on_the_deprojected_cloud(ssd, gpu_device):
     """Same handle, same frames: depth input (device-generated, in HBM) and float input (host-deprojected) give bitwise equal results."""
     sc_list = scenes.batch_scenes(ssd, 640, 480, 6, base_seed=321)
