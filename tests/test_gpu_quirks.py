@@ -182,6 +182,15 @@ def test_resolutions_off_the_beaten_path(ssd, oracle, gpu_device, res):
         res3 = det.process_host(three)
         assert bytes(res3[0]) == bytes(res3[2]) and res3[1].n_steps == 0
         parity.check_results_only(ssd, oracle, cfg, trans.constants, xyz, res3[0])
+        if W % 4 == 0:
+            # the same scene as 16-bit depth (round 4: the row of a pixel by a multiply-high above 128 columns, by a division
+            # below; the x-map as one 16-byte load): results = the oracle's on the deprojected frame
+            intr = ssd.intrinsics_for_scene(sc)
+            depth = ssd.synth_depth_host([sc])[0]
+            det.set_intrinsics(intr)
+            got = det.process_depth_host(np.stack([depth, depth]))
+            assert bytes(got[0]) == bytes(got[1])
+            parity.check_results_only(ssd, oracle, cfg, trans.constants, oracle.deproject(intr, depth), got[0])
         det.close()
 
 
