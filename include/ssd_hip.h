@@ -44,6 +44,7 @@ extern "C" {
 #define SSD_MAX_PLATEAUS 32       /* filtered histogram peaks per frame */
 #define SSD_MAX_STEP_IMAGES 16    /* plateaus at or above minHeight per frame (each owns a bit image) */
 #define SSD_MAX_STEPS (SSD_MAX_STEP_IMAGES + 1)
+#define SSD_MAX_PLANES 24         /* single-pass batches: bit images of candidate height bins per frame (workspace size) */
 #define SSD_MAX_SCANS 128
 #define SSD_MAX_EDGE_PTS 256
 #define SSD_LINE_CAP 4096

@@ -47,6 +47,18 @@ long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, 
  * points outside = all of the plateau's, their sum = the plateau's total).  Between ssd_enqueue_stages(.. up to SSD_STAGE_INQUAD)
  * and ssd_enqueue_stages(SSD_STAGE_FINAL): the case calcAverageZ divides 0.0 by 0 in (pointcloud.cpp:574-581). */
 int ssd_test_empty_quadrilateral(ssd_handle *h, int frame, int surface);
+/* The single pass (K1 rasters the step plateaus itself into planes of predicted height bins).  mode: -1 = as
+ * the product decides (whole pipeline, a batch of >= 64 frames, a tile a whole number of camera rows), 0 = never, 1 = whenever the
+ * geometry allows (a handle without planes gets them).  sabotage: 0 = none, 1 = the predictor's planes three bins above the right
+ * ones, 2 = no planes at all - either way every frame with steps must come out through k_raster, bit-equal. */
+int ssd_test_single_pass(ssd_handle *h, int mode, int sabotage);
+/* of the last enqueue (synchronises): returns 1 when it ran the single pass, else 0 (counts zero); counts[0] = frames whose step
+ * plateaus the planes covered (k_raster skipped them), [1] = frames with step plateaus, [2] = planes over all frames,
+ * [3] = 64-bit words of the lane's plane images that are not zero (the invariant between batches: 0) */
+int ssd_test_single_pass_stats(ssd_handle *h, int frames, long long counts[4]);
+/* one frame of the last enqueue: the predictor's table (height bin -> plane, 0xff = none; SSD_MAX_BINS entries),
+ * info[0] = planes, info[1] = 1 when they covered the frame's step plateaus, info[2] = step plateaus */
+int ssd_test_single_pass_frame(ssd_handle *h, int frame, uint8_t *plane_of_bin, int info[3]);
 /* tools hook (tools/k1place.py): places the first workspace's cell records `offset_bytes` (a multiple of 8, within the extra bytes a
  * preceding ssd_test_record_realloc_sized asked for) into their allocation; the records' content is undefined afterwards until the
  * next full enqueue */

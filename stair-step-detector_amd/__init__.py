@@ -25,6 +25,7 @@ LIB_PATH = os.environ.get("SSD_HIP_LIB") or os.path.join(_HERE, "lib", "libssd_h
 MAX_BINS = 128
 MAX_PLATEAUS = 32
 MAX_STEP_IMAGES = 16
+MAX_PLANES = 24
 MAX_STEPS = MAX_STEP_IMAGES + 1
 MAX_SCANS = 128
 MAX_EDGE_PTS = 256
@@ -149,7 +150,7 @@ SOURCE_EXPORTS = [
 # libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
 HOOK_EXPORTS = [
     "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_ground_image", "ssd_test_line_host", "ssd_test_intersect_host", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_best_line_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
-    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_test_record_offset", "ssd_test_record_realloc", "ssd_test_record_realloc_sized", "ssd_test_record_release", "ssd_testhooks_last_error",
+    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_test_single_pass", "ssd_test_single_pass_stats", "ssd_test_single_pass_frame", "ssd_test_record_offset", "ssd_test_record_realloc", "ssd_test_record_realloc_sized", "ssd_test_record_release", "ssd_testhooks_last_error",
 ]
 SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
 HOOKS_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_testhooks.so")
@@ -266,6 +267,9 @@ def hooks_lib():
     L.ssd_test_frame_state.restype = C.c_longlong
     L.ssd_test_ground_image.argtypes = [vp, i32, vp]
     L.ssd_test_empty_quadrilateral.argtypes = [vp, i32, i32]
+    L.ssd_test_single_pass.argtypes = [vp, i32, i32]
+    L.ssd_test_single_pass_stats.argtypes = [vp, i32, vp]
+    L.ssd_test_single_pass_frame.argtypes = [vp, i32, vp, vp]
     L.ssd_test_record_offset.argtypes = [vp, C.c_size_t]
     L.ssd_test_record_realloc.argtypes = [vp]
     L.ssd_test_record_realloc.restype = C.c_ulonglong
@@ -491,6 +495,26 @@ class Detector:
     def empty_quadrilateral(self, frame, surface):
         """test hook: rewrites the sums of a surface (-1 = ground, else plateau index) as if its quadrilateral had accepted no point"""
         _check(hooks_lib().ssd_test_empty_quadrilateral(self._h, frame, surface), "hooks")
+
+    def single_pass(self, mode, sabotage=0):
+        """test hook: the single pass (K1 rasters the step plateaus itself) -1 = as the product decides, 0 = never, 1 = whenever the
+        geometry allows; sabotage 1 / 2 = the predictor's planes in the wrong bins / none (every frame must fall back to k_raster)"""
+        _check(hooks_lib().ssd_test_single_pass(self._h, mode, sabotage), "hooks")
+
+    def single_pass_stats(self, frames):
+        """test hook, of the last enqueue: {'ran': it ran the single pass, 'covered': frames whose step plateaus the planes covered,
+        'with_steps': frames with step plateaus, 'planes': planes over all frames, 'dirty_words': words of the lane's plane images
+        that are not zero (always counted)}"""
+        counts = (C.c_longlong * 4)()
+        ran = _check(hooks_lib().ssd_test_single_pass_stats(self._h, frames, counts), "hooks")
+        return dict(ran=bool(ran), covered=int(counts[0]), with_steps=int(counts[1]), planes=int(counts[2]), dirty_words=int(counts[3]))
+
+    def single_pass_frame(self, frame):
+        """test hook, one frame of the last enqueue: (plane of each height bin as a uint8 array, 255 = none; planes; covered; step plateaus)"""
+        table = (C.c_uint8 * MAX_BINS)()
+        info = (C.c_int32 * 3)()
+        _check(hooks_lib().ssd_test_single_pass_frame(self._h, frame, table, info), "hooks")
+        return np.frombuffer(bytes(table), dtype=np.uint8).copy(), int(info[0]), bool(info[1]), int(info[2])
 
     def record_offset(self, offset_bytes):
         """tools hook: where the first workspace's cell records lie inside their allocation"""

@@ -415,6 +415,9 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   h->imgWords = static_cast<size_t>(P.H) * P.W64;
   const size_t stepBytes = static_cast<size_t>(h->F) * P.maxStepImages * h->imgWords * 8;
   const size_t groundBytes = static_cast<size_t>(h->F) * h->imgWords * 8;
+  /* the planes of the single pass, for handles whose batches can qualify (ssd_launch.h) */
+  const size_t planeBytes = single_pass_geometry(P.W, P.H) && h->F >= kSinglePassMinFrames
+                            ? static_cast<size_t>(h->F) * kMaxPlanes * h->imgWords * 8 : 0;
   auto cleanup = [&]() { ssd_destroy(h); };
 #define HIP_TRY_H(expr)                                                                                 \
   do                                                                                                    \
@@ -445,6 +448,13 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
     HIP_TRY_H(hipMemset(L.dState, 0, sizeof(FrameState) * h->F));
     HIP_TRY_H(hipMemset(L.dStepImg, 0, stepBytes));
     HIP_TRY_H(hipMemset(L.dGroundImg, 0, groundBytes));
+    if(planeBytes)
+    {
+      HIP_TRY_H(hipMalloc(&L.dPlaneImg, planeBytes));
+      HIP_TRY_H(hipMemset(L.dPlaneImg, 0, planeBytes));
+      HIP_TRY_H(hipMalloc(&L.dFallback, sizeof(int) * (1 + static_cast<size_t>(h->F))));
+      HIP_TRY_H(hipMemset(L.dFallback, 0, sizeof(int) * (1 + static_cast<size_t>(h->F))));
+    }
   }
   const size_t resBytes = sizeof(ssd_frame_result) * h->F * h->nSlots;
   HIP_TRY_H(hipMalloc(&h->dResults, resBytes));
@@ -456,7 +466,7 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   HIP_TRY_H(hipMemset(h->dResults, 0, resBytes));
   HIP_TRY_H(hipDeviceSynchronize());
 #undef HIP_TRY_H
-  h->bytes = static_cast<size_t>(depth) * (sizeof(FrameState) * h->F + stepBytes + groundBytes + maskBytes) + resBytes;
+  h->bytes = static_cast<size_t>(depth) * (sizeof(FrameState) * h->F + stepBytes + groundBytes + planeBytes + maskBytes) + resBytes;
   *out = h;
   return SSD_OK;
 }
@@ -472,6 +482,8 @@ int ssd_destroy(ssd_handle *h)
     if(L.dState) (void)hipFree(L.dState);
     if(L.dStepImg) (void)hipFree(L.dStepImg);
     if(L.dGroundImg) (void)hipFree(L.dGroundImg);
+    if(L.dPlaneImg) (void)hipFree(L.dPlaneImg);
+    if(L.dFallback) (void)hipFree(L.dFallback);
     if(L.dTileMasksBase) (void)hipFree(L.dTileMasksBase);
     if(L.in) (void)hipEventDestroy(L.in);
     if(L.done) (void)hipEventDestroy(L.done);
@@ -751,6 +763,13 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   }
   DebugFrame *dbg = h->debug ? h->dDebug : nullptr;
   unsigned long long *dbgImg = h->debug == 1 ? h->dDebugImg : nullptr;
+  /* The single pass: K1 rasters the step plateaus while it counts, into planes of the height bins k_predict expects them in;
+   * k_peaks checks that against the complete histogram, frame by frame, and k_raster does the frames it does not cover.  Only
+   * the whole pipeline in one call (the planes are set in the first stage and consumed in the fourth), only batches. */
+  unsigned long long *planeImg = nullptr;
+  if(L.dPlaneImg && stages == SSD_STAGE_ALL && h->singlePassMode != 0 && (h->singlePassMode == 1 || nframes >= kSinglePassMinFrames))
+    planeImg = L.dPlaneImg;
+  h->lastSinglePass = planeImg != nullptr;
   const bool timing = h->timing && !h->ev.empty();
   int evi = static_cast<int>(h->enqueueCount % SSD_TIMING_SLOTS) * 8;
 
@@ -765,16 +784,16 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
     auto mk = [&]() { if(marks) (void)hipEventRecord(h->ev[evi++], cs); };
     mk();
     if(stages & SSD_STAGE_HIST)
-      launch_hist(xyz, strideFloats, P, L.dState, L.dTileMasks, h->tileMaskStride, nframes, chunkHist, depth, cs);
+      launch_hist(xyz, strideFloats, P, L.dState, L.dTileMasks, h->tileMaskStride, nframes, chunkHist, depth, planeImg, planeImg ? L.dFallback : nullptr, h->singlePassSabotage, cs);
     mk();
     if(stages & SSD_STAGE_PEAKS)
-      launch_peaks(P, L.dState, nframes, dbg, cs);
+      launch_peaks(P, L.dState, nframes, dbg, planeImg ? L.dFallback : nullptr, cs);
     mk();
     if(stages & SSD_STAGE_RASTER)
-      launch_raster(xyz, strideFloats, P, L.dState, L.dStepImg, L.dTileMasks, h->tileMaskStride, nframes, chunkRaster, depth, cs);
+      launch_raster(xyz, strideFloats, P, L.dState, L.dStepImg, L.dTileMasks, h->tileMaskStride, nframes, chunkRaster, depth, planeImg ? L.dFallback : nullptr, cs);
     mk();
     if(stages & SSD_STAGE_OUTLINE)
-      launch_outline(P, L.dState, L.dStepImg, nframes, dbg, dbgImg, cs);
+      launch_outline(P, L.dState, L.dStepImg, planeImg, nframes, dbg, dbgImg, cs);
     mk();
     if(stages & SSD_STAGE_QUADS)
       launch_quads(P, L.dState, nframes, dbg, cs);

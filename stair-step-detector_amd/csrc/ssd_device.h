@@ -5,6 +5,9 @@
  *   FrameState  state[F]            per-frame histogram, plateau table, quad tests, accumulators, result
  *   uint32_t    step_img[F][S][H][W32]   raw top-down bit images of the step plateaus (1 bit / pixel)
  *   uint32_t    ground_img[F][H][W32]    raw bit image of the ground points inside the ground quadrilateral
+ *   uint32_t    plane_img[F][kMaxPlanes][H][W32]   single-pass batches only: per HEIGHT BIN images of the bins k_predict expects
+ *                                   step plateaus in, rastered by k_hist itself; k_outline merges a plateau's (two) planes
+ *                                   into its step image (section "single pass" of DESIGN.md)
  *   DebugFrame  debug[F]            only when debug capture is on
  * W32 = ceil(W/64)*2 32-bit words per image row (rows are padded to whole 64-bit words).
  * Invariant: all bit images are zero between batches (the kernel that consumes an image clears it).
@@ -25,6 +28,13 @@ constexpr int kGroundAcc = kMaxPlateaus;          /* accumulator slot of the gro
 constexpr int kMaxRisers = SSD_MAX_RISERS;
 constexpr int kMaxLive = kMaxStepImages + 1;      /* quadrilaterals a frame can have points tested against: one per step image + the ground */
 constexpr int kZFixShift = 40;                    /* mean z accumulates round(z * 2^40) in int64 */
+/* single pass: planes (one bit image per predicted height bin) a frame can have; beyond, the frame is rastered by k_raster */
+constexpr int kMaxPlanes = SSD_MAX_PLANES;
+/* k_predict samples one cell (64 consecutive points) of every kSpecSample */
+#ifndef SSD_SPEC_SAMPLE
+#define SSD_SPEC_SAMPLE 16
+#endif
+constexpr int kSpecSample = SSD_SPEC_SAMPLE;
 constexpr int kMaxGroundStrips = 168;              /* pixel strips of the ground image the bottom scan reads: one per 50 columns (+ 2), width <= 8192 */
 
 /* the four horizontal edges of a plateau outline, in this order everywhere (segmentation.cpp:585-589) */
@@ -179,6 +189,23 @@ struct FrameState
   /* k_inquad's strip raster: per strip, the bottom-most row (largest) in which a ground point fell on the strip's CENTRE column
    * so far (-1: none; k_quads resets it) - pixels more than two rows above it cannot reach k_final's bottom scan */
   int groundStripMax[kMaxGroundStrips];
+  /* Single pass (k_predict -> k_hist -> k_peaks -> k_outline).  k_predict: histogram of a sample of the frame's cells
+   * (predHist / predDone are its accumulators, left zero), the bins that may belong to a step plateau, a plane for each:
+   * specPlane[bin] (0xff: none).  k_hist rasters the points of those bins into their planes as it counts them: per plane the
+   * bounding box of the bits, the sum of round(z * 2^40) and the points outside the image (quirk Q5).  k_peaks, with the
+   * exact histogram: every bin of every step plateau has a plane (or no points) -> specOk, the step images' boxes / sums /
+   * planes (imgPlane) from the planes'; otherwise the frame goes through k_raster as before.  k_outline merges and clears
+   * the planes of its image and clears the planes no image uses (planeUsed == 0). */
+  unsigned int predHist[kMaxBins];
+  unsigned int predDone;
+  unsigned char specPlane[kMaxBins];
+  int nPlanes;
+  int specOk;
+  int planeYMin[kMaxPlanes], planeYMax[kMaxPlanes], planeXMin[kMaxPlanes], planeXMax[kMaxPlanes];
+  long long planeTotZ[kMaxPlanes];
+  unsigned int planeOob[kMaxPlanes];
+  unsigned char planeUsed[kMaxPlanes];
+  unsigned char imgPlane[kMaxStepImages][2];
   /* vertical faces (extension): written by k_final, accumulated by k_risers */
   int nRisers;
   unsigned int wantedRisers;

@@ -32,6 +32,8 @@ struct ssd_lane
   ssd::FrameState *dState = nullptr;
   unsigned long long *dStepImg = nullptr;
   unsigned long long *dGroundImg = nullptr;
+  int *dFallback = nullptr;                 /* single pass: 1 + F ints, the frames of the batch that k_raster has to do (count first) */
+  unsigned long long *dPlaneImg = nullptr;  /* single pass: [F][kMaxPlanes] bit images, one per candidate height bin (null: the handle never runs it) */
   uint2 *dTileMasks = nullptr;             /* per cell (64 points): which groups of 4 height bins occur; K1 -> K2, K4, K6 */
   uint2 *dTileMasksBase = nullptr;         /* the allocation dTileMasks lies in (the tools' placement hooks put the records elsewhere in a larger one) */
   size_t recordSlack = 0;                   /* bytes of that allocation beyond the records (0 unless a tools hook allocated it) */
@@ -88,6 +90,10 @@ struct ssd_handle
   unsigned long long *dDebugImg = nullptr;
   int debug = 0;                  /* 0 off, 1 records + images (the whole ground image is rastered for it), 2 records only */
   int lastFrames = 0;
+  /* single pass (k_hist rasters the step plateaus itself): -1 = whenever a call qualifies (whole pipeline, >= kSinglePassMinFrames
+   * frames, geometry), 0 = never, 1 = whenever the geometry allows; sabotage: k_predict's (test hooks set both) */
+  int singlePassMode = -1, singlePassSabotage = 0;
+  bool lastSinglePass = false;    /* the last enqueue ran it */
   size_t bytes = 0;
   /* per-stage timing: a ring of event sets, one per enqueue, so that a timed loop never has to synchronise */
   bool timing = false;

@@ -102,7 +102,10 @@ __device__ __forceinline__ int height_bin(const PointParams &P, double wz)
 constexpr int kThreads = 256;
 constexpr int kPts = 4;                 /* points per thread per iteration: four CONSECUTIVE points (48 B) */
 constexpr int kTile = kThreads * kPts;  /* 1024 points per block iteration */
-constexpr int kHistCopies = 32;         /* LDS histogram privatised by lane & 31: bank = copy, no conflicts */
+#ifndef SSD_HIST_COPIES
+#define SSD_HIST_COPIES 32
+#endif
+constexpr int kHistCopies = SSD_HIST_COPIES;         /* LDS histogram privatised by lane & 31: bank = copy, no conflicts */
 
 /* Point sources of the streaming kernels */
 constexpr int kSrcF3 = 0;          /* float xyz, 12-byte loads (unaligned frames, or a point count not divisible by 4) */
@@ -369,381 +372,8 @@ __device__ __forceinline__ void load_cell(const float *__restrict__ base, int ce
   }
 }
 
-/* The streaming kernels are written as block bodies over an explicit LDS struct, (frame, chunk) given by the caller:
- * the kernels below pass blockIdx (tools and experiments have paired two bodies in one launch: DESIGN.md section 3). */
-struct HistLds
-{
-  uint2 lInfo[kMaxCellsPerBlock];
-  /* [bin][copy]: a vote goes to copy = lane & 31, i.e. LDS bank = copy: the 32 lanes the LDS serves per
-   * cycle never collide, whatever their bins (a camera row sweeping one plateau puts all 64 lanes in one bin) */
-  unsigned int lh[kMaxBins * kHistCopies];
-  unsigned int lNonZero;
-};
-
-template<int SRC>
-__device__ __forceinline__ void hist_block(HistLds &L, const float *__restrict__ xyz, size_t strideFloats, const PointParams &P,
-                                           FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
-                                           size_t tileMaskStride, int chunkPoints, const DepthSrc &D, const int frame, const int chunkIdx)
-{
-  uint2 (&lInfo)[kMaxCellsPerBlock] = L.lInfo;
-  unsigned int (&lh)[kMaxBins * kHistCopies] = L.lh;
-  unsigned int &lNonZero = L.lNonZero;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  /* strideFloats counts floats, or 16-bit depth values for kSrcDepth16 */
-  const float *base = SRC == kSrcDepth16
-    ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(xyz) + static_cast<size_t>(frame) * strideFloats)
-    : xyz + static_cast<size_t>(frame) * strideFloats;
-  const int begin = chunkIdx * chunkPoints;
-  const int end = min(begin + chunkPoints, P.nPoints);
-
-  for(int i = tid; i < kMaxBins * kHistCopies; i += kThreads)
-    lh[i] = 0;
-  if(tid == 0)
-    lNonZero = 0;
-  __syncthreads();
-
-  unsigned int *mine = lh + (lane & (kHistCopies - 1));
-  unsigned int nz = 0;                                               /* wave-uniform: the count of the whole wave (scalar popcounts) */
-  int it = 0;
-  auto tileBody = [&](const F3 (&v)[kPts])
-  {
-    unsigned int groups = 0u;
-    /* extremes of (x - xMin, y - yMin) over the lane's in-range points, as the high dwords of the doubles (see row_min_u32) */
-    unsigned int x0 = 0xffffffffu, x1 = 0u, y0 = 0xffffffffu, y1 = 0u;
-#pragma unroll
-    for(int j = 0; j < kPts; j++)
-    {
-      double wx, wy, wz;
-      nz += static_cast<unsigned int>(__popcll(__ballot(v[j].z > 0.0f)));    /* pointcloud.cpp:143-146, counted per wave on the scalar unit */
-      if(world_point_flat(P, v[j], wx, wy, wz))
-      {
-        const unsigned int b = static_cast<unsigned int>(height_bin(P, wz));     /* in [0, nBins) for a point in range */
-        atomicAdd(mine + b * kHistCopies, 1u);                          /* ++hist[bin], pointcloud.cpp:199-202 */
-        groups |= 1u << (b / static_cast<unsigned int>(kBinsPerGroup));
-        const unsigned int hx = static_cast<unsigned int>(__double2hiint(wx - P.xMin)), hy = static_cast<unsigned int>(__double2hiint(wy - P.yMin));
-        x0 = min(x0, hx); x1 = max(x1, hx);
-        y0 = min(y0, hy); y1 = max(y1, hy);
-      }
-    }
-    groups = row_or_u32(groups);
-    x0 = row_min_u32(x0); x1 = row_max_u32(x1);
-    y0 = row_min_u32(y0); y1 = row_max_u32(y1);
-    /* the reductions end here, in all lanes: left to itself the compiler moves their last step into the branch below, where a
-     * DPP operand cannot be folded into the min / max (ten instructions instead of five per tile) */
-    asm volatile("" : "+v"(groups), "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
-    if((lane & 15) == 0)                                         /* cell = 64 consecutive points = lanes 16q .. 16q+15 */
-      lInfo[it * kCellsPerTile + (tid >> 4)] = make_uint2(groups, cell_box_from_high_dwords(x0, x1, y0, y1, P.boxX, P.boxY));
-    it++;
-  };
-  if(SRC == kSrcDepth16)
-  {
-    /* The depth stream: 8 bytes per lane and tile, and the maps.  A tile is 1024 consecutive pixels, so from tile to tile a
-     * lane's row advances by 1024 / W and its column by 1024 % W (wrapping once at most): no division in the loop, and when
-     * 1024 % W == 0 (XGA: a tile is one image row) the lane's four x-map entries never change - loaded once per block.  The
-     * next tile's pixels and map values are requested before the current tile is processed, as in SSD_STREAM_LOOP.
-     * (Round 3 went through load_points: per tile a division, five dependent map loads, ~90 instructions; K1 on depth input is
-     * bound by instruction issue, not by its 2 bytes per point.) */
-    const unsigned short *depth = reinterpret_cast<const unsigned short *>(base);
-    const int dRow = kTile / D.W, dCol = kTile - dRow * D.W;
-    int idx = begin + kPts * tid;
-    int row = depth_row(D, idx), col = idx - row * D.W;
-    float4 xm = *reinterpret_cast<const float4 *>(D.xmap + col);
-    float ym = D.ymap[min(row, D.H - 1)];
-    uint2 raw = idx < end ? *reinterpret_cast<const uint2 *>(depth + idx) : make_uint2(0u, 0u);
-    while(true)
-    {
-      const bool more = idx - kPts * tid + kTile < end;                    /* block-uniform */
-      uint2 rawN = make_uint2(0u, 0u);
-      float4 xmN = xm;
-      float ymN = ym;
-      if(more)
-      {
-        idx += kTile;
-        row += dRow; col += dCol;
-        if(col >= D.W) { col -= D.W; row++; }
-        if(idx < end)
-          rawN = *reinterpret_cast<const uint2 *>(depth + idx);
-        ymN = D.ymap[min(row, D.H - 1)];
-        if(dCol != 0)
-          xmN = *reinterpret_cast<const float4 *>(D.xmap + col);
-      }
-      F3 v[kPts];
-      deproject4(raw, xm, ym, D.depthUnits, v);
-      tileBody(v);
-      if(!more)
-        break;
-      raw = rawN; xm = xmN; ym = ymN;
-    }
-  }
-  else
-    SSD_STREAM_LOOP(tileBody)
-
-  if(lane == 0 && nz)
-    atomicAdd(&lNonZero, nz);
-  __syncthreads();
-
-  FrameState &fs = st[frame];
-  for(int b = tid; b < P.nBins; b += kThreads)
-  {
-    unsigned int s = 0;
-#pragma unroll
-    for(int k = 0; k < kHistCopies; k++)
-      s += lh[b * kHistCopies + ((k + tid) & (kHistCopies - 1))];      /* rotated: conflict-free */
-    if(s)
-      atomicAdd(&fs.histAcc[b], s);
-  }
-  if(tid == 0 && lNonZero)
-    atomicAdd(&fs.nNonZeroAcc, lNonZero);
-  /* the block's cell records, in one burst */
-  {
-    uint2 *dst = tileMasks + static_cast<size_t>(frame) * tileMaskStride + static_cast<size_t>(begin / kCell);
-    for(int i = tid; i < it * kCellsPerTile; i += kThreads)
-      dst[i] = lInfo[i];
-  }
-}
-
-template<int SRC>
-__global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
-                                                   FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
-                                                   size_t tileMaskStride, int chunkPoints, DepthSrc D)
-{
-  __shared__ HistLds L;
-  hist_block<SRC>(L, xyz, strideFloats, P, st, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);   /* frame on the fast grid axis: see launch note on XCD balance */
-}
-
 /* ========================================================================= */
-/* K1b: peaks, plateaus, LUT — one thread per frame (121 bins: trivial)        */
-
-/* one wave per frame: the histogram is staged in LDS, lane 0 walks it (the peak / plateau logic is a
- * sequential scan with carried state), all lanes write the tables out */
-__global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__ st, int nframes, DebugFrame *__restrict__ dbg)
-{
-  __shared__ unsigned int hist[kMaxBins + 1];
-  __shared__ unsigned char lut[kMaxBins];
-  __shared__ int plPeak[kMaxPlateaus], plLo[kMaxPlateaus], plHi[kMaxPlateaus], plEffLo[kMaxPlateaus], plEffHi[kMaxPlateaus], plN[kMaxPlateaus];
-  __shared__ int dbgPeaks[kMaxPlateaus];
-  __shared__ int sNPl, sNPeaks, sOverflow, sGround, sFirstStep, sNImg;
-
-  const int frame = blockIdx.x, lane = threadIdx.x;
-  if(frame >= nframes)
-    return;
-  FrameState &fs = st[frame];
-  const int nb = P.nBins;
-
-  unsigned int total = 0;
-  for(int b = lane; b <= kMaxBins; b += 64)
-  {
-    /* K1's accumulator is taken over and left zero for the next call (FrameState::histAcc) */
-    const unsigned int v = b < nb ? fs.histAcc[b] : 0u;
-    hist[b] = v;
-    total += v;
-    if(b < kMaxBins)
-    {
-      lut[b] = 0xff;
-      fs.hist[b] = v;
-      if(b < nb)
-        fs.histAcc[b] = 0u;
-    }
-  }
-#pragma unroll
-  for(int o = 32; o > 0; o >>= 1)
-    total += __shfl_xor(total, o);
-  __syncthreads();
-
-  /* findPeaks (pointcloud.cpp:214-241) + filterPeaks (:243-256), all lanes: lane l looks at bins l and l + 64.  The
-   * reference walks the bins with one carried flag: a bin is a peak when the count falls after it and the last CHANGE
-   * before it was a rise (so a flat top reports its last index, quirk Q1).  Here: rise / fall bits of all bins by two
-   * ballots each, then "the highest changed bin below me is a rise" by bit scans. */
-  unsigned long long peakBits[2];
-  {
-    unsigned long long up[2], down[2];
-#pragma unroll
-    for(int w = 0; w < 2; w++)
-    {
-      const int i = lane + 64 * w;
-      const bool inRange = i < nb - 1;
-      const unsigned int c = hist[min(i, kMaxBins - 1)], succ = hist[min(i + 1, kMaxBins)];
-      up[w] = __ballot(inRange && c < succ);
-      down[w] = __ballot(inRange && c > succ);
-    }
-    const unsigned long long changed[2] = { up[0] | down[0], up[1] | down[1] };
-#pragma unroll
-    for(int w = 0; w < 2; w++)
-    {
-      const int i = lane + 64 * w;
-      bool peak = false;
-      if((down[w] >> lane) & 1ull)
-      {
-        const unsigned long long below = changed[w] & ((1ull << lane) - 1ull);
-        bool lastWasRise = false;
-        if(below)
-          lastWasRise = (up[w] >> (63 - __clzll(static_cast<long long>(below)))) & 1ull;
-        else if(w == 1 && changed[0])
-          lastWasRise = (up[0] >> (63 - __clzll(static_cast<long long>(changed[0])))) & 1ull;
-        if(lastWasRise)
-        {
-          const unsigned int np = hist[i];
-          peak = np >= 2000u && (np * 2u - hist[i - 1] - hist[i + 1]) * 2u > np;     /* filterPeaks; i >= 1 after a rise */
-        }
-      }
-      peakBits[w] = __ballot(peak);
-    }
-  }
-
-  if(lane == 0)
-  {
-    int nPl = 0;
-    int consumedUpTo = -1;           /* every bin <= this has already left pointsHt */
-    bool overflow = false;
-    int nPeaksDbg = 0;
-    for(int w = 0; w < 2; w++)
-      for(unsigned long long bits = peakBits[w]; bits; bits &= bits - 1ull)
-      {
-        const int i = 64 * w + __ffsll(static_cast<long long>(bits)) - 1;
-        const unsigned int succ = hist[i + 1];
-        if(nPeaksDbg < kMaxPlateaus)
-          dbgPeaks[nPeaksDbg] = i;
-        nPeaksDbg++;
-        if(nPl >= kMaxPlateaus)
-          overflow = true;
-        else
-        {
-          /* extractPlateauPoints (:300-335): choose the pair, then take what is left of it */
-          int hMin, hMax;
-          if(hist[i - 1] > succ) { hMin = i - 1; hMax = i; }
-          else { hMin = i; hMax = i + 1; }
-          int lo, hi;
-          if(hMin == 0)
-          {
-            /* quirk Q4: Height_t(heightMin - 1) wraps to 65535: everything goes to the remainder */
-            lo = 1; hi = 0;
-            consumedUpTo = nb;
-          }
-          else
-          {
-            lo = max(hMin, consumedUpTo + 1);
-            hi = hMax;
-            consumedUpTo = max(consumedUpTo, hMax);
-          }
-          unsigned int cnt = 0;
-          for(int b = lo; b <= hi; b++)
-          {
-            cnt += hist[b];
-            lut[b] = static_cast<unsigned char>(nPl);
-          }
-          plPeak[nPl] = i; plLo[nPl] = hMin; plHi[nPl] = hMax; plEffLo[nPl] = lo; plEffHi[nPl] = hi;
-          plN[nPl] = static_cast<int>(cnt);
-          nPl++;
-        }
-      }
-
-    /* ground = most populous plateau below minHeight (pointcloud.cpp:402-418) */
-    int groundInd = -1, i = 0;
-    unsigned int maxGround = 0;
-    for( ; i < nPl; i++)
-    {
-      if(plPeak[i] >= P.minHeight)
-        break;
-      if(maxGround < static_cast<unsigned int>(plN[i]))
-      {
-        maxGround = static_cast<unsigned int>(plN[i]);
-        groundInd = i;
-      }
-    }
-    int nImg = nPl - i;
-    if(nImg > P.maxStepImages)
-    {
-      nImg = P.maxStepImages;
-      overflow = true;
-    }
-    sNPl = nPl; sNPeaks = nPeaksDbg; sOverflow = overflow ? 1 : 0; sGround = groundInd; sFirstStep = i; sNImg = nImg;
-  }
-  __syncthreads();
-
-  const int nPl = sNPl, firstStep = sFirstStep, nImg = sNImg;
-  unsigned int wanted = 0u;
-  for(int b = lane; b < kMaxBins; b += 64)
-  {
-    const unsigned char l = lut[b];
-    fs.lut[b] = l;
-    const int slot = static_cast<int>(l) - firstStep;
-    if(b < nb && l != 0xff && slot >= 0 && slot < nImg)
-      wanted |= 1u << (b / kBinsPerGroup);
-  }
-#pragma unroll
-  for(int o = 32; o > 0; o >>= 1)
-    wanted |= __shfl_xor(wanted, o);
-  if(lane < nPl)
-  {
-    PlateauState &pl = fs.pl[lane];
-    pl.peakBin = plPeak[lane];
-    pl.binLo = plLo[lane];
-    pl.binHi = plHi[lane];
-    pl.effLo = plEffLo[lane];
-    pl.effHi = plEffHi[lane];
-    pl.nPoints = plN[lane];
-    pl.isStep = plPeak[lane] >= P.minHeight ? 1 : 0;
-    pl.outlineFound = 0;
-    pl.valid = 0;
-    for(int k = 0; k < 8; k++) { pl.quadImg[k] = 0.0; pl.quadWorld[k] = 0.0; }
-  }
-  if(lane <= kMaxStepImages)                          /* [kMaxStepImages] = the ground image */
-  {
-    fs.imgYMin[lane] = 0x7fffffff; fs.imgYMax[lane] = -1;
-    fs.imgXMin[lane] = 0x7fffffff; fs.imgXMax[lane] = -1;
-  }
-  if(lane < kMaxStepImages)
-    fs.totZ[lane] = 0;                                 /* k_raster's sums start from zero */
-  if(lane == 0)
-  {
-    fs.nNonZero = fs.nNonZeroAcc;
-    fs.nNonZeroAcc = 0u;
-    fs.nOob = 0u;
-    fs.status = sOverflow ? static_cast<unsigned int>(SSD_ST_OVERFLOW) : 0u;     /* the frame's status starts here */
-    fs.nInRange = total;
-    fs.nPlateaus = nPl;
-    fs.groundInd = sGround;
-    fs.firstStep = firstStep;
-    fs.nStepImages = nImg;
-    fs.firstValidInd = -1;
-    fs.wantedSteps = wanted;
-    fs.wantedQuads = 0u;
-    fs.anyActive = 0u;
-  }
-
-  if(dbg)
-  {
-    ssd_debug_frame &d = dbg[frame].d;
-    for(int b = lane; b < kMaxBins; b += 64)
-      d.hist[b] = hist[b];
-    if(lane < min(sNPeaks, kMaxPlateaus))
-      d.peaks[lane] = dbgPeaks[lane];
-    if(lane < nPl)
-    {
-      ssd_debug_plateau &p = d.plateaus[lane];
-      p.peak_bin = plPeak[lane]; p.bin_lo = plLo[lane]; p.bin_hi = plHi[lane];
-      p.eff_lo = plEffLo[lane]; p.eff_hi = plEffHi[lane];
-      p.n_points = plN[lane];
-      p.is_step = plPeak[lane] >= P.minHeight ? 1 : 0;
-    }
-    if(lane == 0)
-    {
-      d.n_nonzero = static_cast<int>(fs.nNonZero);
-      d.n_inrange = static_cast<int>(total);
-      d.n_bins = nb;
-      d.min_height = P.minHeight;
-      d.min_img_y_extent = P.minImgYExtent;
-      d.n_peaks = sNPeaks;
-      d.n_plateaus = nPl;
-      d.first_step = firstStep;
-      d.ground_ind = sGround;
-    }
-  }
-}
-
-/* ========================================================================= */
-/* K2: raster the step plateaus into bit images                               */
+/* LDS image windows, pixel keys, fixed-point z: shared by K1 (single pass), K2 and K4 */
 
 /* Write-combining LDS windows for the rasterising kernels — one per WAVE, no barriers.
  *
@@ -945,6 +575,868 @@ __device__ __forceinline__ long long z_plus_magic_bits(double z)
 }
 constexpr long long kMagicBits = 0x40B8000000000000ll;       /* bits of 6144.0 */
 
+/* ---- single pass: K1's window spans FOUR planes ----
+ * K1 rasters the points of the bins k_predict chose, one bit image ("plane") per height bin: which two adjacent bins make a
+ * plateau is only known once the histogram is complete (k_peaks), and range noise spreads a tread over two or three bins
+ * whose pixels interleave.  A window over one image would send every pixel of the minority bins to memory; this one
+ * holds the same patch of four consecutive planes (one tread's bins and a spare), 16 rows x 8 words each: 4 KiB per wave.  Keys
+ * as pixel_key with the plane in the slot field, "inside" by one subtraction and one AND as window_hit. */
+#ifndef SSD_SPEC_PLANE_BITS
+#define SSD_SPEC_PLANE_BITS 1
+#endif
+#ifndef SSD_SPEC_ROW_BITS
+#define SSD_SPEC_ROW_BITS 4
+#endif
+constexpr int kSpecPlaneBits = SSD_SPEC_PLANE_BITS, kSpecRowBits = SSD_SPEC_ROW_BITS;
+constexpr int kSpecWinPlanes = 1 << kSpecPlaneBits, kSpecWinRows = 1 << kSpecRowBits, kSpecWinCols = 8;
+constexpr int kSpecWinWords = kSpecWinPlanes * kSpecWinRows * kSpecWinCols;
+constexpr unsigned int kSpecInside = (static_cast<unsigned int>(kSpecWinPlanes - 1) << 26) | (static_cast<unsigned int>(kSpecWinRows - 1) << 13)
+                                     | static_cast<unsigned int>(64 * kSpecWinCols - 1);
+static_assert(kSpecWinCols == 8, "the index arithmetic below is written for eight word columns");
+static_assert(kMaxPlanes <= 32 - kSpecWinPlanes, "a plane offset that borrows must fall outside the window's planes");
+
+struct SpecWindow
+{
+  int plane0 = -1, row0 = 0, col0 = 0;   /* wave-uniform */
+};
+__device__ __forceinline__ unsigned int specwin_base(const SpecWindow &w)
+{
+  return w.plane0 < 0 ? kNoWindow : pixel_key(w.plane0, w.row0, w.col0 << 6);
+}
+__device__ __forceinline__ bool specwin_hit(unsigned int d)
+{
+  return (d & ~kSpecInside) == 0u;
+}
+/* OR over the wave, result in every lane's SGPR copy: rows by DPP, the four rows by readlane */
+__device__ __forceinline__ unsigned int wave_or_u32(unsigned int v)
+{
+  v = row_or_u32(v);
+  return static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(v), 0) | __builtin_amdgcn_readlane(static_cast<int>(v), 16)
+                                   | __builtin_amdgcn_readlane(static_cast<int>(v), 32) | __builtin_amdgcn_readlane(static_cast<int>(v), 48));
+}
+/* the window out (non-zero words only) and cleared; per plane the rows and word columns that held bits, as two bit masks
+ * OR-ed over the wave (one reduction per plane with bits, not four min / max), extend the plane's box; all 64 lanes */
+__device__ __forceinline__ void specwin_flush(unsigned long long *ww, const SpecWindow &w, unsigned long long *__restrict__ planes,
+                                              unsigned int imgWords, int W64, ImageBox *boxes, int lane)
+{
+  if(w.plane0 < 0)
+    return;
+#pragma unroll
+  for(int pl = 0; pl < kSpecWinPlanes; pl++)
+  {
+    unsigned long long *img = planes + static_cast<size_t>(w.plane0 + pl) * imgWords;
+    unsigned long long seen = 0ull;             /* bits 0..31: rows, 32..39: word columns */
+#pragma unroll
+    for(int k = 0; k < kSpecWinRows * kSpecWinCols / 64; k++)
+    {
+      const int i = k * 64 + lane;              /* within the plane: row = i >> 3, column = i & 7 */
+      const unsigned long long v = ww[pl * (kSpecWinRows * kSpecWinCols) + i];
+      if(v)
+      {
+        const int y = w.row0 + (i >> 3), x = w.col0 + (i & 7);
+        atomicOr(img + static_cast<size_t>(y) * W64 + x, v);
+        ww[pl * (kSpecWinRows * kSpecWinCols) + i] = 0ull;
+        seen |= (1ull << (i >> 3)) | (0x100000000ull << (i & 7));
+      }
+    }
+    if(__ballot(seen != 0ull) == 0ull)
+      continue;
+    const unsigned int rows = wave_or_u32(static_cast<unsigned int>(seen)), cols = wave_or_u32(static_cast<unsigned int>(seen >> 32));
+    if(lane == 0)
+    {
+      ImageBox &b = boxes[w.plane0 + pl];
+      atomicMin(&b.yMin, w.row0 + __ffs(static_cast<int>(rows)) - 1); atomicMax(&b.yMax, w.row0 + 31 - __clz(static_cast<int>(rows)));
+      atomicMin(&b.xMin, w.col0 + __ffs(static_cast<int>(cols)) - 1); atomicMax(&b.xMax, w.col0 + 31 - __clz(static_cast<int>(cols)));
+    }
+  }
+}
+/* as wavewin_prepare; the new origin: one plane below the lowest missing one (a tread's minority bin may lie on either side
+ * of the bin seen first), the lowest missing row, one word left of the lowest missing column */
+__device__ __forceinline__ void specwin_prepare(unsigned long long *ww, SpecWindow &w, unsigned long long *__restrict__ planes,
+                                                unsigned int imgWords, int W64, ImageBox *boxes, unsigned int first, int lane)
+{
+  const bool has = first != kNoPixel;
+  const bool miss = has && !specwin_hit(first - specwin_base(w));
+  const unsigned long long missing = __ballot(miss);
+  if(missing == 0ull || 2 * __popcll(missing) <= __popcll(__ballot(has)))
+    return;
+  const unsigned int loPlane = __builtin_amdgcn_readfirstlane(wave_min_u32(has ? first >> 26 : 31u));     /* of ALL the tile's pixels: the planes of a tread alternate */
+  const unsigned int loRow = __builtin_amdgcn_readfirstlane(wave_min_u32(miss ? (first >> 13) & 0x1fffu : 0x1fffu));
+  const unsigned int loCol = __builtin_amdgcn_readfirstlane(wave_min_u32(miss ? first & 0x1fffu : 0x1fffu));
+  specwin_flush(ww, w, planes, imgWords, W64, boxes, lane);
+  w.plane0 = max(0, min(static_cast<int>(loPlane) - (kSpecWinPlanes > 2 ? 1 : 0), kMaxPlanes - kSpecWinPlanes));
+  w.row0 = static_cast<int>(loRow);
+  w.col0 = max(0, min(static_cast<int>(loCol >> 6) - 1, W64 - kSpecWinCols));
+}
+/* The pixels a lane sent straight to memory because they missed the window: their bounding box and planes, in the lane's
+ * registers (K2 / K4 keep them per wave in LDS with five LDS atomics per miss, wavemiss_*; here two or three times as many
+ * pixels miss - the points of a candidate bin that lie elsewhere in the image, on a wall behind the stairs - and the lane
+ * has registers to spare).  specmiss_flush, end of the block's loop: reduced over the wave, into the block's boxes. */
+struct SpecMiss
+{
+  int y0 = 0x7fffffff, y1 = -1, x0 = 0x7fffffff, x1 = -1;
+  unsigned int planes = 0u;
+};
+__device__ __forceinline__ void specmiss_flush(const SpecMiss &m, ImageBox *boxes, int lane)
+{
+  const unsigned int planes = wave_or_u32(m.planes);
+  if(planes == 0u)
+    return;
+  const int y0 = wave_min_i(m.y0), y1 = wave_max_i(m.y1), x0 = wave_min_i(m.x0), x1 = wave_max_i(m.x1);
+  if(lane < 32 && ((planes >> lane) & 1u))
+  {
+    atomicMin(&boxes[lane].yMin, y0); atomicMax(&boxes[lane].yMax, y1);
+    atomicMin(&boxes[lane].xMin, x0); atomicMax(&boxes[lane].xMax, x1);
+  }
+}
+/* as wavewin_emit */
+__device__ __forceinline__ void specwin_emit(unsigned long long *ww, SpecMiss &miss, SpecWindow &w, unsigned long long *__restrict__ planes,
+                                             unsigned int imgWords, int W64, ImageBox *boxes, const unsigned int (&key)[4], int lane)
+{
+  specwin_prepare(ww, w, planes, imgWords, W64, boxes, min(min(key[0], key[1]), min(key[2], key[3])), lane);
+  const unsigned int base = specwin_base(w);
+  unsigned int *ww32 = reinterpret_cast<unsigned int *>(ww);
+#pragma unroll
+  for(int j = 0; j < 4; j++)
+  {
+    const unsigned int k = key[j], d = k - base;
+    const unsigned int bit = 1u << (k & 31u);
+    if(specwin_hit(d))
+      atomicOr(&ww32[((d >> 26) << (kSpecRowBits + 4)) | (((d >> 13) & (kSpecWinRows - 1u)) << 4) | ((d & 0x1fffu) >> 5)], bit);     /* (plane, row, half word) */
+    else if(k != kNoPixel)
+    {
+      const unsigned int slot = k >> 26, iy = (k >> 13) & 0x1fffu, ix = k & 0x1fffu, xw = ix >> 6;
+      atomicOr(reinterpret_cast<unsigned int *>(planes + (slot * imgWords + iy * static_cast<unsigned int>(W64) + xw)) + ((ix >> 5) & 1u), bit);
+      miss.y0 = min(miss.y0, static_cast<int>(iy)); miss.y1 = max(miss.y1, static_cast<int>(iy));
+      miss.x0 = min(miss.x0, static_cast<int>(xw)); miss.x1 = max(miss.x1, static_cast<int>(xw));
+      miss.planes |= 1u << slot;
+    }
+  }
+}
+
+/* The streaming kernels are written as block bodies over an explicit LDS struct, (frame, chunk) given by the caller:
+ * the kernels below pass blockIdx (tools and experiments have paired two bodies in one launch: DESIGN.md section 3). */
+/* what the single pass adds to K1's LDS */
+struct SpecLds
+{
+  unsigned long long wins[kThreads / 64][kSpecWinWords];
+  ImageBox boxes[kMaxPlanes];
+  unsigned char plane[kMaxBins];                 /* FrameState::specPlane */
+  unsigned int oob[kMaxPlanes];
+  unsigned long long ltot[kMaxPlanes][8];        /* sum of round(z * 2^40) per plane (this block's share) */
+};
+struct NoSpecLds {};
+
+struct HistLds
+{
+  uint2 lInfo[kMaxCellsPerBlock];
+  /* [bin][copy]: a vote goes to copy = lane & 31, i.e. LDS bank = copy: the 32 lanes the LDS serves per
+   * cycle never collide, whatever their bins (a camera row sweeping one plateau puts all 64 lanes in one bin) */
+  unsigned int lh[kMaxBins * kHistCopies];
+  unsigned int lNonZero;
+};
+
+/* SPEC (single pass): the block also rasters the points of the bins that have a plane (FrameState::specPlane, k_predict) into
+ * the frame's planes, as k_raster does for the plateaus' bins: pixel (image_pixel), the plane's z sum and out-of-image count. */
+template<int SRC, bool SPEC, typename SPECLDS>
+__device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float *__restrict__ xyz, size_t strideFloats, const PointParams &P,
+                                           const PixelParams &X, FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
+                                           unsigned long long *__restrict__ planeImg,
+                                           size_t tileMaskStride, int chunkPoints, const DepthSrc &D, const int frame, const int chunkIdx)
+{
+  uint2 (&lInfo)[kMaxCellsPerBlock] = L.lInfo;
+  unsigned int (&lh)[kMaxBins * kHistCopies] = L.lh;
+  unsigned int &lNonZero = L.lNonZero;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  SpecWindow win;
+  SpecMiss missed;
+  int curT = -1;
+  unsigned long long accT = 0;
+  const unsigned int imgWords = static_cast<unsigned int>(X.H) * static_cast<unsigned int>(X.W64);
+  unsigned long long *frameImg = nullptr;
+  if constexpr(SPEC)
+  {
+    frameImg = planeImg + static_cast<size_t>(frame) * kMaxPlanes * imgWords;
+    const unsigned char planeMine = tid < kMaxBins ? st[frame].specPlane[tid] : static_cast<unsigned char>(0xff);
+    if(tid < kMaxBins)
+      SL.plane[tid] = planeMine;
+    if(tid < kMaxPlanes)
+    {
+      SL.boxes[tid] = ImageBox{ 0x7fffffff, -1, 0x7fffffff, -1 };
+      SL.oob[tid] = 0u;
+    }
+    if(tid < kMaxPlanes * 8)
+      (&SL.ltot[0][0])[tid] = 0ull;
+    for(int i = tid; i < (kThreads / 64) * kSpecWinWords; i += kThreads)
+      (&SL.wins[0][0])[i] = 0ull;
+  }
+  /* strideFloats counts floats, or 16-bit depth values for kSrcDepth16 */
+  const float *base = SRC == kSrcDepth16
+    ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(xyz) + static_cast<size_t>(frame) * strideFloats)
+    : xyz + static_cast<size_t>(frame) * strideFloats;
+  const int begin = chunkIdx * chunkPoints;
+  const int end = min(begin + chunkPoints, P.nPoints);
+
+  for(int i = tid; i < kMaxBins * kHistCopies; i += kThreads)
+    lh[i] = 0;
+  if(tid == 0)
+    lNonZero = 0;
+  __syncthreads();
+
+  unsigned int *mine = lh + (lane & (kHistCopies - 1));
+  unsigned int nz = 0;                                               /* wave-uniform: the count of the whole wave (scalar popcounts) */
+  int it = 0;
+  auto tileBody = [&](const F3 (&v)[kPts])
+  {
+    unsigned int groups = 0u;
+    /* extremes of (x - xMin, y - yMin) over the lane's in-range points, as the high dwords of the doubles (see row_min_u32) */
+    unsigned int x0 = 0xffffffffu, x1 = 0u, y0 = 0xffffffffu, y1 = 0u;
+    unsigned int key[kPts];
+#pragma unroll
+    for(int j = 0; j < kPts; j++)
+    {
+      double wx, wy, wz;
+      key[j] = kNoPixel;
+      nz += static_cast<unsigned int>(__popcll(__ballot(v[j].z > 0.0f)));    /* pointcloud.cpp:143-146, counted per wave on the scalar unit */
+      if(world_point_flat(P, v[j], wx, wy, wz))
+      {
+        const unsigned int b = static_cast<unsigned int>(height_bin(P, wz));     /* in [0, nBins) for a point in range */
+        atomicAdd(mine + b * kHistCopies, 1u);                          /* ++hist[bin], pointcloud.cpp:199-202 */
+        groups |= 1u << (b / static_cast<unsigned int>(kBinsPerGroup));
+        const unsigned int hx = static_cast<unsigned int>(__double2hiint(wx - P.xMin)), hy = static_cast<unsigned int>(__double2hiint(wy - P.yMin));
+        x0 = min(x0, hx); x1 = max(x1, hx);
+        y0 = min(y0, hy); y1 = max(y1, hy);
+        if constexpr(SPEC)
+        {
+          const int plane = SL.plane[b];
+          if(plane != 0xff)
+          {
+            /* as k_raster's body: projectToBinaryImage (pointcloud.cpp:458-471) for a bin that may turn out a plateau's */
+            int ix, iy;
+            const bool inside = image_pixel(P, X, wx, wy, ix, iy);
+            if(plane != curT)
+            {
+              if(curT >= 0)
+                atomicAdd(&SL.ltot[curT][lane & 7], accT);
+              curT = plane;
+              accT = 0;
+            }
+            accT += static_cast<unsigned long long>(z_to_fixed(wz));
+            if(!inside)
+              atomicAdd(&SL.oob[plane], 1u);                   /* quirk Q5, rare */
+            key[j] = inside ? pixel_key(plane, iy, ix) : kNoPixel;
+          }
+        }
+      }
+    }
+    groups = row_or_u32(groups);
+    x0 = row_min_u32(x0); x1 = row_max_u32(x1);
+    y0 = row_min_u32(y0); y1 = row_max_u32(y1);
+    /* the reductions end here, in all lanes: left to itself the compiler moves their last step into the branch below, where a
+     * DPP operand cannot be folded into the min / max (ten instructions instead of five per tile) */
+    asm volatile("" : "+v"(groups), "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
+    if((lane & 15) == 0)                                         /* cell = 64 consecutive points = lanes 16q .. 16q+15 */
+      lInfo[it * kCellsPerTile + (tid >> 4)] = make_uint2(groups, cell_box_from_high_dwords(x0, x1, y0, y1, P.boxX, P.boxY));
+    it++;
+    if constexpr(SPEC)
+    {
+      /* most tiles hold no point of a candidate bin (ground, risers, background): one ballot */
+      if(__ballot((key[0] & key[1] & key[2] & key[3]) != kNoPixel) != 0ull)
+        specwin_emit(SL.wins[tid >> 6], missed, win, frameImg, imgWords, X.W64, SL.boxes, key, lane);
+    }
+  };
+  if(SRC == kSrcDepth16)
+  {
+    /* The depth stream: 8 bytes per lane and tile, and the maps.  A tile is 1024 consecutive pixels, so from tile to tile a
+     * lane's row advances by 1024 / W and its column by 1024 % W (wrapping once at most): no division in the loop, and when
+     * 1024 % W == 0 (XGA: a tile is one image row) the lane's four x-map entries never change - loaded once per block.  The
+     * next tile's pixels and map values are requested before the current tile is processed, as in SSD_STREAM_LOOP.
+     * (Round 3 went through load_points: per tile a division, five dependent map loads, ~90 instructions; K1 on depth input is
+     * bound by instruction issue, not by its 2 bytes per point.) */
+    const unsigned short *depth = reinterpret_cast<const unsigned short *>(base);
+    const int dRow = kTile / D.W, dCol = kTile - dRow * D.W;
+    int idx = begin + kPts * tid;
+    int row = depth_row(D, idx), col = idx - row * D.W;
+    float4 xm = *reinterpret_cast<const float4 *>(D.xmap + col);
+    float ym = D.ymap[min(row, D.H - 1)];
+    uint2 raw = idx < end ? *reinterpret_cast<const uint2 *>(depth + idx) : make_uint2(0u, 0u);
+    while(true)
+    {
+      const bool more = idx - kPts * tid + kTile < end;                    /* block-uniform */
+      uint2 rawN = make_uint2(0u, 0u);
+      float4 xmN = xm;
+      float ymN = ym;
+      if(more)
+      {
+        idx += kTile;
+        row += dRow; col += dCol;
+        if(col >= D.W) { col -= D.W; row++; }
+        if(idx < end)
+          rawN = *reinterpret_cast<const uint2 *>(depth + idx);
+        ymN = D.ymap[min(row, D.H - 1)];
+        if(dCol != 0)
+          xmN = *reinterpret_cast<const float4 *>(D.xmap + col);
+      }
+      F3 v[kPts];
+      deproject4(raw, xm, ym, D.depthUnits, v);
+      tileBody(v);
+      if(!more)
+        break;
+      raw = rawN; xm = xmN; ym = ymN;
+    }
+  }
+  else
+    SSD_STREAM_LOOP(tileBody)
+
+  if constexpr(SPEC)
+  {
+    specwin_flush(SL.wins[tid >> 6], win, frameImg, imgWords, X.W64, SL.boxes, lane);
+    specmiss_flush(missed, SL.boxes, lane);
+    if(curT >= 0)
+      atomicAdd(&SL.ltot[curT][lane & 7], accT);
+  }
+  if(lane == 0 && nz)
+    atomicAdd(&lNonZero, nz);
+  __syncthreads();
+
+  FrameState &fs = st[frame];
+  if constexpr(SPEC)
+  {
+    if(tid < kMaxPlanes)
+    {
+      unsigned long long t = 0;
+#pragma unroll
+      for(int k = 0; k < 8; k++)
+        t += SL.ltot[tid][k];
+      if(t)
+        atomicAdd(reinterpret_cast<unsigned long long *>(&fs.planeTotZ[tid]), t);
+      if(SL.boxes[tid].yMax >= 0)
+      {
+        atomicMin(&fs.planeYMin[tid], SL.boxes[tid].yMin); atomicMax(&fs.planeYMax[tid], SL.boxes[tid].yMax);
+        atomicMin(&fs.planeXMin[tid], SL.boxes[tid].xMin); atomicMax(&fs.planeXMax[tid], SL.boxes[tid].xMax);
+      }
+      if(SL.oob[tid])
+        atomicAdd(&fs.planeOob[tid], SL.oob[tid]);
+    }
+  }
+  for(int b = tid; b < P.nBins; b += kThreads)
+  {
+    unsigned int s = 0;
+#pragma unroll
+    for(int k = 0; k < kHistCopies; k++)
+      s += lh[b * kHistCopies + ((k + tid) & (kHistCopies - 1))];      /* rotated: conflict-free */
+    if(s)
+      atomicAdd(&fs.histAcc[b], s);
+  }
+  if(tid == 0 && lNonZero)
+    atomicAdd(&fs.nNonZeroAcc, lNonZero);
+  /* the block's cell records, in one burst */
+  {
+    uint2 *dst = tileMasks + static_cast<size_t>(frame) * tileMaskStride + static_cast<size_t>(begin / kCell);
+    for(int i = tid; i < it * kCellsPerTile; i += kThreads)
+      dst[i] = lInfo[i];
+  }
+}
+
+template<int SRC>
+__global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
+                                                   FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
+                                                   size_t tileMaskStride, int chunkPoints, DepthSrc D)
+{
+  __shared__ HistLds L;
+  NoSpecLds none;
+  hist_block<SRC, false>(L, none, xyz, strideFloats, P, PixelParams{}, st, tileMasks, nullptr, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);   /* frame on the fast grid axis: see launch note on XCD balance */
+}
+
+/* K1 of a single-pass batch: histogram, cell records AND the planes of the candidate bins.  39 KiB of LDS: four blocks per CU. */
+#ifndef SSD_K1S_WAVES
+#define SSD_K1S_WAVES 5
+#endif
+template<int SRC>
+__global__ __launch_bounds__(kThreads, SSD_K1S_WAVES) void k_hist_planes(const float *__restrict__ xyz, size_t strideFloats, PointParams P, PixelParams X,
+                                                   FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
+                                                   unsigned long long *__restrict__ planeImg,
+                                                   size_t tileMaskStride, int chunkPoints, DepthSrc D)
+{
+  __shared__ HistLds L;
+  __shared__ SpecLds SL;
+  hist_block<SRC, true>(L, SL, xyz, strideFloats, P, X, st, tileMasks, planeImg, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
+}
+
+/* K0 of a single-pass batch: which height bins may belong to a step plateau?  A histogram of one cell in every kSpecSample (a
+ * different column of the camera image from row to row), the reference's peak filter (pointcloud.cpp:243-256) on it with
+ * slack, a plane for each candidate peak's bin and its two neighbours (the plateau takes the peak bin and the fuller
+ * neighbour: only the complete histogram decides which).  Nothing here has to be right: k_peaks checks the planes against the
+ * plateaus it finds in the complete histogram, and a frame whose plateaus are not covered is rastered by k_raster.
+ * Grid (frame, part): the blocks of a frame add their counts into FrameState::predHist; the last one to finish makes the table
+ * and leaves the accumulators zero.  sabotage (tests): 1 = planes three bins above the right ones, 2 = no planes. */
+template<int SRC>
+__global__ __launch_bounds__(kThreads) void k_predict(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
+                                                      FrameState *__restrict__ st, DepthSrc D, int minHeight, int sabotage, int *__restrict__ fallback)
+{
+  __shared__ unsigned int sh[kMaxBins + 2];
+  __shared__ unsigned int shc[kMaxBins * kHistCopies];        /* [bin][copy], as K1's: the lanes of a wave mostly vote for ONE bin */
+  __shared__ int sLast;
+  const int frame = blockIdx.x, part = blockIdx.y, nParts = gridDim.y, tid = threadIdx.x;
+  const float *base = SRC == kSrcDepth16
+    ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(xyz) + static_cast<size_t>(frame) * strideFloats)
+    : xyz + static_cast<size_t>(frame) * strideFloats;
+  if(tid < kMaxBins + 2)
+    sh[tid] = 0u;
+  for(int i = tid; i < kMaxBins * kHistCopies; i += kThreads)
+    shc[i] = 0u;
+  __syncthreads();
+  unsigned int *mine = shc + (tid & (kHistCopies - 1));
+  /* the sample: runs of 16 consecutive points (four lanes' loads, 192 B), one of every kSpecSample runs, at a place in its group
+   * of runs that changes from group to group.  (Whole cells of 64 points were tried first: neighbouring pixels share a height
+   * bin, so a bin's count is really a count of runs - with 64-point runs a background bin's 150 samples were five runs and
+   * one bin in six passed the peak filter by chance.) */
+#ifndef SSD_K0_RUN
+#define SSD_K0_RUN 16
+#endif
+  constexpr int kRun = SSD_K0_RUN, kLanesPerRun = kRun / kPts;
+  const int nRuns = (P.nPoints + kRun - 1) / kRun;
+  const int nGroups = (nRuns + kSpecSample - 1) / kSpecSample;
+  for(int g = part * (kThreads / kLanesPerRun) + tid / kLanesPerRun; g < nGroups; g += nParts * (kThreads / kLanesPerRun))
+  {
+    const int run = g * kSpecSample + ((g * 5) & (kSpecSample - 1));
+    F3 v[kPts];
+    load_points<SRC>(base, run * kRun + kPts * (tid % kLanesPerRun), P.nPoints, v, D);
+#pragma unroll
+    for(int j = 0; j < kPts; j++)
+    {
+      double wx, wy, wz;
+      if(world_point_flat(P, v[j], wx, wy, wz))
+        atomicAdd(mine + height_bin(P, wz) * kHistCopies, 1u);
+    }
+  }
+  __syncthreads();
+  FrameState &fs = st[frame];
+  if(tid < P.nBins)
+  {
+    unsigned int c = 0;
+#pragma unroll
+    for(int k = 0; k < kHistCopies; k++)
+      c += shc[tid * kHistCopies + ((k + tid) & (kHistCopies - 1))];      /* rotated: conflict-free */
+    /* The adds are taken WITH their results: a thread that holds the old value knows its add has been performed (device-scope
+     * atomics act on the memory side, as does the exchange that reads the sums below), so after the barrier the block's
+     * share is in place and its ticket may be drawn - without a __threadfence(), which on this part writes the whole L2
+     * back: with two of them per block this kernel took 1.0 ms instead of 0.1. */
+    if(c)
+    {
+      const unsigned int before = atomicAdd(&fs.predHist[tid], c);
+      asm volatile("" :: "v"(before));
+    }
+  }
+  __syncthreads();
+  if(tid == 0)
+    sLast = atomicAdd(&fs.predDone, 1u) == static_cast<unsigned int>(nParts - 1) ? 1 : 0;
+  __syncthreads();
+  if(!sLast)
+    return;
+  /* the frame's sample is complete: sh[1 + bin] (a zero either side) */
+  const unsigned int mineCount = tid < P.nBins ? atomicExch(&fs.predHist[tid], 0u) : 0u;
+  __syncthreads();
+  if(tid < kMaxBins)
+    sh[1 + tid] = mineCount;
+  if(tid == 0)
+    sh[0] = sh[kMaxBins + 1] = 0u;
+  __syncthreads();
+  /* candidate peak: filterPeaks' two conditions (>= 2000 points; twice the count exceeds the neighbours' sum by more than
+   * half the count) on the sample: from 1200 points scaled up, the sharpness as it is plus a few samples.  (A tread stands
+   * far above both thresholds.  Looser - the neighbours' sum below 1.75 counts - and a flat background of a few thousand
+   * points per bin, a wall behind the stairs, passes in every sixth of its bins on sampling noise alone: more candidates
+   * than planes.) */
+  auto candidate = [&](int b) -> bool
+  {
+    if(b < max(minHeight, 1) || b >= P.nBins - 1)
+      return false;
+    const unsigned int c = sh[1 + b], l = sh[b], r = sh[2 + b];
+    return c * kSpecSample >= 1200u && (l + r) * 2u < 3u * c + 16u;
+  };
+  /* at most kMaxPlanes / 3 candidates: the fullest ones (a sampled background still throws up a false peak here and there;
+   * they cost planes and stray raster work, never results) */
+  __shared__ unsigned int sCand[kMaxBins];
+  const bool cand = tid < kMaxBins && sabotage != 2 && candidate(tid);
+  /* The plateau is the peak's bin and the fuller of its neighbours (extractPlateauPoints, pointcloud.cpp:300-335; the upper
+   * one on a tie).  Where the sample leaves no doubt which - one neighbour more than twice the other - the other gets no
+   * plane: it holds no tread, only what lies at that height elsewhere in the image, points that would miss the windows. */
+  unsigned int code = 0u;
+  if(cand)
+  {
+    const unsigned int l = sh[tid], r = sh[2 + tid];
+    code = 1u | (r > 2u * l + 8u ? 0u : 2u) | (l > 2u * r + 8u ? 0u : 4u);        /* chosen | lower neighbour | upper neighbour */
+  }
+  if(tid < kMaxBins)
+    sCand[tid] = cand ? sh[1 + tid] : 0u;
+  __syncthreads();
+  if(tid < kMaxBins)
+  {
+    int fuller = 0;
+    if(cand)
+      for(int b = 0; b < kMaxBins; b++)
+        fuller += (sCand[b] > sCand[tid] || (sCand[b] == sCand[tid] && b < tid)) ? 1 : 0;
+    sh[1 + tid] = cand && fuller < kMaxPlanes / 3 ? code : 0u;        /* the table of chosen peaks, zeros either side as before */
+  }
+  __syncthreads();
+  /* Bins to planes.  A peak whose fuller neighbour is beyond doubt shares ONE plane with it - the plateau's image as k_raster
+   * would make it, the tread's pixels in one window however the range noise deals its points to the two bins; a peak with
+   * neighbours too alike to call gets three planes (its own holds the tread; k_outline reads it together with the
+   * neighbour k_peaks picks).  code(k): the chosen-peak code of bin k (0: none), shifted by the sabotage. */
+  const int shift = sabotage == 1 ? 3 : 0;
+  auto code_of = [&](int k) -> unsigned int
+  {
+    k -= shift;
+    return k >= 0 && k < kMaxBins ? sh[1 + k] : 0u;
+  };
+  bool want = false, start = false;
+  if(tid < kMaxBins)
+  {
+    auto wanted = [&](int k) { return k >= 0 && k < P.nBins && ((code_of(k - 1) & 4u) | (code_of(k) & 1u) | (code_of(k + 1) & 2u)) != 0u; };
+    want = wanted(tid);
+    /* shares the plane of the bin below: the upper neighbour of a peak sure of it, or a peak sure of its lower neighbour */
+    const bool withBelow = want && wanted(tid - 1) && (code_of(tid - 1) == 5u || code_of(tid) == 3u);
+    start = want && !withBelow;
+  }
+  __shared__ unsigned long long sStart[2];
+  if(tid < 2 * 64)
+  {
+    const unsigned long long m = __ballot(start);
+    if((tid & 63) == 0)
+      sStart[tid >> 6] = m;
+  }
+  __syncthreads();
+  const int total = __popcll(sStart[0]) + __popcll(sStart[1]);
+  const bool fits = total <= kMaxPlanes;
+  if(tid < kMaxBins)
+  {
+    /* plane = starts at or below this bin, minus one */
+    const unsigned long long upTo = tid < 64 ? (2ull << tid) - 1ull : ~0ull;
+    const int n = tid < 64 ? __popcll(sStart[0] & upTo) : __popcll(sStart[0]) + __popcll(sStart[1] & ((2ull << (tid - 64)) - 1ull));
+    fs.specPlane[tid] = (want && fits) ? static_cast<unsigned char>(n - 1) : static_cast<unsigned char>(0xff);
+  }
+  if(tid < kMaxPlanes)
+  {
+    fs.planeYMin[tid] = 0x7fffffff; fs.planeYMax[tid] = -1;
+    fs.planeXMin[tid] = 0x7fffffff; fs.planeXMax[tid] = -1;
+    fs.planeTotZ[tid] = 0;
+    fs.planeOob[tid] = 0u;
+    fs.planeUsed[tid] = 0;
+  }
+  if(tid == 0)
+  {
+    fs.nPlanes = fits ? total : 0;
+    fs.predDone = 0u;
+    if(frame == 0)
+      fallback[0] = 0;                     /* k_raster's work list of this batch starts empty (k_peaks appends) */
+  }
+}
+
+/* ========================================================================= */
+/* K1b: peaks, plateaus, LUT — one thread per frame (121 bins: trivial)        */
+
+/* one wave per frame: the histogram is staged in LDS, lane 0 walks it (the peak / plateau logic is a
+ * sequential scan with carried state), all lanes write the tables out */
+__global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__ st, int nframes, DebugFrame *__restrict__ dbg, int spec, int *__restrict__ fallback)
+{
+  __shared__ unsigned char sImgPlane[kMaxStepImages][2];
+  __shared__ int sSpecOk;
+  __shared__ unsigned int hist[kMaxBins + 1];
+  __shared__ unsigned char lut[kMaxBins];
+  __shared__ int plPeak[kMaxPlateaus], plLo[kMaxPlateaus], plHi[kMaxPlateaus], plEffLo[kMaxPlateaus], plEffHi[kMaxPlateaus], plN[kMaxPlateaus];
+  __shared__ int dbgPeaks[kMaxPlateaus];
+  __shared__ int sNPl, sNPeaks, sOverflow, sGround, sFirstStep, sNImg;
+
+  const int frame = blockIdx.x, lane = threadIdx.x;
+  if(frame >= nframes)
+    return;
+  FrameState &fs = st[frame];
+  const int nb = P.nBins;
+
+  unsigned int total = 0;
+  for(int b = lane; b <= kMaxBins; b += 64)
+  {
+    /* K1's accumulator is taken over and left zero for the next call (FrameState::histAcc) */
+    const unsigned int v = b < nb ? fs.histAcc[b] : 0u;
+    hist[b] = v;
+    total += v;
+    if(b < kMaxBins)
+    {
+      lut[b] = 0xff;
+      fs.hist[b] = v;
+      if(b < nb)
+        fs.histAcc[b] = 0u;
+    }
+  }
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1)
+    total += __shfl_xor(total, o);
+  __syncthreads();
+
+  /* findPeaks (pointcloud.cpp:214-241) + filterPeaks (:243-256), all lanes: lane l looks at bins l and l + 64.  The
+   * reference walks the bins with one carried flag: a bin is a peak when the count falls after it and the last CHANGE
+   * before it was a rise (so a flat top reports its last index, quirk Q1).  Here: rise / fall bits of all bins by two
+   * ballots each, then "the highest changed bin below me is a rise" by bit scans. */
+  unsigned long long peakBits[2];
+  {
+    unsigned long long up[2], down[2];
+#pragma unroll
+    for(int w = 0; w < 2; w++)
+    {
+      const int i = lane + 64 * w;
+      const bool inRange = i < nb - 1;
+      const unsigned int c = hist[min(i, kMaxBins - 1)], succ = hist[min(i + 1, kMaxBins)];
+      up[w] = __ballot(inRange && c < succ);
+      down[w] = __ballot(inRange && c > succ);
+    }
+    const unsigned long long changed[2] = { up[0] | down[0], up[1] | down[1] };
+#pragma unroll
+    for(int w = 0; w < 2; w++)
+    {
+      const int i = lane + 64 * w;
+      bool peak = false;
+      if((down[w] >> lane) & 1ull)
+      {
+        const unsigned long long below = changed[w] & ((1ull << lane) - 1ull);
+        bool lastWasRise = false;
+        if(below)
+          lastWasRise = (up[w] >> (63 - __clzll(static_cast<long long>(below)))) & 1ull;
+        else if(w == 1 && changed[0])
+          lastWasRise = (up[0] >> (63 - __clzll(static_cast<long long>(changed[0])))) & 1ull;
+        if(lastWasRise)
+        {
+          const unsigned int np = hist[i];
+          peak = np >= 2000u && (np * 2u - hist[i - 1] - hist[i + 1]) * 2u > np;     /* filterPeaks; i >= 1 after a rise */
+        }
+      }
+      peakBits[w] = __ballot(peak);
+    }
+  }
+
+  if(lane == 0)
+  {
+    int nPl = 0;
+    int consumedUpTo = -1;           /* every bin <= this has already left pointsHt */
+    bool overflow = false;
+    int nPeaksDbg = 0;
+    for(int w = 0; w < 2; w++)
+      for(unsigned long long bits = peakBits[w]; bits; bits &= bits - 1ull)
+      {
+        const int i = 64 * w + __ffsll(static_cast<long long>(bits)) - 1;
+        const unsigned int succ = hist[i + 1];
+        if(nPeaksDbg < kMaxPlateaus)
+          dbgPeaks[nPeaksDbg] = i;
+        nPeaksDbg++;
+        if(nPl >= kMaxPlateaus)
+          overflow = true;
+        else
+        {
+          /* extractPlateauPoints (:300-335): choose the pair, then take what is left of it */
+          int hMin, hMax;
+          if(hist[i - 1] > succ) { hMin = i - 1; hMax = i; }
+          else { hMin = i; hMax = i + 1; }
+          int lo, hi;
+          if(hMin == 0)
+          {
+            /* quirk Q4: Height_t(heightMin - 1) wraps to 65535: everything goes to the remainder */
+            lo = 1; hi = 0;
+            consumedUpTo = nb;
+          }
+          else
+          {
+            lo = max(hMin, consumedUpTo + 1);
+            hi = hMax;
+            consumedUpTo = max(consumedUpTo, hMax);
+          }
+          unsigned int cnt = 0;
+          for(int b = lo; b <= hi; b++)
+          {
+            cnt += hist[b];
+            lut[b] = static_cast<unsigned char>(nPl);
+          }
+          plPeak[nPl] = i; plLo[nPl] = hMin; plHi[nPl] = hMax; plEffLo[nPl] = lo; plEffHi[nPl] = hi;
+          plN[nPl] = static_cast<int>(cnt);
+          nPl++;
+        }
+      }
+
+    /* ground = most populous plateau below minHeight (pointcloud.cpp:402-418) */
+    int groundInd = -1, i = 0;
+    unsigned int maxGround = 0;
+    for( ; i < nPl; i++)
+    {
+      if(plPeak[i] >= P.minHeight)
+        break;
+      if(maxGround < static_cast<unsigned int>(plN[i]))
+      {
+        maxGround = static_cast<unsigned int>(plN[i]);
+        groundInd = i;
+      }
+    }
+    int nImg = nPl - i;
+    if(nImg > P.maxStepImages)
+    {
+      nImg = P.maxStepImages;
+      overflow = true;
+    }
+    sNPl = nPl; sNPeaks = nPeaksDbg; sOverflow = overflow ? 1 : 0; sGround = groundInd; sFirstStep = i; sNImg = nImg;
+
+    /* single pass: did k_predict give every bin of every step plateau a plane?  (A bin without points needs none.) */
+    bool ok = spec != 0;
+    for(int slot = 0; slot < nImg; slot++)
+    {
+      unsigned char a = 0xff, b2 = 0xff;
+      const int lo = plEffLo[i + slot], hi = plEffHi[i + slot];
+      for(int b = lo; b <= hi; b++)                                        /* two bins at most */
+      {
+        const unsigned char p = spec ? fs.specPlane[b] : static_cast<unsigned char>(0xff);
+        if(p == 0xff)
+          ok = ok && hist[b] == 0u;
+        else if(a == 0xff)
+          a = p;
+        else if(p != a)
+          b2 = p;
+      }
+      /* a plane may hold two bins (k_predict): it must not bring points of a bin outside the plateau */
+      if(spec && lo <= hi)
+      {
+        if(lo > 0 && fs.specPlane[lo - 1] != 0xff && (fs.specPlane[lo - 1] == a || fs.specPlane[lo - 1] == b2))
+          ok = ok && hist[lo - 1] == 0u;
+        if(hi + 1 < nb && fs.specPlane[hi + 1] != 0xff && (fs.specPlane[hi + 1] == a || fs.specPlane[hi + 1] == b2))
+          ok = ok && hist[hi + 1] == 0u;
+      }
+      sImgPlane[slot][0] = a; sImgPlane[slot][1] = b2;
+    }
+    sSpecOk = ok ? 1 : 0;
+  }
+  __syncthreads();
+
+  const int nPl = sNPl, firstStep = sFirstStep, nImg = sNImg;
+  unsigned int wanted = 0u;
+  for(int b = lane; b < kMaxBins; b += 64)
+  {
+    const unsigned char l = lut[b];
+    fs.lut[b] = l;
+    const int slot = static_cast<int>(l) - firstStep;
+    if(b < nb && l != 0xff && slot >= 0 && slot < nImg)
+      wanted |= 1u << (b / kBinsPerGroup);
+  }
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1)
+    wanted |= __shfl_xor(wanted, o);
+  if(lane < nPl)
+  {
+    PlateauState &pl = fs.pl[lane];
+    pl.peakBin = plPeak[lane];
+    pl.binLo = plLo[lane];
+    pl.binHi = plHi[lane];
+    pl.effLo = plEffLo[lane];
+    pl.effHi = plEffHi[lane];
+    pl.nPoints = plN[lane];
+    pl.isStep = plPeak[lane] >= P.minHeight ? 1 : 0;
+    pl.outlineFound = 0;
+    pl.valid = 0;
+    for(int k = 0; k < 8; k++) { pl.quadImg[k] = 0.0; pl.quadWorld[k] = 0.0; }
+  }
+  /* The step images' boxes and z sums: empty / zero for k_raster to fill, or - single pass, every plateau covered - what
+   * k_hist found in the planes of the plateau's bins (k_outline merges those planes into the image). */
+  const bool specOk = sSpecOk != 0;
+  unsigned int oobSum = 0u;
+  if(lane <= kMaxStepImages)                          /* [kMaxStepImages] = the ground image */
+  {
+    int y0 = 0x7fffffff, y1 = -1, x0 = 0x7fffffff, x1 = -1;
+    long long tz = 0;
+    if(specOk && lane < nImg)
+    {
+#pragma unroll
+      for(int k = 0; k < 2; k++)
+      {
+        const int p = sImgPlane[lane][k];
+        if(p == 0xff)
+          continue;
+        if(fs.planeYMax[p] >= fs.planeYMin[p])
+        {
+          y0 = min(y0, fs.planeYMin[p]); y1 = max(y1, fs.planeYMax[p]);
+          x0 = min(x0, fs.planeXMin[p]); x1 = max(x1, fs.planeXMax[p]);
+        }
+        tz += fs.planeTotZ[p];
+        oobSum += fs.planeOob[p];
+      }
+    }
+    fs.imgYMin[lane] = y0; fs.imgYMax[lane] = y1;
+    fs.imgXMin[lane] = x0; fs.imgXMax[lane] = x1;
+    if(lane < kMaxStepImages)
+    {
+      fs.totZ[lane] = tz;                              /* k_raster's sums start from zero */
+      fs.imgPlane[lane][0] = specOk && lane < nImg ? sImgPlane[lane][0] : static_cast<unsigned char>(0xff);
+      fs.imgPlane[lane][1] = specOk && lane < nImg ? sImgPlane[lane][1] : static_cast<unsigned char>(0xff);
+    }
+  }
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1)
+    oobSum += __shfl_xor(oobSum, o);
+  if(spec && lane < kMaxPlanes)
+  {
+    bool used = false;
+    if(specOk)
+      for(int sl = 0; sl < nImg; sl++)
+        used = used || sImgPlane[sl][0] == lane || sImgPlane[sl][1] == lane;
+    fs.planeUsed[lane] = used ? 1 : 0;
+  }
+  if(lane == 0)
+  {
+    if(spec && !specOk && nImg > 0)
+      fallback[1 + atomicAdd(&fallback[0], 1)] = frame;          /* k_raster's work list (k_predict zeroed the count) */
+    fs.specOk = specOk ? 1 : 0;
+    fs.nNonZero = fs.nNonZeroAcc;
+    fs.nNonZeroAcc = 0u;
+    fs.nOob = oobSum;
+    fs.status = (sOverflow ? static_cast<unsigned int>(SSD_ST_OVERFLOW) : 0u) | (oobSum ? static_cast<unsigned int>(SSD_ST_OOB_PIXEL) : 0u);     /* the frame's status starts here */
+    fs.nInRange = total;
+    fs.nPlateaus = nPl;
+    fs.groundInd = sGround;
+    fs.firstStep = firstStep;
+    fs.nStepImages = nImg;
+    fs.firstValidInd = -1;
+    fs.wantedSteps = wanted;
+    fs.wantedQuads = 0u;
+    fs.anyActive = 0u;
+  }
+
+  if(dbg)
+  {
+    ssd_debug_frame &d = dbg[frame].d;
+    for(int b = lane; b < kMaxBins; b += 64)
+      d.hist[b] = hist[b];
+    if(lane < min(sNPeaks, kMaxPlateaus))
+      d.peaks[lane] = dbgPeaks[lane];
+    if(lane < nPl)
+    {
+      ssd_debug_plateau &p = d.plateaus[lane];
+      p.peak_bin = plPeak[lane]; p.bin_lo = plLo[lane]; p.bin_hi = plHi[lane];
+      p.eff_lo = plEffLo[lane]; p.eff_hi = plEffHi[lane];
+      p.n_points = plN[lane];
+      p.is_step = plPeak[lane] >= P.minHeight ? 1 : 0;
+    }
+    if(lane == 0)
+    {
+      d.n_nonzero = static_cast<int>(fs.nNonZero);
+      d.n_inrange = static_cast<int>(total);
+      d.n_bins = nb;
+      d.min_height = P.minHeight;
+      d.min_img_y_extent = P.minImgYExtent;
+      d.n_peaks = sNPeaks;
+      d.n_plateaus = nPl;
+      d.first_step = firstStep;
+      d.ground_ind = sGround;
+    }
+  }
+}
+
+/* ========================================================================= */
+/* K2: raster the step plateaus into bit images                               */
+
 struct RasterLds
 {
   unsigned long long wins[kThreads / 64][kWinWords];
@@ -980,7 +1472,7 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
   const int firstStep = fs.firstStep;
   const unsigned char lutMine = tid < kMaxBins ? fs.lut[tid] : static_cast<unsigned char>(0xff);
   const unsigned int wantedSteps = fs.wantedSteps;
-  if(nImg == 0)
+  if(nImg == 0 || fs.specOk)                 /* single pass: k_hist has rastered this frame's plateaus already */
     return;
   BlockPhase ph(0);
   if(tid < kMaxBins)
@@ -1109,13 +1601,26 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
   ph.finish();
 }
 
+/* fallback != nullptr (single pass): the grid's x blocks share the frames k_peaks listed there (count, then frame indices) - the
+ * frames whose step plateaus the planes did not cover; none, as a rule, and then every block leaves after one cached load */
 template<int SRC>
 __global__ __launch_bounds__(kThreads, SSD_K2_WAVES) void k_raster(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                         PixelParams X, FrameState *__restrict__ st,
                                                         unsigned long long *__restrict__ stepImg,
-                                                        const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
+                                                        const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D,
+                                                        const int *__restrict__ fallback)
 {
   __shared__ RasterLds L;
+  if(fallback)
+  {
+    const int n = fallback[0];
+    for(int e = blockIdx.x; e < n; e += gridDim.x)
+    {
+      raster_block<SRC>(L, xyz, strideFloats, P, X, st, stepImg, tileMasks, tileMaskStride, chunkPoints, D, fallback[1 + e], blockIdx.y);
+      __syncthreads();
+    }
+    return;
+  }
   raster_block<SRC>(L, xyz, strideFloats, P, X, st, stepImg, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
 }
 
@@ -1242,6 +1747,7 @@ struct OutlineShared
 template<int T>
 __global__ __launch_bounds__(T) void k_outline(Params P, FrameState *__restrict__ st,
                                                       unsigned long long *__restrict__ stepImg,
+                                                      unsigned long long *__restrict__ planeImg,
                                                       DebugFrame *__restrict__ dbg,
                                                       unsigned long long *__restrict__ dbgImg)
 {
@@ -1249,15 +1755,55 @@ __global__ __launch_bounds__(T) void k_outline(Params P, FrameState *__restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int slot = blockIdx.y, frame = blockIdx.x;
   FrameState &fs = st[frame];
+  const size_t imgWords = static_cast<size_t>(P.H) * P.W64;
+  if(planeImg)
+  {
+    /* single pass: the planes no step image is made of (bins beside a plateau; every plane of a frame that k_raster had to
+     * do) are cleared where k_hist set bits, and their boxes emptied - by the frame's blocks that have no image to work on */
+    const int nBusy = min(fs.nStepImages, static_cast<int>(gridDim.y));
+    const bool everyone = nBusy >= static_cast<int>(gridDim.y);              /* no block without an image: all share the duty */
+    const int pFirst = everyone ? slot : slot - nBusy, pStep = everyone ? static_cast<int>(gridDim.y) : static_cast<int>(gridDim.y) - nBusy;
+    for(int p = pFirst < 0 ? fs.nPlanes : pFirst; p < fs.nPlanes; p += pStep)
+    {
+      if(fs.planeUsed[p])
+        continue;
+      const int y0 = fs.planeYMin[p], y1 = fs.planeYMax[p], c0 = fs.planeXMin[p], c1 = fs.planeXMax[p];
+      if(y1 < y0)
+        continue;
+      unsigned long long *pi = planeImg + (static_cast<size_t>(frame) * kMaxPlanes + p) * imgWords;
+      const int bw = c1 - c0 + 1, n = bw * (y1 - y0 + 1);
+      for(int t = tid; t < n; t += T)
+      {
+        const int y = y0 + t / bw, c = c0 + t % bw;
+        pi[static_cast<size_t>(y) * P.W64 + c] = 0ull;
+      }
+      __syncthreads();                               /* everybody has read the box */
+      if(tid == 0)
+      {
+        fs.planeYMin[p] = 0x7fffffff; fs.planeYMax[p] = -1;
+        fs.planeXMin[p] = 0x7fffffff; fs.planeXMax[p] = -1;
+      }
+    }
+  }
   if(slot >= fs.nStepImages)
     return;
   const int plIdx = fs.firstStep + slot;
   PlateauState &pl = fs.pl[plIdx];
   ssd_debug_plateau *dp = dbg ? &dbg[frame].d.plateaus[plIdx] : nullptr;
 
-  const size_t imgWords = static_cast<size_t>(P.H) * P.W64;
+  /* The raw image: the step image k_raster filled, or - single pass, the frame's plateaus covered - the planes of the
+   * plateau's (two) bins, read together (BitImg::w2).  Its box (k_peaks) is the union of the planes' boxes. */
   unsigned long long *img = stepImg + (static_cast<size_t>(frame) * P.maxStepImages + slot) * imgWords;
-  const BitImg im{ img, P.W, P.H, P.W64 };
+  unsigned long long *img2 = nullptr;
+  if(planeImg && fs.specOk)
+  {
+    const int pa = fs.imgPlane[slot][0], pb = fs.imgPlane[slot][1];
+    if(pa != 0xff)
+      img = planeImg + (static_cast<size_t>(frame) * kMaxPlanes + pa) * imgWords;
+    if(pb != 0xff)
+      img2 = planeImg + (static_cast<size_t>(frame) * kMaxPlanes + pb) * imgWords;
+  }
+  const BitImg im{ img, P.W, P.H, P.W64, img2 };
   SSD_PHASE(0, 0);
 
   /* scan columns: x_j = xr0 + 25 j; the centre column xc = W/2 is j = jc */
@@ -1315,7 +1861,7 @@ __global__ __launch_bounds__(T) void k_outline(Params P, FrameState *__restrict_
       const int yA = by0 + band * bandRows, yB = min(yA + bandRows, by1 + 1);
       closed_column(im, c, yA, yB, true, [&](int y, unsigned long long cw)
       {
-        dbgRaw[y * P.W64 + c] = img[y * P.W64 + c];
+        dbgRaw[y * P.W64 + c] = raw_word(im, y, c);
         dbgClosed[y * P.W64 + c] = cw;
       });
     }
@@ -1754,6 +2300,18 @@ __global__ __launch_bounds__(T) void k_outline(Params P, FrameState *__restrict_
       const int ry = idx / cw;
       const size_t o = static_cast<size_t>(cy0 + ry) * P.W64 + cc0 + (idx - ry * cw);
       img[o] = 0ull;                                 /* unconditionally: a load first would make every word a round trip */
+      if(img2)
+        img2[o] = 0ull;
+    }
+    if(planeImg && fs.specOk && tid < 2)
+    {
+      /* the planes' boxes go with their bits (k_predict resets them as well; this keeps "box empty = plane zero" at all times) */
+      const int p = fs.imgPlane[slot][tid];
+      if(p != 0xff)
+      {
+        fs.planeYMin[p] = 0x7fffffff; fs.planeYMax[p] = -1;
+        fs.planeXMin[p] = 0x7fffffff; fs.planeXMax[p] = -1;
+      }
     }
   }
   SSD_PHASE(0, 11);
@@ -2892,9 +3450,29 @@ static inline bool aligned16(const float *xyz, size_t strideFloats, int nPoints)
 }
 
 void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, uint2 *tileMasks, size_t tileMaskStride,
-                 int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
+                 int nframes, int chunkPoints, const DepthSrc *depth, unsigned long long *planeImg, int *fallback, int sabotage, hipStream_t s)
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
+  if(planeImg)
+  {
+    dim3 pgrid(nframes, kPredictParts);
+    if(depth)
+    {
+      hipLaunchKernelGGL(k_predict<kSrcDepth16>, pgrid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, *depth, P.minHeight, sabotage, fallback);
+      hipLaunchKernelGGL(k_hist_planes<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, *depth);
+    }
+    else if(aligned16(xyz, strideFloats, P.nPoints))
+    {
+      hipLaunchKernelGGL(k_predict<kSrcF3Aligned>, pgrid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, DepthSrc{}, P.minHeight, sabotage, fallback);
+      hipLaunchKernelGGL(k_hist_planes<kSrcF3Aligned>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, DepthSrc{});
+    }
+    else
+    {
+      hipLaunchKernelGGL(k_predict<kSrcF3>, pgrid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, DepthSrc{}, P.minHeight, sabotage, fallback);
+      hipLaunchKernelGGL(k_hist_planes<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, DepthSrc{});
+    }
+    return;
+  }
   if(depth)
     hipLaunchKernelGGL(k_hist<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, tileMasks, tileMaskStride, chunkPoints, *depth);
   else if(aligned16(xyz, strideFloats, P.nPoints))
@@ -2902,29 +3480,29 @@ void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameSt
   else
     hipLaunchKernelGGL(k_hist<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
 }
-void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s)
+void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, int *fallback, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_peaks, dim3(nframes), dim3(64), 0, s, P, st, nframes, dbg);
+  hipLaunchKernelGGL(k_peaks, dim3(nframes), dim3(64), 0, s, P, st, nframes, dbg, fallback ? 1 : 0, fallback);
 }
 void launch_raster(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *stepImg,
-                   const uint2 *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s)
+                   const uint2 *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, const int *fallback, hipStream_t s)
 {
-  dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
+  dim3 grid(fallback ? (nframes + 3) / 4 : nframes, chunks_for(P.nPoints, chunkPoints));
   if(depth)
-    hipLaunchKernelGGL(k_raster<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints, *depth);
+    hipLaunchKernelGGL(k_raster<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints, *depth, fallback);
   else if(aligned16(xyz, strideFloats, P.nPoints))
-    hipLaunchKernelGGL(k_raster<kSrcF3Aligned>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
+    hipLaunchKernelGGL(k_raster<kSrcF3Aligned>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints, DepthSrc{}, fallback);
   else
-    hipLaunchKernelGGL(k_raster<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
+    hipLaunchKernelGGL(k_raster<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints, DepthSrc{}, fallback);
 }
-void launch_outline(const Params &P, FrameState *st, unsigned long long *stepImg, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
+void launch_outline(const Params &P, FrameState *st, unsigned long long *stepImg, unsigned long long *planeImg, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
 {
   dim3 grid(nframes, P.maxStepImages);
   /* while every image has a CU of its own, the block that gets through its phases soonest; beyond that the cheapest */
   if(nframes <= kImgFewFrames)
-    hipLaunchKernelGGL(k_outline<kImgThreadsFew>, grid, dim3(kImgThreadsFew), 0, s, P, st, stepImg, dbg, dbgImg);
+    hipLaunchKernelGGL(k_outline<kImgThreadsFew>, grid, dim3(kImgThreadsFew), 0, s, P, st, stepImg, planeImg, dbg, dbgImg);
   else
-    hipLaunchKernelGGL(k_outline<kImgThreadsBatch>, grid, dim3(kImgThreadsBatch), 0, s, P, st, stepImg, dbg, dbgImg);
+    hipLaunchKernelGGL(k_outline<kImgThreadsBatch>, grid, dim3(kImgThreadsBatch), 0, s, P, st, stepImg, planeImg, dbg, dbgImg);
 }
 void launch_quads(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s)
 {

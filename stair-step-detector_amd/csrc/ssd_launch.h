@@ -13,13 +13,21 @@ constexpr int kMaxTilesPerBlockHost = 32;
 constexpr int kMaxTilesPerBlockRasterHost = 128;   /* K2 only */
 constexpr int kMaxTilesPerBlockInquadHost = 128;   /* K4 only */
 constexpr int kCellHost = 64;               /* points per cell (one gating mask each) */
+/* The single pass (k_hist rasters the step plateaus itself) needs each wave of K1 to stay in one band of
+ * camera columns from tile to tile - a tile (1024 points) is a whole number of camera rows - and pays a kernel (k_predict)
+ * that a few frames do not earn back. */
+constexpr int kSinglePassMinFrames = 64;
+constexpr int kPredictParts = 4;            /* blocks of k_predict per frame */
+inline bool single_pass_geometry(int W, int H) { return W >= 64 && kTileHost % W == 0 && H >= 16 && H <= 4096; }
 
+/* planeImg != nullptr: the single pass (k_predict, then K1 rastering the candidate bins' planes); fallback: the batch's list of
+ * frames for k_raster (count, indices; k_predict resets, k_peaks appends, k_raster reads); sabotage: see k_predict */
 void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, uint2 *tileMasks, size_t tileMaskStride,
-                 int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s);
-void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s);
+                 int nframes, int chunkPoints, const DepthSrc *depth, unsigned long long *planeImg, int *fallback, int sabotage, hipStream_t s);
+void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, int *fallback, hipStream_t s);
 void launch_raster(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *stepImg,
-                   const uint2 *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s);
-void launch_outline(const Params &P, FrameState *st, unsigned long long *stepImg, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s);
+                   const uint2 *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, const int *fallback, hipStream_t s);
+void launch_outline(const Params &P, FrameState *st, unsigned long long *stepImg, unsigned long long *planeImg, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s);
 void launch_quads(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, hipStream_t s);
 void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *groundImg,
                    const uint2 *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, hipStream_t s);

@@ -4,6 +4,7 @@
  * and evaluate it, a frame's raw device state).  C ABI in include/ssd_testhooks.h.  Not part of the product ABI.
  */
 #include "ssd_handle.h"
+#include "ssd_launch.h"
 #include "ssd_math.h"
 #include "ssd_quadtest.h"
 #include "ssd_closing.h"
@@ -12,6 +13,7 @@
 #include "../../include/ssd_testhooks.h"
 
 #include <cstddef>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -254,6 +256,73 @@ int ssd_test_empty_quadrilateral(ssd_handle *h, int frame, int surface)
   }
   HIP_TRY(hipMemcpy(&d->sumZ[acc], &fs.sumZ[acc], sizeof(fs.sumZ[acc]), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(&d->cnt[acc], &fs.cnt[acc], sizeof(fs.cnt[acc]), hipMemcpyHostToDevice));
+  return SSD_OK;
+}
+
+int ssd_test_single_pass(ssd_handle *h, int mode, int sabotage)
+{
+  if(!h || mode < -1 || mode > 1 || sabotage < 0 || sabotage > 2)
+    return fail(SSD_E_ARG, "ssd_test_single_pass: bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  if(mode == 1)
+  {
+    if(!single_pass_geometry(h->P.W, h->P.H))
+      return fail(SSD_E_ARG, "ssd_test_single_pass: a tile of 1024 points is not a whole number of this geometry's camera rows");
+    const size_t planeBytes = static_cast<size_t>(h->F) * kMaxPlanes * h->imgWords * 8;
+    for(int k = 0; k < h->depth; k++)
+      if(!h->lane[k].dPlaneImg)
+      {
+        HIP_TRY(hipMalloc(&h->lane[k].dPlaneImg, planeBytes));
+        HIP_TRY(hipMemset(h->lane[k].dPlaneImg, 0, planeBytes));
+        HIP_TRY(hipMalloc(&h->lane[k].dFallback, sizeof(int) * (1 + static_cast<size_t>(h->F))));
+        HIP_TRY(hipMemset(h->lane[k].dFallback, 0, sizeof(int) * (1 + static_cast<size_t>(h->F))));
+      }
+  }
+  h->singlePassMode = mode;
+  h->singlePassSabotage = sabotage;
+  return SSD_OK;
+}
+
+int ssd_test_single_pass_stats(ssd_handle *h, int frames, long long counts[4])
+{
+  if(!h || !counts || frames < 0 || frames > h->F)
+    return fail(SSD_E_ARG, "ssd_test_single_pass_stats: bad argument");
+  counts[0] = counts[1] = counts[2] = counts[3] = 0;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const ssd_lane &L = h->lane[h->lastLane];
+  if(L.dPlaneImg)
+  {
+    const size_t words = static_cast<size_t>(h->F) * kMaxPlanes * h->imgWords;
+    std::vector<unsigned long long> img(words);
+    HIP_TRY(hipMemcpy(img.data(), L.dPlaneImg, words * 8, hipMemcpyDeviceToHost));
+    for(const unsigned long long w : img)
+      counts[3] += w != 0ull;
+  }
+  if(!h->lastSinglePass)
+    return 0;
+  std::vector<FrameState> st(static_cast<size_t>(frames));
+  HIP_TRY(hipMemcpy(st.data(), L.dState, sizeof(FrameState) * st.size(), hipMemcpyDeviceToHost));
+  for(const FrameState &fs : st)
+  {
+    counts[0] += fs.nStepImages > 0 && fs.specOk;
+    counts[1] += fs.nStepImages > 0;
+    counts[2] += fs.nPlanes;
+  }
+  return 1;
+}
+
+int ssd_test_single_pass_frame(ssd_handle *h, int frame, uint8_t *plane_of_bin, int info[3])
+{
+  if(!h || !plane_of_bin || !info || frame < 0 || frame >= h->F)
+    return fail(SSD_E_ARG, "ssd_test_single_pass_frame: bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  FrameState fs;
+  HIP_TRY(hipMemcpy(&fs, h->lane[h->lastLane].dState + frame, sizeof(fs), hipMemcpyDeviceToHost));
+  std::memcpy(plane_of_bin, fs.specPlane, kMaxBins);
+  info[0] = fs.nPlanes; info[1] = fs.specOk; info[2] = fs.nStepImages;
   return SSD_OK;
 }
 

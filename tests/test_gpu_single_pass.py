@@ -1,0 +1,108 @@
+"""The single pass: K1 rasters the step plateaus itself, into planes of the height bins a sampled histogram (k_predict) expects them
+in; k_peaks checks the planes against the plateaus of the complete histogram frame by frame, and k_raster does the frames they do
+not cover.  Whatever the predictor says, the results are those of the two-pass pipeline, bit for bit, and the planes are left
+zero."""
+import numpy as np
+import pytest
+
+import parity
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(det, buf, n):
+    det.enqueue(buf.ptr, n)
+    return [bytes(x) for x in det.fetch_list(n)]
+
+
+def _batch(ssd, gpu_device, W, H, n, base_seed, rng_seed):
+    sc = scenes.batch_scenes(ssd, W, H, n, base_seed=base_seed, rng_seed=rng_seed)
+    buf = ssd.DeviceBuffer(W * H * 12 * n, gpu_device)
+    ssd.synth_device(sc, buf.ptr, device=gpu_device)
+    return sc, buf
+
+
+def test_single_pass_covers_the_batch_and_matches_the_two_pass_pipeline(ssd, oracle, gpu_device):
+    """256 XGA staircase frames: the default handle runs the single pass on them (a batch of >= 64 frames), the predictor covers
+    nearly every frame, the planes are zero afterwards, and the results equal those of the same handle with the single pass
+    switched off - and the oracle's, every frame."""
+    W, H, n = 1024, 768, 256
+    sc, buf = _batch(ssd, gpu_device, W, H, n, 41000, 41)
+    trans = ssd.transformation_for_scene(sc[0])
+    cfg = ssd.default_config(W, H, max_frames_per_batch=n)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    single = _run(det, buf, n)
+    st = det.single_pass_stats(n)
+    assert st["ran"] and st["dirty_words"] == 0
+    assert st["with_steps"] >= n * 9 // 10
+    assert st["covered"] >= st["with_steps"] * 9 // 10, st
+    assert st["with_steps"] <= st["planes"] <= ssd.MAX_PLANES * n
+    assert _run(det, buf, n) == single                       # the planes and their boxes were left clean
+    det.single_pass(0)
+    assert _run(det, buf, n) == single
+    assert not det.single_pass_stats(n)["ran"]
+    det.single_pass(-1)
+    det.enqueue(buf.ptr, n)
+    res = det.fetch_list(n)
+    assert parity.check_batch_against_oracle(ssd, oracle, cfg, trans.constants, buf, W * H * 12, res, W, H) == n
+    det.close()
+    buf.free()
+
+
+@pytest.mark.parametrize("sabotage", [1, 2])
+def test_a_wrong_predictor_costs_time_not_results(ssd, gpu_device, sabotage):
+    """k_predict sabotaged (its planes three bins above the right ones / no planes at all): K1 rasters the wrong bins or nothing,
+    k_peaks finds the plateaus uncovered, k_raster does every frame, k_outline clears the stray planes."""
+    W, H, n = 1024, 768, 128
+    sc, buf = _batch(ssd, gpu_device, W, H, n, 42000, 42)
+    det = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=n), ssd.transformation_for_scene(sc[0]), gpu_device)
+    det.single_pass(0)
+    two_pass = _run(det, buf, n)
+    det.single_pass(-1, sabotage)
+    assert _run(det, buf, n) == two_pass
+    st = det.single_pass_stats(n)
+    assert st["ran"] and st["dirty_words"] == 0 and st["with_steps"] >= n * 9 // 10
+    assert st["covered"] == 0 if sabotage == 2 else st["covered"] < st["with_steps"] // 4, st
+    assert (st["planes"] == 0) == (sabotage == 2)
+    det.single_pass(-1, 0)
+    assert _run(det, buf, n) == two_pass
+    assert det.single_pass_stats(n)["covered"] >= st["with_steps"] * 9 // 10
+    det.close()
+    buf.free()
+
+
+@pytest.mark.parametrize("W,H", [(1024, 768), (512, 384), (256, 192)])
+def test_single_pass_forced_on_small_batches(ssd, oracle, gpu_device, W, H):
+    """Geometries whose tile of 1024 points is one, two or four camera rows, 12 frames with the single pass forced on (the product
+    only takes it for batches of 64 and more), every frame with its images against the oracle."""
+    n = 12
+    sc, buf = _batch(ssd, gpu_device, W, H, n, 43000 + W, 43)
+    trans = ssd.transformation_for_scene(sc[0])
+    cfg = ssd.default_config(W, H, max_frames_per_batch=n)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    det.single_pass(0)
+    two_pass = _run(det, buf, n)
+    det.single_pass(1)
+    assert _run(det, buf, n) == two_pass
+    st = det.single_pass_stats(n)
+    assert st["ran"] and st["dirty_words"] == 0
+    det.enqueue(buf.ptr, n)
+    res = det.fetch_list(n)
+    assert parity.check_batch_against_oracle(ssd, oracle, cfg, trans.constants, buf, W * H * 12, res, W, H) == n
+    det.close()
+    buf.free()
+
+
+def test_geometry_without_whole_rows_per_tile_stays_two_pass(ssd, gpu_device):
+    """640 x 480: a tile is 1.6 camera rows, a wave of K1 would hop between column bands - the handle has no planes, the hook
+    refuses to force them"""
+    W, H, n = 640, 480, 64
+    sc, buf = _batch(ssd, gpu_device, W, H, n, 44000, 44)
+    det = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=n), ssd.transformation_for_scene(sc[0]), gpu_device)
+    _run(det, buf, n)
+    assert not det.single_pass_stats(n)["ran"]
+    with pytest.raises(ssd.SsdError):
+        det.single_pass(1)
+    det.close()
+    buf.free()
