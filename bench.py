@@ -203,6 +203,7 @@ def main():
                     help="workspaces of the handle (ssd_config::batches_in_flight), asked for explicitly: 3 = SSD_BATCHES_IN_FLIGHT_THROUGHPUT "
                          "(the bench enqueues ahead of its fetches); 1 (or 0, the library's default) = strictly one batch at a time in stream "
                          "order — what the profiling passes use, so that a kernel's traced duration is its own")
+    ap.add_argument("--two-pass", action="store_true", help="A/B: switch the single pass off (test hook; K1 then k_raster over every frame, as before round 4's single pass)")
     ap.add_argument("--prewarm-seconds", type=float, default=0.5,
                     help="untimed load in front of the W warm-up steps (an idle device needs more than a few steps to reach its clocks)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -257,6 +258,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     det = ssd.Detector(cfg, trans, device)
     depth = det.batches_in_flight
+    if args.two_pass:
+        det.single_pass(0)
     if args.risers:
         det.set_risers(True, tolerance=0.03, min_support=200)
     intr = ssd.intrinsics_for_scene(sc_list[0])
@@ -319,6 +322,7 @@ def main():
     stream_ms = [ssd.stream_read_ms(frames.data_ptr(), F * frame_bytes, reps=5, device=device)] if not depth_in else []
     stage = {k: 0.0 for k in ssd.STAGE_NAMES}
     per_pass = []
+    predict_ms = 0.0
     for b in range(n_extra + 1):
         c0 = time.perf_counter()
         enqueue()
@@ -327,6 +331,8 @@ def main():
             per_pass.append((time.perf_counter() - c0) * 1e3)
             for k, v in det.stage_times_ms().items():
                 stage[k] += v / n_extra
+            predict_ms += det.predict_time_ms() / n_extra
+    single_pass = det.single_pass_stats(F, scan_planes=False)     # of the last pass: did K1 raster the step plateaus itself, for how many frames
     one_at_a_time_ms = sorted(per_pass)[len(per_pass) // 2]      # median: a host hiccup in one pass is not the handle's rate
     if not depth_in:
         stream_ms.append(ssd.stream_read_ms(frames.data_ptr(), F * frame_bytes, reps=5, device=device))
@@ -338,7 +344,7 @@ def main():
     k1_ms = stage["hist"]
     alg_bytes = (2.0 if depth_in else 12.0) * W * H * F    # 12 B per raw point (2 B per depth pixel), read once
     mine = {"rank": rank, "device": device, "where": where, "frames": [lo, hi], "seconds": dt, "steps_found": int(sum(r.n_steps for r in res)),
-            "stage_ms": stage, "k1_frac_of_hbm_peak": (alg_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k1_ms > 0 else 0.0,
+            "stage_ms": stage, "predict_ms": predict_ms, "k1_frac_of_hbm_peak": (alg_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k1_ms > 0 else 0.0,
             "one_batch_at_a_time_ms": one_at_a_time_ms}
     if world > 1 and not args.no_cpu:
         import oracle_binding as ob
@@ -412,7 +418,9 @@ def main():
                                     "tread/yaw/noise) resident in HBM, streamed through the whole per-frame path; per GPU") % (F, W, H),
                        "frames_per_gpu_per_step": F, "width": W, "height": H, "input": args.input, "risers": bool(args.risers),
                        "batches_in_flight": depth, "parallelism": "frame-sharded x%d, no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_hist (K1: transform+crop+bin+histogram)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": ("k_hist_planes (K1 of the single pass: transform+crop+bin+histogram+cell records, and the raster of "
+                                                    "the step plateaus into planes)" if single_pass["ran"] else "k_hist (K1: transform+crop+bin+histogram)"),
+                         "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": None if traffic is None else "profiles/pmc_k_hist.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                            "of this command, committed; not re-measured in this run)",
@@ -424,6 +432,12 @@ def main():
             "floors": floors,
             "prewarm": prewarm,
             "stage_ms": stage,
+            "predict_ms": predict_ms,
+            "single_pass": {"ran": single_pass["ran"], "frames_with_steps": single_pass["with_steps"], "frames_covered_by_the_predictor": single_pass["covered"],
+                            "planes_per_frame": single_pass["planes"] / float(F),
+                            "note": "K1 rasters the step plateaus itself into planes of the height bins k_predict (predict_ms, in front of the seven stages) "
+                                    "expects them in; k_peaks checks the planes against the complete histogram frame by frame and k_raster (stage "
+                                    "'raster') does only the frames not covered; of the last of the separate timed steps"},
             "stage_ms_source": "separate timed steps: %d extra passes after the timed region, one batch at a time (enqueue, fetch), HIP events "
                                "between the launches on the kernels' stream; the timed region itself keeps %d batches in flight" % (n_extra, depth),
             "one_batch_at_a_time": {"ms_per_step": one_at_a_time_ms, "frames_per_s": F / one_at_a_time_ms * 1e3,

@@ -266,6 +266,9 @@ int ssd_get_stage_times(ssd_handle *h, float ms[7]);
 /* the same for an earlier enqueue: back = 0 is the last, 1 the one before, ... (< SSD_TIMING_SLOTS),
  * so a timed loop can read all its steps after one final synchronisation */
 int ssd_get_stage_times_back(ssd_handle *h, int back, float ms[7]);
+/* single-pass batches (section "Batches" below) run one kernel in front of the seven stages, k_predict: its time for the same enqueue
+ * (0 when the enqueue did not run it) */
+int ssd_get_predict_time_back(ssd_handle *h, int back, float *ms);
 
 /* Stairs::serialize(): returns the text length, or SSD_E_CAP. A frame whose status has SSD_ST_THROW
  * serialises to the empty string (the reference process terminates instead of printing). */

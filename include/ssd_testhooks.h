@@ -55,7 +55,7 @@ int ssd_test_single_pass(ssd_handle *h, int mode, int sabotage);
 /* of the last enqueue (synchronises): returns 1 when it ran the single pass, else 0 (counts zero); counts[0] = frames whose step
  * plateaus the planes covered (k_raster skipped them), [1] = frames with step plateaus, [2] = planes over all frames,
  * [3] = 64-bit words of the lane's plane images that are not zero (the invariant between batches: 0) */
-int ssd_test_single_pass_stats(ssd_handle *h, int frames, long long counts[4]);
+int ssd_test_single_pass_stats(ssd_handle *h, int frames, int scan_planes, long long counts[4]);   /* scan_planes = 0: counts[3] = -1, the images are not fetched */
 /* one frame of the last enqueue: the predictor's table (height bin -> plane, 0xff = none; SSD_MAX_BINS entries),
  * info[0] = planes, info[1] = 1 when they covered the frame's step plateaus, info[2] = step plateaus */
 int ssd_test_single_pass_frame(ssd_handle *h, int frame, uint8_t *plane_of_bin, int info[3]);

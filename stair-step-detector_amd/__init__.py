@@ -135,7 +135,7 @@ EXPORTS = [
     "ssd_create", "ssd_destroy", "ssd_last_error", "ssd_workspace_bytes",
     "ssd_process_host", "ssd_enqueue", "ssd_fetch", "ssd_enqueue_stages",
     "ssd_set_intrinsics", "ssd_process_depth_host", "ssd_enqueue_depth", "ssd_deproject_host",
-    "ssd_fetch_back", "ssd_stream_wait", "ssd_batches_in_flight", "ssd_set_risers", "ssd_fetch_risers", "ssd_set_timing", "ssd_get_stage_times", "ssd_get_stage_times_back", "ssd_serialize",
+    "ssd_fetch_back", "ssd_stream_wait", "ssd_batches_in_flight", "ssd_set_risers", "ssd_fetch_risers", "ssd_set_timing", "ssd_get_stage_times", "ssd_get_stage_times_back", "ssd_get_predict_time_back", "ssd_serialize",
     "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
     "ssd_device_count", "ssd_device_alloc", "ssd_device_free", "ssd_device_upload", "ssd_device_download",
     "ssd_device_sync", "ssd_host_alloc", "ssd_host_free", "ssd_device_info_get", "ssd_bind_thread_to_device",
@@ -196,6 +196,7 @@ def lib():
     L.ssd_fetch_risers.argtypes = [vp, C.POINTER(FrameRisers), i32, vp]
     L.ssd_get_stage_times.argtypes = [vp, C.POINTER(C.c_float)]
     L.ssd_get_stage_times_back.argtypes = [vp, i32, C.POINTER(C.c_float)]
+    L.ssd_get_predict_time_back.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.ssd_serialize.argtypes = [C.POINTER(FrameResult), C.c_char_p, sz]
     L.ssd_set_debug.argtypes = [vp, i32]
     L.ssd_get_debug.argtypes = [vp, i32, C.POINTER(DebugFrame)]
@@ -268,7 +269,7 @@ def hooks_lib():
     L.ssd_test_ground_image.argtypes = [vp, i32, vp]
     L.ssd_test_empty_quadrilateral.argtypes = [vp, i32, i32]
     L.ssd_test_single_pass.argtypes = [vp, i32, i32]
-    L.ssd_test_single_pass_stats.argtypes = [vp, i32, vp]
+    L.ssd_test_single_pass_stats.argtypes = [vp, i32, i32, vp]
     L.ssd_test_single_pass_frame.argtypes = [vp, i32, vp, vp]
     L.ssd_test_record_offset.argtypes = [vp, C.c_size_t]
     L.ssd_test_record_realloc.argtypes = [vp]
@@ -474,6 +475,12 @@ class Detector:
         _check(lib().ssd_get_stage_times_back(self._h, back, ms))
         return dict(zip(STAGE_NAMES, [float(x) for x in ms]))
 
+    def predict_time_ms(self, back=0):
+        """Device time of k_predict, the kernel in front of the stages of a single-pass batch (0.0: the enqueue did not run it)."""
+        ms = C.c_float(0.0)
+        _check(lib().ssd_get_predict_time_back(self._h, back, C.byref(ms)))
+        return float(ms.value)
+
     def set_debug(self, on=True, images=True):
         """debug capture: records + images (the whole ground image is rastered for it), or records only (images=False:
         the kernels run exactly as in production)"""
@@ -501,12 +508,12 @@ class Detector:
         geometry allows; sabotage 1 / 2 = the predictor's planes in the wrong bins / none (every frame must fall back to k_raster)"""
         _check(hooks_lib().ssd_test_single_pass(self._h, mode, sabotage), "hooks")
 
-    def single_pass_stats(self, frames):
+    def single_pass_stats(self, frames, scan_planes=True):
         """test hook, of the last enqueue: {'ran': it ran the single pass, 'covered': frames whose step plateaus the planes covered,
         'with_steps': frames with step plateaus, 'planes': planes over all frames, 'dirty_words': words of the lane's plane images
-        that are not zero (always counted)}"""
+        that are not zero (-1 with scan_planes=False: the images are not fetched)}"""
         counts = (C.c_longlong * 4)()
-        ran = _check(hooks_lib().ssd_test_single_pass_stats(self._h, frames, counts), "hooks")
+        ran = _check(hooks_lib().ssd_test_single_pass_stats(self._h, frames, 1 if scan_planes else 0, counts), "hooks")
         return dict(ran=bool(ran), covered=int(counts[0]), with_steps=int(counts[1]), planes=int(counts[2]), dirty_words=int(counts[3]))
 
     def single_pass_frame(self, frame):

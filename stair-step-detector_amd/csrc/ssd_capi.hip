@@ -507,6 +507,8 @@ int ssd_destroy(ssd_handle *h)
   if(h->hRisersBatch) (void)hipHostFree(h->hRisersBatch);
   if(h->dDebug) (void)hipFree(h->dDebug);
   if(h->dDebugImg) (void)hipFree(h->dDebugImg);
+  for(hipEvent_t e : h->evPredict)
+    if(e) (void)hipEventDestroy(e);
   for(hipEvent_t e : h->ev)
     (void)hipEventDestroy(e);
   delete h;
@@ -635,6 +637,9 @@ int ssd_set_timing(ssd_handle *h, int enable)
       ev.push_back(e);
     }
     h->ev.swap(ev);
+    for(int i = 0; i < SSD_TIMING_SLOTS; i++)
+      if(hipEventCreate(&h->evPredict[i]) != hipSuccess)
+        return fail(SSD_E_HIP, "hipEventCreate (predict)");
   }
   h->timing = enable != 0;
   h->timedFrom = h->enqueueCount;
@@ -770,8 +775,10 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   if(L.dPlaneImg && stages == SSD_STAGE_ALL && h->singlePassMode != 0 && (h->singlePassMode == 1 || nframes >= kSinglePassMinFrames))
     planeImg = L.dPlaneImg;
   h->lastSinglePass = planeImg != nullptr;
+  h->predictTimed[h->enqueueCount % SSD_TIMING_SLOTS] = planeImg != nullptr;
   const bool timing = h->timing && !h->ev.empty();
-  int evi = static_cast<int>(h->enqueueCount % SSD_TIMING_SLOTS) * 8;
+  const int timingSlot = static_cast<int>(h->enqueueCount % SSD_TIMING_SLOTS);
+  int evi = timingSlot * 8;
 
   const int slot = static_cast<int>(h->finalCount % static_cast<unsigned long long>(h->nSlots));
   const bool direct = nframes <= kDirectResultFrames && h->hResultsDev != nullptr;
@@ -782,9 +789,15 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   auto chain = [&](hipStream_t cs, bool marks)
   {
     auto mk = [&]() { if(marks) (void)hipEventRecord(h->ev[evi++], cs); };
+    if(planeImg)
+    {
+      /* k_predict in front of the seven stages, timed by itself (ssd_get_predict_time_back) */
+      if(marks) (void)hipEventRecord(h->evPredict[timingSlot], cs);
+      launch_predict(xyz, strideFloats, P, L.dState, nframes, depth, L.dFallback, h->singlePassSabotage, cs);
+    }
     mk();
     if(stages & SSD_STAGE_HIST)
-      launch_hist(xyz, strideFloats, P, L.dState, L.dTileMasks, h->tileMaskStride, nframes, chunkHist, depth, planeImg, planeImg ? L.dFallback : nullptr, h->singlePassSabotage, cs);
+      launch_hist(xyz, strideFloats, P, L.dState, L.dTileMasks, h->tileMaskStride, nframes, chunkHist, depth, planeImg, cs);
     mk();
     if(stages & SSD_STAGE_PEAKS)
       launch_peaks(P, L.dState, nframes, dbg, planeImg ? L.dFallback : nullptr, cs);
@@ -950,6 +963,24 @@ int ssd_get_stage_times_back(ssd_handle *h, int back, float ms[7])
   HIP_TRY(hipEventSynchronize(h->ev[base + 7]));
   for(int i = 0; i < 7; i++)
     HIP_TRY(hipEventElapsedTime(&ms[i], h->ev[base + i], h->ev[base + i + 1]));
+  return SSD_OK;
+}
+
+/* k_predict's time, the kernel in front of the seven stages of a single-pass batch (0 for an enqueue that did not run it) */
+int ssd_get_predict_time_back(ssd_handle *h, int back, float *ms)
+{
+  if(!h || !ms)
+    return fail(SSD_E_ARG, "ssd_get_predict_time_back: null");
+  if(!h->timing || h->ev.empty() || back < 0 || back >= SSD_TIMING_SLOTS ||
+     h->enqueueCount < static_cast<unsigned long long>(back) + 1 || h->enqueueCount - 1 - back < h->timedFrom)
+    return fail(SSD_E_ARG, "ssd_get_predict_time_back: no timed enqueue at that position");
+  HIP_TRY(hipSetDevice(h->device));
+  const int slot = static_cast<int>((h->enqueueCount - 1 - back) % SSD_TIMING_SLOTS);
+  *ms = 0.0f;
+  if(!h->predictTimed[slot])
+    return SSD_OK;
+  HIP_TRY(hipEventSynchronize(h->ev[slot * 8 + 7]));
+  HIP_TRY(hipEventElapsedTime(ms, h->evPredict[slot], h->ev[slot * 8]));
   return SSD_OK;
 }
 

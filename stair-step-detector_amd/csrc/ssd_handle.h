@@ -98,6 +98,8 @@ struct ssd_handle
   /* per-stage timing: a ring of event sets, one per enqueue, so that a timed loop never has to synchronise */
   bool timing = false;
   std::vector<hipEvent_t> ev;     /* kTimingSlots x 8 */
+  hipEvent_t evPredict[SSD_TIMING_SLOTS] = {};   /* recorded in front of k_predict (single-pass enqueues) */
+  bool predictTimed[SSD_TIMING_SLOTS] = {};
   unsigned long long enqueueCount = 0;
   unsigned long long timedFrom = 0;
 };

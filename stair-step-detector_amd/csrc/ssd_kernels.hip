@@ -3449,28 +3449,29 @@ static inline bool aligned16(const float *xyz, size_t strideFloats, int nPoints)
   return (reinterpret_cast<uintptr_t>(xyz) & 15u) == 0 && (strideFloats & 3u) == 0 && (nPoints & 3) == 0;
 }
 
+void launch_predict(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, int nframes, const DepthSrc *depth,
+                    int *fallback, int sabotage, hipStream_t s)
+{
+  dim3 pgrid(nframes, kPredictParts);
+  if(depth)
+    hipLaunchKernelGGL(k_predict<kSrcDepth16>, pgrid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, *depth, P.minHeight, sabotage, fallback);
+  else if(aligned16(xyz, strideFloats, P.nPoints))
+    hipLaunchKernelGGL(k_predict<kSrcF3Aligned>, pgrid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, DepthSrc{}, P.minHeight, sabotage, fallback);
+  else
+    hipLaunchKernelGGL(k_predict<kSrcF3>, pgrid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, DepthSrc{}, P.minHeight, sabotage, fallback);
+}
 void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, uint2 *tileMasks, size_t tileMaskStride,
-                 int nframes, int chunkPoints, const DepthSrc *depth, unsigned long long *planeImg, int *fallback, int sabotage, hipStream_t s)
+                 int nframes, int chunkPoints, const DepthSrc *depth, unsigned long long *planeImg, hipStream_t s)
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
   if(planeImg)
   {
-    dim3 pgrid(nframes, kPredictParts);
     if(depth)
-    {
-      hipLaunchKernelGGL(k_predict<kSrcDepth16>, pgrid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, *depth, P.minHeight, sabotage, fallback);
       hipLaunchKernelGGL(k_hist_planes<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, *depth);
-    }
     else if(aligned16(xyz, strideFloats, P.nPoints))
-    {
-      hipLaunchKernelGGL(k_predict<kSrcF3Aligned>, pgrid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, DepthSrc{}, P.minHeight, sabotage, fallback);
       hipLaunchKernelGGL(k_hist_planes<kSrcF3Aligned>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, DepthSrc{});
-    }
     else
-    {
-      hipLaunchKernelGGL(k_predict<kSrcF3>, pgrid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, DepthSrc{}, P.minHeight, sabotage, fallback);
       hipLaunchKernelGGL(k_hist_planes<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, DepthSrc{});
-    }
     return;
   }
   if(depth)

@@ -20,10 +20,13 @@ constexpr int kSinglePassMinFrames = 64;
 constexpr int kPredictParts = 4;            /* blocks of k_predict per frame */
 inline bool single_pass_geometry(int W, int H) { return W >= 64 && kTileHost % W == 0 && H >= 16 && H <= 4096; }
 
-/* planeImg != nullptr: the single pass (k_predict, then K1 rastering the candidate bins' planes); fallback: the batch's list of
- * frames for k_raster (count, indices; k_predict resets, k_peaks appends, k_raster reads); sabotage: see k_predict */
+/* The single pass: launch_predict (k_predict; fallback = the batch's list of frames for k_raster - count, then indices: k_predict
+ * resets it, k_peaks appends, k_raster reads; sabotage: see k_predict), then launch_hist with planeImg != nullptr (K1 rastering the
+ * candidate bins' planes), launch_peaks / launch_raster with the list, launch_outline with the planes. */
+void launch_predict(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, int nframes, const DepthSrc *depth,
+                    int *fallback, int sabotage, hipStream_t s);
 void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, uint2 *tileMasks, size_t tileMaskStride,
-                 int nframes, int chunkPoints, const DepthSrc *depth, unsigned long long *planeImg, int *fallback, int sabotage, hipStream_t s);
+                 int nframes, int chunkPoints, const DepthSrc *depth, unsigned long long *planeImg, hipStream_t s);
 void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, int *fallback, hipStream_t s);
 void launch_raster(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, unsigned long long *stepImg,
                    const uint2 *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, const int *fallback, hipStream_t s);

@@ -284,7 +284,7 @@ int ssd_test_single_pass(ssd_handle *h, int mode, int sabotage)
   return SSD_OK;
 }
 
-int ssd_test_single_pass_stats(ssd_handle *h, int frames, long long counts[4])
+int ssd_test_single_pass_stats(ssd_handle *h, int frames, int scan_planes, long long counts[4])
 {
   if(!h || !counts || frames < 0 || frames > h->F)
     return fail(SSD_E_ARG, "ssd_test_single_pass_stats: bad argument");
@@ -292,7 +292,9 @@ int ssd_test_single_pass_stats(ssd_handle *h, int frames, long long counts[4])
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
   const ssd_lane &L = h->lane[h->lastLane];
-  if(L.dPlaneImg)
+  if(!scan_planes)
+    counts[3] = -1;
+  else if(L.dPlaneImg)
   {
     const size_t words = static_cast<size_t>(h->F) * kMaxPlanes * h->imgWords;
     std::vector<unsigned long long> img(words);

@@ -106,3 +106,65 @@ def test_geometry_without_whole_rows_per_tile_stays_two_pass(ssd, gpu_device):
         det.single_pass(1)
     det.close()
     buf.free()
+
+
+def test_single_pass_on_depth_input_and_unaligned_vertices(ssd, oracle, gpu_device):
+    """The other two sources of K1: 16-bit depth frames deprojected on the fly, and vertex frames whose stride is not a multiple
+    of 16 bytes (12-byte loads) - 96 XGA frames each, single pass against two passes, depth also against the oracle."""
+    W, H, n = 1024, 768, 96
+    sc = scenes.batch_scenes(ssd, W, H, n, base_seed=45000, rng_seed=45)
+    trans = ssd.transformation_for_scene(sc[0])
+    cfg = ssd.default_config(W, H, max_frames_per_batch=n)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    intr = ssd.intrinsics_for_scene(sc[0])
+    det.set_intrinsics(intr)
+    dbuf = ssd.DeviceBuffer(W * H * 2 * n, gpu_device)
+    ssd.synth_depth_device(sc, dbuf.ptr, device=gpu_device)
+
+    def run_depth():
+        det.enqueue_depth(dbuf.ptr, n)
+        return det.fetch_list(n)
+
+    det.single_pass(0)
+    two_pass = [bytes(x) for x in run_depth()]
+    det.single_pass(-1)
+    res = run_depth()
+    assert [bytes(x) for x in res] == two_pass
+    st = det.single_pass_stats(n)
+    assert st["ran"] and st["dirty_words"] == 0 and st["covered"] >= st["with_steps"] * 9 // 10
+    depth = dbuf.download(W * H * 2 * n, dtype=np.uint16).reshape(n, H, W)
+    for i in range(0, n, 8):
+        parity.check_results_only(ssd, oracle, cfg, trans.constants, oracle.deproject(intr, depth[i]), res[i])
+    dbuf.free()
+    # vertices at a stride of 12 * W * H + 4 bytes: every second frame starts off a 16-byte boundary
+    stride = W * H * 12 + 4
+    xyz = ssd.synth_host(sc[:64])
+    raw = np.zeros(64 * stride, dtype=np.uint8)
+    for i in range(64):
+        raw[i * stride:i * stride + W * H * 12] = xyz[i].view(np.uint8).reshape(-1)
+    vbuf = ssd.DeviceBuffer(raw.size, gpu_device)
+    vbuf.upload(raw)
+    det.single_pass(0)
+    det.enqueue(vbuf.ptr, 64, stride_bytes=stride)
+    two_pass = [bytes(x) for x in det.fetch_list(64)]
+    det.single_pass(-1)
+    det.enqueue(vbuf.ptr, 64, stride_bytes=stride)
+    assert [bytes(x) for x in det.fetch_list(64)] == two_pass
+    st = det.single_pass_stats(64)
+    assert st["ran"] and st["dirty_words"] == 0
+    vbuf.free()
+    det.close()
+
+
+def test_the_predictor_is_timed_beside_the_stages(ssd, gpu_device):
+    W, H, n = 1024, 768, 64
+    sc, buf = _batch(ssd, gpu_device, W, H, n, 46000, 46)
+    det = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=n), ssd.transformation_for_scene(sc[0]), gpu_device)
+    det.set_timing(True)
+    _run(det, buf, n)
+    assert det.predict_time_ms() > 0.0 and det.stage_times_ms()["hist"] > 0.0
+    det.single_pass(0)
+    _run(det, buf, n)
+    assert det.predict_time_ms() == 0.0 and det.predict_time_ms(back=1) > 0.0
+    det.close()
+    buf.free()

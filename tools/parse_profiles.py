@@ -17,7 +17,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STREAMING = ("k_hist", "k_raster", "k_inquad", "k_stream_read")
+STREAMING = ("k_hist", "k_predict", "k_raster", "k_inquad", "k_stream_read")      # 16-byte loads per lane ("k_hist" also names k_hist_planes)
 NOT_PIPELINE = ("synth", "k_stream_read")          # frame generator; bench.py's plain read stream beside K1
 
 
