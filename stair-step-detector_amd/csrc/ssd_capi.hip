@@ -772,7 +772,9 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
    * k_peaks checks that against the complete histogram, frame by frame, and k_raster does the frames it does not cover.  Only
    * the whole pipeline in one call (the planes are set in the first stage and consumed in the fourth), only batches. */
   unsigned long long *planeImg = nullptr;
-  if(L.dPlaneImg && stages == SSD_STAGE_ALL && h->singlePassMode != 0 && (h->singlePassMode == 1 || nframes >= kSinglePassMinFrames))
+  /* (not on 16-bit depth input: K1 is bound by instruction issue there, not by the bytes a second pass would re-read - k_raster
+   * reads a sixth of them -, and the raster's instructions cost K1 what k_raster took: 384.6 k against 386.8 k frames/s) */
+  if(L.dPlaneImg && stages == SSD_STAGE_ALL && h->singlePassMode != 0 && (h->singlePassMode == 1 || (nframes >= kSinglePassMinFrames && !depthInput)))
     planeImg = L.dPlaneImg;
   h->lastSinglePass = planeImg != nullptr;
   h->predictTimed[h->enqueueCount % SSD_TIMING_SLOTS] = planeImg != nullptr;

@@ -722,6 +722,7 @@ struct SpecLds
   unsigned long long wins[kThreads / 64][kSpecWinWords];
   ImageBox boxes[kMaxPlanes];
   unsigned char plane[kMaxBins];                 /* FrameState::specPlane */
+  unsigned char order[kMaxTilesPerBlock * (kTile / 256)];   /* STRIPS: the chunk's 256-point strips by (column band, index) */
   unsigned int oob[kMaxPlanes];
   unsigned long long ltot[kMaxPlanes][8];        /* sum of round(z * 2^40) per plane (this block's share) */
 };
@@ -738,7 +739,7 @@ struct HistLds
 
 /* SPEC (single pass): the block also rasters the points of the bins that have a plane (FrameState::specPlane, k_predict) into
  * the frame's planes, as k_raster does for the plateaus' bins: pixel (image_pixel), the plane's z sum and out-of-image count. */
-template<int SRC, bool SPEC, typename SPECLDS>
+template<int SRC, bool SPEC, bool STRIPS, typename SPECLDS>
 __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float *__restrict__ xyz, size_t strideFloats, const PointParams &P,
                                            const PixelParams &X, FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
                                            unsigned long long *__restrict__ planeImg,
@@ -787,7 +788,8 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
   unsigned int *mine = lh + (lane & (kHistCopies - 1));
   unsigned int nz = 0;                                               /* wave-uniform: the count of the whole wave (scalar popcounts) */
   int it = 0;
-  auto tileBody = [&](const F3 (&v)[kPts])
+  int nStore = -1;                                                    /* cell records to store (STRIPS), else it * kCellsPerTile */
+  auto tileBody = [&](const F3 (&v)[kPts], const int cellAt)
   {
     unsigned int groups = 0u;
     /* extremes of (x - xMin, y - yMin) over the lane's in-range points, as the high dwords of the doubles (see row_min_u32) */
@@ -837,8 +839,7 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
      * DPP operand cannot be folded into the min / max (ten instructions instead of five per tile) */
     asm volatile("" : "+v"(groups), "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
     if((lane & 15) == 0)                                         /* cell = 64 consecutive points = lanes 16q .. 16q+15 */
-      lInfo[it * kCellsPerTile + (tid >> 4)] = make_uint2(groups, cell_box_from_high_dwords(x0, x1, y0, y1, P.boxX, P.boxY));
-    it++;
+      lInfo[cellAt] = make_uint2(groups, cell_box_from_high_dwords(x0, x1, y0, y1, P.boxX, P.boxY));
     if constexpr(SPEC)
     {
       /* most tiles hold no point of a candidate bin (ground, risers, background): one ballot */
@@ -846,7 +847,64 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
         specwin_emit(SL.wins[tid >> 6], missed, win, frameImg, imgWords, X.W64, SL.boxes, key, lane);
     }
   };
-  if(SRC == kSrcDepth16)
+  if constexpr(STRIPS)
+  {
+    /* Single pass at a width that does not divide a tile (FHD, VGA ..).  Walking the chunk tile by tile, a wave's 256 points
+     * would sit in another band of camera columns every tile - its image window would be flushed and re-anchored every tile.
+     * So the chunk's strips of 256 points are sorted by (column band of 256 pixels, index) and each wave takes a quarter of
+     * the sorted list: it walks down one band, then part of the next.  Sorted by one wave with ballots (<= 128 strips,
+     * <= 32 bands).  A strip that crosses the end of a camera row puts its tail into the first band: those pixels miss the
+     * window and go to memory one by one - one strip in W / 256. */
+    const int nStrips = (end - begin + 255) >> 8;
+    if(tid < 64)
+    {
+      const int sLo = tid, sHi = tid + 64;
+      const int bLo = sLo < nStrips ? ((begin + (sLo << 8)) % X.W) >> 8 : -1, bHi = sHi < nStrips ? ((begin + (sHi << 8)) % X.W) >> 8 : -1;
+      const int nBands = (X.W + 255) >> 8;
+      const unsigned long long below = (1ull << tid) - 1ull;
+      int placed = 0;
+      for(int b = 0; b < nBands; b++)
+      {
+        const unsigned long long mLo = __ballot(bLo == b), mHi = __ballot(bHi == b);
+        if(bLo == b)
+          SL.order[placed + __popcll(mLo & below)] = static_cast<unsigned char>(sLo);
+        if(bHi == b)
+          SL.order[placed + __popcll(mLo) + __popcll(mHi & below)] = static_cast<unsigned char>(sHi);
+        placed += __popcll(mLo) + __popcll(mHi);
+      }
+    }
+    __syncthreads();
+    const int wave = tid >> 6;
+    int k = wave * nStrips / kWavesPerBlock;
+    const int kEnd = (wave + 1) * nStrips / kWavesPerBlock;
+    if(k < kEnd)
+    {
+      F3 va[kPts], vb[kPts];
+      int sa = SL.order[k], sb = 0;
+      load_points<SRC>(base, begin + (sa << 8) + kPts * lane, end, va, D);
+      while(true)
+      {
+        if(k + 1 < kEnd)
+        {
+          sb = SL.order[k + 1];
+          load_points<SRC>(base, begin + (sb << 8) + kPts * lane, end, vb, D);
+        }
+        tileBody(va, sa * 4 + (lane >> 4));
+        if(++k >= kEnd)
+          break;
+        if(k + 1 < kEnd)
+        {
+          sa = SL.order[k + 1];
+          load_points<SRC>(base, begin + (sa << 8) + kPts * lane, end, va, D);
+        }
+        tileBody(vb, sb * 4 + (lane >> 4));
+        if(++k >= kEnd)
+          break;
+      }
+    }
+    nStore = nStrips * (256 / kCell);           /* every strip's four cells were written */
+  }
+  else if(SRC == kSrcDepth16)
   {
     /* The depth stream: 8 bytes per lane and tile, and the maps.  A tile is 1024 consecutive pixels, so from tile to tile a
      * lane's row advances by 1024 / W and its column by 1024 % W (wrapping once at most): no division in the loop, and when
@@ -880,14 +938,22 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
       }
       F3 v[kPts];
       deproject4(raw, xm, ym, D.depthUnits, v);
-      tileBody(v);
+      tileBody(v, it * kCellsPerTile + (tid >> 4));
+      it++;
       if(!more)
         break;
       raw = rawN; xm = xmN; ym = ymN;
     }
   }
   else
-    SSD_STREAM_LOOP(tileBody)
+  {
+    auto tileInOrder = [&](const F3 (&v)[kPts])
+    {
+      tileBody(v, it * kCellsPerTile + (tid >> 4));
+      it++;
+    };
+    SSD_STREAM_LOOP(tileInOrder)
+  }
 
   if constexpr(SPEC)
   {
@@ -934,7 +1000,8 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
   /* the block's cell records, in one burst */
   {
     uint2 *dst = tileMasks + static_cast<size_t>(frame) * tileMaskStride + static_cast<size_t>(begin / kCell);
-    for(int i = tid; i < it * kCellsPerTile; i += kThreads)
+    const int n = nStore >= 0 ? nStore : it * kCellsPerTile;
+    for(int i = tid; i < n; i += kThreads)
       dst[i] = lInfo[i];
   }
 }
@@ -946,14 +1013,14 @@ __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ 
 {
   __shared__ HistLds L;
   NoSpecLds none;
-  hist_block<SRC, false>(L, none, xyz, strideFloats, P, PixelParams{}, st, tileMasks, nullptr, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);   /* frame on the fast grid axis: see launch note on XCD balance */
+  hist_block<SRC, false, false>(L, none, xyz, strideFloats, P, PixelParams{}, st, tileMasks, nullptr, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);   /* frame on the fast grid axis: see launch note on XCD balance */
 }
 
 /* K1 of a single-pass batch: histogram, cell records AND the planes of the candidate bins.  39 KiB of LDS: four blocks per CU. */
 #ifndef SSD_K1S_WAVES
 #define SSD_K1S_WAVES 5
 #endif
-template<int SRC>
+template<int SRC, bool STRIPS>
 __global__ __launch_bounds__(kThreads, SSD_K1S_WAVES) void k_hist_planes(const float *__restrict__ xyz, size_t strideFloats, PointParams P, PixelParams X,
                                                    FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
                                                    unsigned long long *__restrict__ planeImg,
@@ -961,7 +1028,7 @@ __global__ __launch_bounds__(kThreads, SSD_K1S_WAVES) void k_hist_planes(const f
 {
   __shared__ HistLds L;
   __shared__ SpecLds SL;
-  hist_block<SRC, true>(L, SL, xyz, strideFloats, P, X, st, tileMasks, planeImg, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
+  hist_block<SRC, true, STRIPS>(L, SL, xyz, strideFloats, P, X, st, tileMasks, planeImg, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
 }
 
 /* K0 of a single-pass batch: which height bins may belong to a step plateau?  A histogram of one cell in every kSpecSample (a
@@ -1053,7 +1120,7 @@ __global__ __launch_bounds__(kThreads) void k_predict(const float *__restrict__ 
     if(b < max(minHeight, 1) || b >= P.nBins - 1)
       return false;
     const unsigned int c = sh[1 + b], l = sh[b], r = sh[2 + b];
-    return c * kSpecSample >= 1200u && (l + r) * 2u < 3u * c + 16u;
+    return c > l && c >= r && c * kSpecSample >= 1200u && (l + r) * 2u < 3u * c + 16u;     /* a local maximum: of a tread's two almost equally full bins, one */
   };
   /* at most kMaxPlanes / 3 candidates: the fullest ones (a sampled background still throws up a false peak here and there;
    * they cost planes and stray raster work, never results) */
@@ -3466,12 +3533,26 @@ void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameSt
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
   if(planeImg)
   {
+    /* a tile a whole number of camera rows: the tile loop keeps every wave in its band of columns; else the sorted strips */
+    const bool strips = kTile % P.W != 0;
+#define SSD_LAUNCH_PLANES(SRC, DEPTH)                                                                                                    \
+    if(strips)                                                                                                                             \
+      hipLaunchKernelGGL((k_hist_planes<SRC, true>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, DEPTH); \
+    else                                                                                                                                   \
+      hipLaunchKernelGGL((k_hist_planes<SRC, false>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, DEPTH);
     if(depth)
-      hipLaunchKernelGGL(k_hist_planes<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, *depth);
+    {
+      SSD_LAUNCH_PLANES(kSrcDepth16, *depth)
+    }
     else if(aligned16(xyz, strideFloats, P.nPoints))
-      hipLaunchKernelGGL(k_hist_planes<kSrcF3Aligned>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, DepthSrc{});
+    {
+      SSD_LAUNCH_PLANES(kSrcF3Aligned, DepthSrc{})
+    }
     else
-      hipLaunchKernelGGL(k_hist_planes<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, DepthSrc{});
+    {
+      SSD_LAUNCH_PLANES(kSrcF3, DepthSrc{})
+    }
+#undef SSD_LAUNCH_PLANES
     return;
   }
   if(depth)

@@ -13,12 +13,11 @@ constexpr int kMaxTilesPerBlockHost = 32;
 constexpr int kMaxTilesPerBlockRasterHost = 128;   /* K2 only */
 constexpr int kMaxTilesPerBlockInquadHost = 128;   /* K4 only */
 constexpr int kCellHost = 64;               /* points per cell (one gating mask each) */
-/* The single pass (k_hist rasters the step plateaus itself) needs each wave of K1 to stay in one band of
- * camera columns from tile to tile - a tile (1024 points) is a whole number of camera rows - and pays a kernel (k_predict)
- * that a few frames do not earn back. */
+/* The single pass (k_hist rasters the step plateaus itself) pays a kernel (k_predict) that a few frames do
+ * not earn back; its keys hold 13 bits of row and its windows must fit the image. */
 constexpr int kSinglePassMinFrames = 64;
 constexpr int kPredictParts = 4;            /* blocks of k_predict per frame */
-inline bool single_pass_geometry(int W, int H) { return W >= 64 && kTileHost % W == 0 && H >= 16 && H <= 4096; }
+inline bool single_pass_geometry(int W, int H) { return W >= 64 && W <= 8192 && H >= 16 && H <= 4096; }
 
 /* The single pass: launch_predict (k_predict; fallback = the batch's list of frames for k_raster - count, then indices: k_predict
  * resets it, k_peaks appends, k_raster reads; sabotage: see k_predict), then launch_hist with planeImg != nullptr (K1 rastering the

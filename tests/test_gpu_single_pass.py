@@ -72,10 +72,11 @@ def test_a_wrong_predictor_costs_time_not_results(ssd, gpu_device, sabotage):
     buf.free()
 
 
-@pytest.mark.parametrize("W,H", [(1024, 768), (512, 384), (256, 192)])
+@pytest.mark.parametrize("W,H", [(1024, 768), (512, 384), (256, 192), (640, 480), (848, 480), (1280, 720), (1920, 1080)])
 def test_single_pass_forced_on_small_batches(ssd, oracle, gpu_device, W, H):
-    """Geometries whose tile of 1024 points is one, two or four camera rows, 12 frames with the single pass forced on (the product
-    only takes it for batches of 64 and more), every frame with its images against the oracle."""
+    """Geometries whose tile of 1024 points is one, two or four camera rows (K1 walks its chunk tile by tile) and geometries where
+    it is not (K1 walks the chunk's strips of 256 points sorted by column band; 848 is not even a whole number of cells), 12
+    frames with the single pass forced on (the product only takes it for batches of 64 and more), against two passes and the oracle."""
     n = 12
     sc, buf = _batch(ssd, gpu_device, W, H, n, 43000 + W, 43)
     trans = ssd.transformation_for_scene(sc[0])
@@ -94,16 +95,36 @@ def test_single_pass_forced_on_small_batches(ssd, oracle, gpu_device, W, H):
     buf.free()
 
 
-def test_geometry_without_whole_rows_per_tile_stays_two_pass(ssd, gpu_device):
-    """640 x 480: a tile is 1.6 camera rows, a wave of K1 would hop between column bands - the handle has no planes, the hook
-    refuses to force them"""
-    W, H, n = 640, 480, 64
+def test_single_pass_on_a_vga_batch_with_depth_input(ssd, oracle, gpu_device):
+    """640 x 480 (a tile is 1.6 camera rows: the sorted strips), 128 frames as the product runs them, vertices and 16-bit depth"""
+    W, H, n = 640, 480, 128
     sc, buf = _batch(ssd, gpu_device, W, H, n, 44000, 44)
-    det = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=n), ssd.transformation_for_scene(sc[0]), gpu_device)
-    _run(det, buf, n)
-    assert not det.single_pass_stats(n)["ran"]
-    with pytest.raises(ssd.SsdError):
-        det.single_pass(1)
+    trans = ssd.transformation_for_scene(sc[0])
+    cfg = ssd.default_config(W, H, max_frames_per_batch=n)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    single = _run(det, buf, n)
+    st = det.single_pass_stats(n)
+    assert st["ran"] and st["dirty_words"] == 0 and st["covered"] >= st["with_steps"] * 8 // 10, st
+    det.single_pass(0)
+    assert _run(det, buf, n) == single
+    det.single_pass(-1)
+    det.enqueue(buf.ptr, n)
+    res = det.fetch_list(n)
+    assert parity.check_batch_against_oracle(ssd, oracle, cfg, trans.constants, buf, W * H * 12, res, W, H) == n
+    intr = ssd.intrinsics_for_scene(sc[0])
+    det.set_intrinsics(intr)
+    dbuf = ssd.DeviceBuffer(W * H * 2 * n, gpu_device)
+    ssd.synth_depth_device(sc, dbuf.ptr, device=gpu_device)
+    det.enqueue_depth(dbuf.ptr, n)
+    assert not det.single_pass_stats(n)["ran"]          # the product keeps two passes on depth input
+    det.single_pass(1)
+    det.enqueue_depth(dbuf.ptr, n)
+    d1 = [bytes(x) for x in det.fetch_list(n)]
+    assert det.single_pass_stats(n)["ran"]
+    det.single_pass(0)
+    det.enqueue_depth(dbuf.ptr, n)
+    assert [bytes(x) for x in det.fetch_list(n)] == d1
+    dbuf.free()
     det.close()
     buf.free()
 
@@ -127,7 +148,7 @@ def test_single_pass_on_depth_input_and_unaligned_vertices(ssd, oracle, gpu_devi
 
     det.single_pass(0)
     two_pass = [bytes(x) for x in run_depth()]
-    det.single_pass(-1)
+    det.single_pass(1)                       # forced: the product keeps two passes on depth input (no gain there)
     res = run_depth()
     assert [bytes(x) for x in res] == two_pass
     st = det.single_pass_stats(n)
@@ -136,6 +157,7 @@ def test_single_pass_on_depth_input_and_unaligned_vertices(ssd, oracle, gpu_devi
     for i in range(0, n, 8):
         parity.check_results_only(ssd, oracle, cfg, trans.constants, oracle.deproject(intr, depth[i]), res[i])
     dbuf.free()
+    det.single_pass(-1)
     # vertices at a stride of 12 * W * H + 4 bytes: every second frame starts off a 16-byte boundary
     stride = W * H * 12 + 4
     xyz = ssd.synth_host(sc[:64])

@@ -18,6 +18,6 @@ for seed in (100000, 200000, 300000):
             for k, v in det.stage_times_ms().items():
                 acc[k] = acc.get(k, 0.0) + v / 4
     st = det.single_pass_stats(F)
-    print(os.environ.get("SSD_HIP_LIB", "lib").split("/")[-2], seed, "covered %d / %d planes %d" % (st["covered"], st["with_steps"], st["planes"]),
+    print(os.path.basename(os.path.dirname(os.environ.get("SSD_HIP_LIB", "lib/x"))), seed, "covered %d / %d planes %d" % (st["covered"], st["with_steps"], st["planes"]),
           " ".join("%s %.3f" % (k[:5], v) for k, v in acc.items()))
     det.close()
