@@ -456,6 +456,11 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
       HIP_TRY_H(hipMemset(L.dFallback, 0, sizeof(int) * (1 + static_cast<size_t>(h->F))));
     }
   }
+  if(planeBytes)
+  {
+    HIP_TRY_H(hipHostMalloc(&h->hFallback, sizeof(int) * kMaxLanes, hipHostMallocDefault));
+    std::memset(h->hFallback, 0, sizeof(int) * kMaxLanes);
+  }
   const size_t resBytes = sizeof(ssd_frame_result) * h->F * h->nSlots;
   HIP_TRY_H(hipMalloc(&h->dResults, resBytes));
   HIP_TRY_H(hipHostMalloc(&h->hResults, resBytes, hipHostMallocDefault));
@@ -489,6 +494,7 @@ int ssd_destroy(ssd_handle *h)
     if(L.done) (void)hipEventDestroy(L.done);
     if(L.stream) (void)hipStreamDestroy(L.stream);
   }
+  if(h->hFallback) (void)hipHostFree(h->hFallback);
   if(h->dDepthMaps) (void)hipFree(h->dDepthMaps);
   if(h->dResults) (void)hipFree(h->dResults);
   if(h->hResults) (void)hipHostFree(h->hResults);
@@ -775,7 +781,12 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   /* (not on 16-bit depth input: K1 is bound by instruction issue there, not by the bytes a second pass would re-read - k_raster
    * reads a sixth of them -, and the raster's instructions cost K1 what k_raster took: 384.6 k against 386.8 k frames/s) */
   if(L.dPlaneImg && stages == SSD_STAGE_ALL && h->singlePassMode != 0 && (h->singlePassMode == 1 || (nframes >= kSinglePassMinFrames && !depthInput)))
-    planeImg = L.dPlaneImg;
+  {
+    if(h->singlePassMode == 1 || h->singlePassBackoff == 0)
+      planeImg = L.dPlaneImg;
+    else
+      h->singlePassBackoff--;                            /* see ssd_fetch_back */
+  }
   h->lastSinglePass = planeImg != nullptr;
   h->predictTimed[h->enqueueCount % SSD_TIMING_SLOTS] = planeImg != nullptr;
   const bool timing = h->timing && !h->ev.empty();
@@ -865,6 +876,13 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
     if(!direct)
       HIP_TRY(hipMemcpyAsync(h->hResults + static_cast<size_t>(slot) * h->F, h->dResults + static_cast<size_t>(slot) * h->F,
                              sizeof(ssd_frame_result) * nframes, hipMemcpyDeviceToHost, s));
+    /* single pass: how many frames k_raster had to do travels with the results (ssd_fetch_back adapts to it) */
+    h->resultsFallback[slot] = -1;
+    if(planeImg && h->hFallback)
+    {
+      HIP_TRY(hipMemcpyAsync(h->hFallback + slot, L.dFallback, sizeof(int), hipMemcpyDeviceToHost, s));
+      h->resultsFallback[slot] = 0;
+    }
     HIP_TRY(hipEventRecord(h->resultsReady[slot], s));
     h->resultsFrames[slot] = nframes;
     h->resultsLane[slot] = li;
@@ -1003,6 +1021,15 @@ int ssd_fetch_back(ssd_handle *h, ssd_frame_result *results, int nframes, int ba
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipEventSynchronize(h->resultsReady[slot]));
   std::memcpy(results, h->hResults + static_cast<size_t>(slot) * h->F, sizeof(ssd_frame_result) * nframes);
+  /* The single pass pays when its predictor covers the frames.  A batch of which k_raster had to do more than half (scenes
+   * without a sharp peak per tread, or far more treads than planes) says the input is of the other kind: the next
+   * kSinglePassBackoff qualifying batches run two passes, then one batch probes again.  Results do not depend on it. */
+  if(h->resultsFallback[slot] == 0)
+  {
+    h->resultsFallback[slot] = 1;                       /* counted once */
+    if(2 * h->hFallback[slot] > h->resultsFrames[slot])
+      h->singlePassBackoff = kSinglePassBackoff;
+  }
   return SSD_OK;
 }
 

@@ -94,6 +94,9 @@ struct ssd_handle
    * frames, geometry), 0 = never, 1 = whenever the geometry allows; sabotage: k_predict's (test hooks set both) */
   int singlePassMode = -1, singlePassSabotage = 0;
   bool lastSinglePass = false;    /* the last enqueue ran it */
+  int *hFallback = nullptr;       /* pinned, one per result slot: frames of that batch k_raster had to do (copied with the results) */
+  int resultsFallback[kMaxLanes] = {};      /* -1: that slot's batch ran two passes; 0: count on its way; 1: seen by ssd_fetch_back */
+  int singlePassBackoff = 0;      /* qualifying batches still to run two passes after a batch the predictor did not cover */
   size_t bytes = 0;
   /* per-stage timing: a ring of event sets, one per enqueue, so that a timed loop never has to synchronise */
   bool timing = false;

@@ -16,6 +16,7 @@ constexpr int kCellHost = 64;               /* points per cell (one gating mask 
 /* The single pass (k_hist rasters the step plateaus itself) pays a kernel (k_predict) that a few frames do
  * not earn back; its keys hold 13 bits of row and its windows must fit the image. */
 constexpr int kSinglePassMinFrames = 64;
+constexpr int kSinglePassBackoff = 63;      /* batches run in two passes after one the predictor covered less than half of */
 constexpr int kPredictParts = 4;            /* blocks of k_predict per frame */
 inline bool single_pass_geometry(int W, int H) { return W >= 64 && W <= 8192 && H >= 16 && H <= 4096; }
 

@@ -281,6 +281,12 @@ int ssd_test_single_pass(ssd_handle *h, int mode, int sabotage)
   }
   h->singlePassMode = mode;
   h->singlePassSabotage = sabotage;
+  h->singlePassBackoff = 0;
+  if(mode == 1 && !h->hFallback)
+  {
+    HIP_TRY(hipHostMalloc(&h->hFallback, sizeof(int) * kMaxLanes, hipHostMallocDefault));
+    std::memset(h->hFallback, 0, sizeof(int) * kMaxLanes);
+  }
   return SSD_OK;
 }
 

@@ -91,6 +91,12 @@ def test_single_pass_forced_on_small_batches(ssd, oracle, gpu_device, W, H):
     det.enqueue(buf.ptr, n)
     res = det.fetch_list(n)
     assert parity.check_batch_against_oracle(ssd, oracle, cfg, trans.constants, buf, W * H * 12, res, W, H) == n
+    if W in (1024, 640):
+        # one frame with debug capture, still forced: every record, the raw and the closed image of every step plateau (read
+        # from the planes by k_outline) and the ground image against the oracle's
+        xyz = buf.download(W * H * 12, dtype=np.float32).reshape(H, W, 3)
+        rep = parity.check_frame(ssd, oracle, det, cfg, trans.constants, xyz, images=True)
+        assert rep["images_checked"] >= 2 and det.single_pass_stats(1)["ran"]
     det.close()
     buf.free()
 
@@ -188,5 +194,24 @@ def test_the_predictor_is_timed_beside_the_stages(ssd, gpu_device):
     det.single_pass(0)
     _run(det, buf, n)
     assert det.predict_time_ms() == 0.0 and det.predict_time_ms(back=1) > 0.0
+    det.close()
+    buf.free()
+
+
+def test_a_batch_the_predictor_does_not_cover_switches_the_next_ones_to_two_passes(ssd, gpu_device):
+    """ssd_fetch learns with the results how many frames k_raster had to do; more than half of a batch, and the following batches
+    run two passes (63 of them, then one probes again) - a wrong predictor is paid for once, not per batch."""
+    W, H, n = 1024, 768, 64
+    sc, buf = _batch(ssd, gpu_device, W, H, n, 47000, 47)
+    det = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=n), ssd.transformation_for_scene(sc[0]), gpu_device)
+    good = _run(det, buf, n)
+    assert det.single_pass_stats(n)["ran"]
+    assert _run(det, buf, n) == good and det.single_pass_stats(n)["ran"]         # covered: stays on
+    det.single_pass(-1, 2)                                                      # from now on the predictor gives no planes
+    assert _run(det, buf, n) == good and det.single_pass_stats(n)["ran"]         # this batch pays for it
+    for _ in range(3):
+        assert _run(det, buf, n) == good and not det.single_pass_stats(n)["ran"]
+    det.single_pass(-1, 0)                                                      # (the hook also ends the back-off)
+    assert _run(det, buf, n) == good and det.single_pass_stats(n)["ran"]
     det.close()
     buf.free()
