@@ -200,7 +200,8 @@ struct FrameState
   unsigned int predDone;
   unsigned char specPlane[kMaxBins];
   int nPlanes;
-  int specOk;
+  int specOk;                      /* every step plateau of the frame covered */
+  unsigned int slotCovered;        /* bit s: step image s is made of planes (k_peaks); the others are k_raster's */
   int planeYMin[kMaxPlanes], planeYMax[kMaxPlanes], planeXMin[kMaxPlanes], planeXMax[kMaxPlanes];
   long long planeTotZ[kMaxPlanes];
   unsigned int planeOob[kMaxPlanes];

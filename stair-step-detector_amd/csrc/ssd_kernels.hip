@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(kThreads) void k_predict(const float *__restrict__ 
 __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__ st, int nframes, DebugFrame *__restrict__ dbg, int spec, int *__restrict__ fallback)
 {
   __shared__ unsigned char sImgPlane[kMaxStepImages][2];
-  __shared__ int sSpecOk;
+  __shared__ unsigned int sCovered;
   __shared__ unsigned int hist[kMaxBins + 1];
   __shared__ unsigned char lut[kMaxBins];
   __shared__ int plPeak[kMaxPlateaus], plLo[kMaxPlateaus], plHi[kMaxPlateaus], plEffLo[kMaxPlateaus], plEffHi[kMaxPlateaus], plN[kMaxPlateaus];
@@ -1349,10 +1349,13 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
     }
     sNPl = nPl; sNPeaks = nPeaksDbg; sOverflow = overflow ? 1 : 0; sGround = groundInd; sFirstStep = i; sNImg = nImg;
 
-    /* single pass: did k_predict give every bin of every step plateau a plane?  (A bin without points needs none.) */
-    bool ok = spec != 0;
+    /* single pass: did k_predict give every bin of a step plateau a plane?  (A bin without points needs none.)  Plateau by
+     * plateau: the covered ones are read from their planes, k_raster does the others of the frame (typically a weak last
+     * peak at the top of the range that the sample did not show). */
+    unsigned int covered = 0u;
     for(int slot = 0; slot < nImg; slot++)
     {
+      bool ok = spec != 0;
       unsigned char a = 0xff, b2 = 0xff;
       const int lo = plEffLo[i + slot], hi = plEffHi[i + slot];
       for(int b = lo; b <= hi; b++)                                        /* two bins at most */
@@ -1374,8 +1377,9 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
           ok = ok && hist[hi + 1] == 0u;
       }
       sImgPlane[slot][0] = a; sImgPlane[slot][1] = b2;
+      covered |= ok ? 1u << slot : 0u;
     }
-    sSpecOk = ok ? 1 : 0;
+    sCovered = covered;
   }
   __syncthreads();
 
@@ -1386,7 +1390,7 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
     const unsigned char l = lut[b];
     fs.lut[b] = l;
     const int slot = static_cast<int>(l) - firstStep;
-    if(b < nb && l != 0xff && slot >= 0 && slot < nImg)
+    if(b < nb && l != 0xff && slot >= 0 && slot < nImg && !((sCovered >> slot) & 1u))      /* k_raster's gate: the plateaus it has to do */
       wanted |= 1u << (b / kBinsPerGroup);
   }
 #pragma unroll
@@ -1408,13 +1412,15 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
   }
   /* The step images' boxes and z sums: empty / zero for k_raster to fill, or - single pass, every plateau covered - what
    * k_hist found in the planes of the plateau's bins (k_outline merges those planes into the image). */
-  const bool specOk = sSpecOk != 0;
+  const unsigned int covered = sCovered;
+  const bool specOk = nImg > 0 && covered == (nImg >= 32 ? 0xffffffffu : (1u << nImg) - 1u);
   unsigned int oobSum = 0u;
   if(lane <= kMaxStepImages)                          /* [kMaxStepImages] = the ground image */
   {
     int y0 = 0x7fffffff, y1 = -1, x0 = 0x7fffffff, x1 = -1;
     long long tz = 0;
-    if(specOk && lane < nImg)
+    const bool mine = lane < nImg && ((covered >> lane) & 1u) != 0u;
+    if(mine)
     {
 #pragma unroll
       for(int k = 0; k < 2; k++)
@@ -1436,8 +1442,8 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
     if(lane < kMaxStepImages)
     {
       fs.totZ[lane] = tz;                              /* k_raster's sums start from zero */
-      fs.imgPlane[lane][0] = specOk && lane < nImg ? sImgPlane[lane][0] : static_cast<unsigned char>(0xff);
-      fs.imgPlane[lane][1] = specOk && lane < nImg ? sImgPlane[lane][1] : static_cast<unsigned char>(0xff);
+      fs.imgPlane[lane][0] = mine ? sImgPlane[lane][0] : static_cast<unsigned char>(0xff);
+      fs.imgPlane[lane][1] = mine ? sImgPlane[lane][1] : static_cast<unsigned char>(0xff);
     }
   }
 #pragma unroll
@@ -1446,9 +1452,8 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
   if(spec && lane < kMaxPlanes)
   {
     bool used = false;
-    if(specOk)
-      for(int sl = 0; sl < nImg; sl++)
-        used = used || sImgPlane[sl][0] == lane || sImgPlane[sl][1] == lane;
+    for(int sl = 0; sl < nImg; sl++)
+      used = used || (((covered >> sl) & 1u) != 0u && (sImgPlane[sl][0] == lane || sImgPlane[sl][1] == lane));
     fs.planeUsed[lane] = used ? 1 : 0;
   }
   if(lane == 0)
@@ -1456,6 +1461,7 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
     if(spec && !specOk && nImg > 0)
       fallback[1 + atomicAdd(&fallback[0], 1)] = frame;          /* k_raster's work list (k_predict zeroed the count) */
     fs.specOk = specOk ? 1 : 0;
+    fs.slotCovered = covered;
     fs.nNonZero = fs.nNonZeroAcc;
     fs.nNonZeroAcc = 0u;
     fs.nOob = oobSum;
@@ -1539,14 +1545,15 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
   const int firstStep = fs.firstStep;
   const unsigned char lutMine = tid < kMaxBins ? fs.lut[tid] : static_cast<unsigned char>(0xff);
   const unsigned int wantedSteps = fs.wantedSteps;
-  if(nImg == 0 || fs.specOk)                 /* single pass: k_hist has rastered this frame's plateaus already */
+  const unsigned int slotCovered = fs.slotCovered;        /* single pass: plateaus k_hist has rastered already (k_peaks; 0 otherwise) */
+  if(nImg == 0 || wantedSteps == 0u)
     return;
   BlockPhase ph(0);
   if(tid < kMaxBins)
   {
     /* bin -> image slot of a step plateau, 0xff = no image for this bin */
     const int sl = static_cast<int>(lutMine) - firstStep;
-    lut[tid] = (lutMine != 0xff && sl >= 0 && sl < nImg) ? static_cast<unsigned char>(sl) : static_cast<unsigned char>(0xff);
+    lut[tid] = (lutMine != 0xff && sl >= 0 && sl < nImg && !((slotCovered >> sl) & 1u)) ? static_cast<unsigned char>(sl) : static_cast<unsigned char>(0xff);
   }
   if(tid < kMaxStepImages)
     boxes[tid] = ImageBox{ 0x7fffffff, -1, 0x7fffffff, -1 };
@@ -1862,7 +1869,8 @@ __global__ __launch_bounds__(T) void k_outline(Params P, FrameState *__restrict_
    * plateau's (two) bins, read together (BitImg::w2).  Its box (k_peaks) is the union of the planes' boxes. */
   unsigned long long *img = stepImg + (static_cast<size_t>(frame) * P.maxStepImages + slot) * imgWords;
   unsigned long long *img2 = nullptr;
-  if(planeImg && fs.specOk)
+  const bool fromPlanes = planeImg && ((fs.slotCovered >> slot) & 1u) != 0u;
+  if(fromPlanes)
   {
     const int pa = fs.imgPlane[slot][0], pb = fs.imgPlane[slot][1];
     if(pa != 0xff)
@@ -2370,7 +2378,7 @@ __global__ __launch_bounds__(T) void k_outline(Params P, FrameState *__restrict_
       if(img2)
         img2[o] = 0ull;
     }
-    if(planeImg && fs.specOk && tid < 2)
+    if(fromPlanes && tid < 2)
     {
       /* the planes' boxes go with their bits (k_predict resets them as well; this keeps "box empty = plane zero" at all times) */
       const int p = fs.imgPlane[slot][tid];
