@@ -48,7 +48,7 @@ long long ssd_test_frame_state(ssd_handle *h, int frame, void *out, size_t cap, 
  * and ssd_enqueue_stages(SSD_STAGE_FINAL): the case calcAverageZ divides 0.0 by 0 in (pointcloud.cpp:574-581). */
 int ssd_test_empty_quadrilateral(ssd_handle *h, int frame, int surface);
 /* The single pass (K1 rasters the step plateaus itself into planes of predicted height bins).  mode: -1 = as
- * the product decides (whole pipeline, a batch of >= 64 frames, a tile a whole number of camera rows), 0 = never, 1 = whenever the
+ * the product decides (whole pipeline, vertex input, a batch of at least 64 XGA frames' worth of points), 0 = never, 1 = whenever the
  * geometry allows (a handle without planes gets them).  sabotage: 0 = none, 1 = the predictor's planes three bins above the right
  * ones, 2 = no planes at all - either way every frame with steps must come out through k_raster, bit-equal. */
 int ssd_test_single_pass(ssd_handle *h, int mode, int sabotage);

@@ -416,7 +416,7 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   const size_t stepBytes = static_cast<size_t>(h->F) * P.maxStepImages * h->imgWords * 8;
   const size_t groundBytes = static_cast<size_t>(h->F) * h->imgWords * 8;
   /* the planes of the single pass, for handles whose batches can qualify (ssd_launch.h) */
-  const size_t planeBytes = single_pass_geometry(P.W, P.H) && h->F >= kSinglePassMinFrames
+  const size_t planeBytes = single_pass_geometry(P.W, P.H) && single_pass_batch(h->F, P.nPoints)
                             ? static_cast<size_t>(h->F) * kMaxPlanes * h->imgWords * 8 : 0;
   auto cleanup = [&]() { ssd_destroy(h); };
 #define HIP_TRY_H(expr)                                                                                 \
@@ -780,7 +780,7 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
   unsigned long long *planeImg = nullptr;
   /* (not on 16-bit depth input: K1 is bound by instruction issue there, not by the bytes a second pass would re-read - k_raster
    * reads a sixth of them -, and the raster's instructions cost K1 what k_raster took: 384.6 k against 386.8 k frames/s) */
-  if(L.dPlaneImg && stages == SSD_STAGE_ALL && h->singlePassMode != 0 && (h->singlePassMode == 1 || (nframes >= kSinglePassMinFrames && !depthInput)))
+  if(L.dPlaneImg && stages == SSD_STAGE_ALL && h->singlePassMode != 0 && (h->singlePassMode == 1 || (single_pass_batch(nframes, P.nPoints) && !depthInput)))
   {
     if(h->singlePassMode == 1 || h->singlePassBackoff == 0)
       planeImg = L.dPlaneImg;

@@ -90,8 +90,9 @@ struct ssd_handle
   unsigned long long *dDebugImg = nullptr;
   int debug = 0;                  /* 0 off, 1 records + images (the whole ground image is rastered for it), 2 records only */
   int lastFrames = 0;
-  /* single pass (k_hist rasters the step plateaus itself): -1 = whenever a call qualifies (whole pipeline, >= kSinglePassMinFrames
-   * frames, geometry), 0 = never, 1 = whenever the geometry allows; sabotage: k_predict's (test hooks set both) */
+  /* single pass (k_hist rasters the step plateaus itself): -1 = whenever a call qualifies (whole pipeline, a batch of at least
+   * kSinglePassMinPoints points, vertex input, geometry), 0 = never, 1 = whenever the geometry allows; sabotage: k_predict's (test
+   * hooks set both) */
   int singlePassMode = -1, singlePassSabotage = 0;
   bool lastSinglePass = false;    /* the last enqueue ran it */
   int *hFallback = nullptr;       /* pinned, one per result slot: frames of that batch k_raster had to do (copied with the results) */

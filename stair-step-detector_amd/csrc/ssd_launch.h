@@ -15,7 +15,10 @@ constexpr int kMaxTilesPerBlockInquadHost = 128;   /* K4 only */
 constexpr int kCellHost = 64;               /* points per cell (one gating mask each) */
 /* The single pass (k_hist rasters the step plateaus itself) pays a kernel (k_predict) that a few frames do
  * not earn back; its keys hold 13 bits of row and its windows must fit the image. */
-constexpr int kSinglePassMinFrames = 64;
+/* from 64 XGA frames per batch on (tools/sp_frames.py: 48 frames 3 % slower, 64 frames 4 % faster; VGA between 128 and 192
+ * frames, FHD around 24-64): by points */
+constexpr long long kSinglePassMinPoints = 64ll * 1024 * 768;
+inline bool single_pass_batch(int nframes, int nPoints) { return static_cast<long long>(nframes) * nPoints >= kSinglePassMinPoints; }
 constexpr int kSinglePassBackoff = 63;      /* batches run in two passes after one the predictor covered less than half of */
 constexpr int kPredictParts = 4;            /* blocks of k_predict per frame */
 inline bool single_pass_geometry(int W, int H) { return W >= 64 && W <= 8192 && H >= 16 && H <= 4096; }

@@ -24,7 +24,7 @@ def _batch(ssd, gpu_device, W, H, n, base_seed, rng_seed):
 
 
 def test_single_pass_covers_the_batch_and_matches_the_two_pass_pipeline(ssd, oracle, gpu_device):
-    """256 XGA staircase frames: the default handle runs the single pass on them (a batch of >= 64 frames), the predictor covers
+    """256 XGA staircase frames: the default handle runs the single pass on them (a batch of at least 64 XGA frames' worth of points), the predictor covers
     nearly every frame, the planes are zero afterwards, and the results equal those of the same handle with the single pass
     switched off - and the oracle's, every frame."""
     W, H, n = 1024, 768, 256
@@ -76,7 +76,7 @@ def test_a_wrong_predictor_costs_time_not_results(ssd, gpu_device, sabotage):
 def test_single_pass_forced_on_small_batches(ssd, oracle, gpu_device, W, H):
     """Geometries whose tile of 1024 points is one, two or four camera rows (K1 walks its chunk tile by tile) and geometries where
     it is not (K1 walks the chunk's strips of 256 points sorted by column band; 848 is not even a whole number of cells), 12
-    frames with the single pass forced on (the product only takes it for batches of 64 and more), against two passes and the oracle."""
+    frames with the single pass forced on (the product only takes it for batches of 64 XGA frames' worth of points and more), against two passes and the oracle."""
     n = 12
     sc, buf = _batch(ssd, gpu_device, W, H, n, 43000 + W, 43)
     trans = ssd.transformation_for_scene(sc[0])
@@ -102,8 +102,9 @@ def test_single_pass_forced_on_small_batches(ssd, oracle, gpu_device, W, H):
 
 
 def test_single_pass_on_a_vga_batch_with_depth_input(ssd, oracle, gpu_device):
-    """640 x 480 (a tile is 1.6 camera rows: the sorted strips), 128 frames as the product runs them, vertices and 16-bit depth"""
-    W, H, n = 640, 480, 128
+    """640 x 480 (a tile is 1.6 camera rows: the sorted strips), 192 frames as the product runs them (it takes the single pass from
+    64 XGA frames' worth of points on: 164 VGA frames), vertices and 16-bit depth"""
+    W, H, n = 640, 480, 192
     sc, buf = _batch(ssd, gpu_device, W, H, n, 44000, 44)
     trans = ssd.transformation_for_scene(sc[0])
     cfg = ssd.default_config(W, H, max_frames_per_batch=n)

@@ -1,12 +1,12 @@
-"""tools/sp_frames.py — from how many frames per batch does the single pass pay?  XGA, three batches in flight, two passes against
+"""tools/sp_frames.py [W H F,F,..] — from how many frames per batch does the single pass pay?  XGA, three batches in flight, two passes against
 the single pass forced on, alternating"""
 import importlib, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 ssd = importlib.import_module("stair-step-detector_amd")
 import scenes
-W, H = 1024, 768
-for F in (8, 16, 32, 48, 64, 128):
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1024, 768)
+for F in ([int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else (8, 16, 32, 48, 64, 128)):
     sc = scenes.batch_scenes(ssd, W, H, F, base_seed=100000, rng_seed=1000)
     det = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=F, batches_in_flight=3), ssd.transformation_for_scene(sc[0]), 0)
     buf = ssd.DeviceBuffer(W * H * 12 * F, 0)
