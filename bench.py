@@ -445,6 +445,20 @@ def main():
             "pipeline_bytes_moved": pipeline_moved,
             "pipeline_bytes_algorithmic_frac_of_peak": (alg_bytes * args.steps / dt_max / 1e9) / HBM_PEAK_GBS,
         }
+        # the dominant kernel's own issue floor: in the single pass K1 also rasters, and sits nearer to the vector-issue roof than to HBM's
+        if os.path.exists(pi):
+            try:
+                kernels = json.load(open(pi))["kernels"]
+                want = "k_hist_planes" if single_pass["ran"] else "k_hist<"
+                hit = [v for k, v in kernels.items() if want in k and "SQ_INSTS_VALU" in v]
+                if hit and k1_ms > 0 and not depth_in and not fhd and F == 1024:
+                    vf = hit[0]["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9) * 1e3
+                    out["roofline"]["issue"] = {"valu_instructions_per_launch": hit[0]["SQ_INSTS_VALU"], "valu_floor_ms": vf, "frac_of_issue_peak": vf / k1_ms,
+                                                "valu_busy_percent_one_batch_at_a_time": hit[0].get("VALUBusy"),
+                                                "note": "the kernel's vector instructions x 4 cycles / (1024 SIMDs x 2.4 GHz) over its measured launch time; counters: "
+                                                        "profiles/pmc_issue.json (committed pass of this command)"}
+            except Exception:
+                pass
         if floors is not None:           # the whole pass's floors beside the dominant kernel's roofline
             out["roofline"]["valu_floor_ms"] = floors["valu_floor_ms"]
             out["roofline"]["hbm_floor_ms"] = floors["hbm_floor_ms"]
