@@ -59,6 +59,10 @@ int ssd_test_single_pass_stats(ssd_handle *h, int frames, int scan_planes, long 
 /* one frame of the last enqueue: the predictor's table (height bin -> plane, 0xff = none; SSD_MAX_BINS entries),
  * info[0] = planes, info[1] = 1 when they covered the frame's step plateaus, info[2] = step plateaus */
 int ssd_test_single_pass_frame(ssd_handle *h, int frame, uint8_t *plane_of_bin, int info[3]);
+/* the same frame's sample histogram (SSD_MAX_BINS counts): what k_predict made that table of */
+int ssd_test_single_pass_sample(ssd_handle *h, int frame, uint32_t *sample);
+/* the predictor's table as csrc/ssd_predict.h states it (host; no GPU): sample[SSD_MAX_BINS] -> plane_of_bin[SSD_MAX_BINS], returns the planes */
+int ssd_test_predict_table_host(const uint32_t *sample, int n_bins, int min_height, int sabotage, uint8_t *plane_of_bin);
 /* tools hook (tools/k1place.py): places the first workspace's cell records `offset_bytes` (a multiple of 8, within the extra bytes a
  * preceding ssd_test_record_realloc_sized asked for) into their allocation; the records' content is undefined afterwards until the
  * next full enqueue */

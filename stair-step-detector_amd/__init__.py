@@ -150,7 +150,7 @@ SOURCE_EXPORTS = [
 # libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
 HOOK_EXPORTS = [
     "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_ground_image", "ssd_test_line_host", "ssd_test_intersect_host", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_best_line_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
-    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_test_single_pass", "ssd_test_single_pass_stats", "ssd_test_single_pass_frame", "ssd_test_record_offset", "ssd_test_record_realloc", "ssd_test_record_realloc_sized", "ssd_test_record_release", "ssd_testhooks_last_error",
+    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_test_single_pass", "ssd_test_single_pass_stats", "ssd_test_single_pass_frame", "ssd_test_single_pass_sample", "ssd_test_predict_table_host", "ssd_test_record_offset", "ssd_test_record_realloc", "ssd_test_record_realloc_sized", "ssd_test_record_release", "ssd_testhooks_last_error",
 ]
 SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
 HOOKS_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_testhooks.so")
@@ -271,6 +271,8 @@ def hooks_lib():
     L.ssd_test_single_pass.argtypes = [vp, i32, i32]
     L.ssd_test_single_pass_stats.argtypes = [vp, i32, i32, vp]
     L.ssd_test_single_pass_frame.argtypes = [vp, i32, vp, vp]
+    L.ssd_test_single_pass_sample.argtypes = [vp, i32, vp]
+    L.ssd_test_predict_table_host.argtypes = [vp, i32, i32, i32, vp]
     L.ssd_test_record_offset.argtypes = [vp, C.c_size_t]
     L.ssd_test_record_realloc.argtypes = [vp]
     L.ssd_test_record_realloc.restype = C.c_ulonglong
@@ -293,6 +295,15 @@ def _check(rc, which="hip"):
                "hooks": lambda: hooks_lib().ssd_testhooks_last_error()}[which]().decode()
         raise SsdError("libssd_%s error %d: %s" % (which, rc, msg))
     return rc
+
+
+def predict_table_host(sample, n_bins, min_height, sabotage=0):
+    """test hook (host, no GPU): the single pass's bin -> plane table as csrc/ssd_predict.h states it; returns (uint8[MAX_BINS], planes)"""
+    a = np.ascontiguousarray(sample, dtype=np.uint32)
+    assert a.size == MAX_BINS
+    out = np.zeros(MAX_BINS, dtype=np.uint8)
+    n = _check(hooks_lib().ssd_test_predict_table_host(a.ctypes.data_as(C.c_void_p), n_bins, min_height, sabotage, out.ctypes.data_as(C.c_void_p)), "hooks")
+    return out, n
 
 
 def device_info(device):
@@ -522,6 +533,12 @@ class Detector:
         info = (C.c_int32 * 3)()
         _check(hooks_lib().ssd_test_single_pass_frame(self._h, frame, table, info), "hooks")
         return np.frombuffer(bytes(table), dtype=np.uint8).copy(), int(info[0]), bool(info[1]), int(info[2])
+
+    def single_pass_sample(self, frame):
+        """test hook: the sample histogram k_predict made the frame's table of (uint32[MAX_BINS])"""
+        out = np.zeros(MAX_BINS, dtype=np.uint32)
+        _check(hooks_lib().ssd_test_single_pass_sample(self._h, frame, out.ctypes.data_as(C.c_void_p)), "hooks")
+        return out
 
     def record_offset(self, offset_bytes):
         """tools hook: where the first workspace's cell records lie inside their allocation"""

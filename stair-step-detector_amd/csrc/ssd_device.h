@@ -199,6 +199,7 @@ struct FrameState
   unsigned int predHist[kMaxBins];
   unsigned int predDone;
   unsigned char specPlane[kMaxBins];
+  unsigned int predSample[kMaxBins];   /* the sample histogram the table was made of (kept for the tests: ssd_predict.h) */
   int nPlanes;
   int specOk;                      /* every step plateau of the frame covered */
   unsigned int slotCovered;        /* bit s: step image s is made of planes (k_peaks); the others are k_raster's */

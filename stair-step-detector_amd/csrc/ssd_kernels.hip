@@ -14,6 +14,14 @@
  * -ffp-contract=off): the reference is built without FMA (CMakeLists.txt:23-28) and one
  * flipped bin or pixel moves a corner by more than the parity bar.
  * K1 is HBM-read bound (12 B per raw point), K2 / K4 re-read a third of the points and are VALU-issue bound; no MFMA anywhere.
+ *
+ * Batches of 64 XGA frames' worth of points and more (vertex input, the whole pipeline in one call) run the SINGLE PASS instead:
+ *   K0 k_predict      histogram of a sample of the frame -> the height bins that may hold a step plateau, a plane (bit image) each
+ *   K1 k_hist_planes  k_hist, and the raster of those bins' points into their planes
+ *   K1b k_peaks       ... and which step plateaus the planes cover; the frames with others on k_raster's work list
+ *   K2 k_raster       only the listed frames' uncovered plateaus
+ *   K3 k_outline      reads a covered plateau's plane(s) in place of its step image
+ * Nothing the predictor says can change a result ("The single pass").
  */
 #include "ssd_device.h"
 #include "ssd_math.h"
@@ -579,8 +587,11 @@ constexpr long long kMagicBits = 0x40B8000000000000ll;       /* bits of 6144.0 *
  * K1 rasters the points of the bins k_predict chose, one bit image ("plane") per height bin: which two adjacent bins make a
  * plateau is only known once the histogram is complete (k_peaks), and range noise spreads a tread over two or three bins
  * whose pixels interleave.  A window over one image would send every pixel of the minority bins to memory; this one
- * holds the same patch of four consecutive planes (one tread's bins and a spare), 16 rows x 8 words each: 4 KiB per wave.  Keys
- * as pixel_key with the plane in the slot field, "inside" by one subtraction and one AND as window_hit. */
+ * holds the same patch of 2^kSpecPlaneBits consecutive planes, 2^kSpecRowBits rows x 8 words each (2 x 16 x 8: 2 KiB per wave;
+ * 4 planes x 16 rows, 2 x 32 and 1 x 32 measured the same or slower, 4 x 32 - three blocks per CU - much slower:
+ * profiles/r04_single_pass_ab.txt).  Keys as pixel_key with the plane in the slot field, "inside" by one subtraction and one
+ * AND as window_hit.  Since k_predict gives a tread whose fuller neighbour bin is beyond doubt ONE plane for both bins, most
+ * treads live in a single plane anyway. */
 #ifndef SSD_SPEC_PLANE_BITS
 #define SSD_SPEC_PLANE_BITS 1
 #endif
@@ -1016,7 +1027,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ 
   hist_block<SRC, false, false>(L, none, xyz, strideFloats, P, PixelParams{}, st, tileMasks, nullptr, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);   /* frame on the fast grid axis: see launch note on XCD balance */
 }
 
-/* K1 of a single-pass batch: histogram, cell records AND the planes of the candidate bins.  39 KiB of LDS: four blocks per CU. */
+/* K1 of a single-pass batch: histogram, cell records AND the planes of the candidate bins.  31 KiB of LDS: five blocks per CU
+ * (4 .. 6 measure the same). */
 #ifndef SSD_K1S_WAVES
 #define SSD_K1S_WAVES 5
 #endif
@@ -1106,10 +1118,14 @@ __global__ __launch_bounds__(kThreads) void k_predict(const float *__restrict__ 
   const unsigned int mineCount = tid < P.nBins ? atomicExch(&fs.predHist[tid], 0u) : 0u;
   __syncthreads();
   if(tid < kMaxBins)
+  {
     sh[1 + tid] = mineCount;
+    fs.predSample[tid] = mineCount;
+  }
   if(tid == 0)
     sh[0] = sh[kMaxBins + 1] = 0u;
   __syncthreads();
+  /* (the table as a plain function of the sample: ssd_predict.h - the tests hold this kernel's table against it) */
   /* candidate peak: filterPeaks' two conditions (>= 2000 points; twice the count exceeds the neighbours' sum by more than
    * half the count) on the sample: from 1200 points scaled up, the sharpness as it is plus a few samples.  (A tread stands
    * far above both thresholds.  Looser - the neighbours' sum below 1.75 counts - and a flat background of a few thousand
@@ -1353,7 +1369,7 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
      * plateau: the covered ones are read from their planes, k_raster does the others of the frame (typically a weak last
      * peak at the top of the range that the sample did not show). */
     unsigned int covered = 0u;
-    for(int slot = 0; slot < nImg; slot++)
+    for(int slot = 0; spec && slot < nImg; slot++)
     {
       bool ok = spec != 0;
       unsigned char a = 0xff, b2 = 0xff;

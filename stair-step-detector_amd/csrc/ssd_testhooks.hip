@@ -5,6 +5,7 @@
  */
 #include "ssd_handle.h"
 #include "ssd_launch.h"
+#include "ssd_predict.h"
 #include "ssd_math.h"
 #include "ssd_quadtest.h"
 #include "ssd_closing.h"
@@ -332,6 +333,23 @@ int ssd_test_single_pass_frame(ssd_handle *h, int frame, uint8_t *plane_of_bin, 
   std::memcpy(plane_of_bin, fs.specPlane, kMaxBins);
   info[0] = fs.nPlanes; info[1] = fs.specOk; info[2] = fs.nStepImages;
   return SSD_OK;
+}
+
+int ssd_test_single_pass_sample(ssd_handle *h, int frame, uint32_t *sample)
+{
+  if(!h || !sample || frame < 0 || frame >= h->F)
+    return fail(SSD_E_ARG, "ssd_test_single_pass_sample: bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(sample, h->lane[h->lastLane].dState[frame].predSample, sizeof(unsigned int) * kMaxBins, hipMemcpyDeviceToHost));
+  return SSD_OK;
+}
+
+int ssd_test_predict_table_host(const uint32_t *sample, int n_bins, int min_height, int sabotage, uint8_t *plane_of_bin)
+{
+  if(!sample || !plane_of_bin || n_bins < 2 || n_bins > kMaxBins || sabotage < 0 || sabotage > 2)
+    return fail(SSD_E_ARG, "ssd_test_predict_table_host: bad argument");
+  return predict_table(sample, n_bins, min_height, sabotage, plane_of_bin);
 }
 
 /* the kernels' line helpers (csrc/ssd_math.h: line_through_i / line_through_d = LineCoordinates(p, q), types.h:140-158; intersect60 =

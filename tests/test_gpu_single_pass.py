@@ -216,3 +216,37 @@ def test_a_batch_the_predictor_does_not_cover_switches_the_next_ones_to_two_pass
     assert _run(det, buf, n) == good and det.single_pass_stats(n)["ran"]
     det.close()
     buf.free()
+
+
+@pytest.mark.parametrize("W,H,n,sabotage", [(1024, 768, 128, 0), (1024, 768, 64, 1), (640, 480, 32, 0), (1920, 1080, 16, 0)])
+def test_the_kernels_table_is_the_host_statements(ssd, gpu_device, W, H, n, sabotage):
+    """k_predict makes its bin -> plane table with one thread per bin (ballots, rank counting); csrc/ssd_predict.h states it as a
+    plain function (tests/test_predict.py checks that one on the CPU).  On every frame: the table the kernel left equals the
+    function of the sample the kernel counted."""
+    if W == 1920:
+        sc = scenes.fhd_stress_scenes(ssd, n, base_seed=9100)
+    else:
+        sc = scenes.batch_scenes(ssd, W, H, n, base_seed=48000 + W, rng_seed=48)
+    buf = ssd.DeviceBuffer(W * H * 12 * n, gpu_device)
+    ssd.synth_device(sc, buf.ptr, device=gpu_device)
+    cfg = ssd.default_config(W, H, max_frames_per_batch=n)
+    det = ssd.Detector(cfg, ssd.transformation_for_scene(sc[0]), gpu_device)
+    det.set_debug(True, images=False)                                        # the handle's bin count and lowest step bin, from a debug record
+    det.enqueue(buf.ptr, 1)
+    det.fetch(1)
+    n_bins, min_height = det.debug(0).n_bins, det.debug(0).min_height
+    det.set_debug(False)
+    det.single_pass(1, sabotage)
+    det.enqueue(buf.ptr, n)
+    det.fetch(n)
+    total_planes = 0
+    for i in range(n):
+        table, planes, _, _ = det.single_pass_frame(i)
+        sample = det.single_pass_sample(i)
+        assert int(sample.sum()) > W * H // 16 // 4                          # a sixteenth of the frame, most of it in range
+        host, host_planes = ssd.predict_table_host(sample, n_bins, min_height, sabotage)
+        assert planes == host_planes and np.array_equal(table, host), "frame %d" % i
+        total_planes += planes
+    assert total_planes >= n
+    det.close()
+    buf.free()

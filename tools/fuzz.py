@@ -26,6 +26,7 @@ def main():
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     mixed = len(sys.argv) > 4 and sys.argv[4] == "mixed"
     rng = np.random.default_rng(seed)
+    only = set(int(x) for x in os.environ["FUZZ_ONLY"].split(",")) if os.environ.get("FUZZ_ONLY") else None
     oracle = ob.load_oracle()
     cores = len(os.sched_getaffinity(0))
     total = bad = thrown = 0
@@ -46,7 +47,7 @@ def main():
                             yaw_deg=float(rng.uniform(-45.0, 45.0)) if rng.random() < 0.5 else float(rng.uniform(-10.0, 10.0)),
                             sigma=float(rng.uniform(0.0, 0.004)), outlier_frac=float(rng.choice([0.0, 0.0, 0.01, 0.05, 0.15])),
                             invalid_frac=float(rng.choice([0.0, 0.0, 0.02, 0.2]))))
-        scenes = [ssd.make_scene(W, H, **kw) for kw in kws]
+        scenes = [ssd.make_scene(W, H, **kw) for kw in kws] if only is None or pose in only else [ssd.make_scene(W, H, **kws[0])]
         trans = ssd.transformation_for_scene(scenes[0])
         # workspaces of the handle: the library's choice (3 from 128 frames on), or one (every call in the same workspace)
         cfg = ssd.default_config(W, H, max_frames_per_batch=F, batches_in_flight=int(rng.choice([1, 3])))
@@ -61,9 +62,14 @@ def main():
                 cfg.height_interval = float(rng.choice([0.01, 0.01, 0.0125, 0.015, 0.02]))
                 cfg.min_height_above_ground = float(rng.uniform(0.03, 0.09))
                 cfg.min_step_depth = float(rng.uniform(0.05, 0.2))
-        det = ssd.Detector(cfg, trans, 0)
         risers = mixed and rng.random() < 0.5
         r_tol, r_min = float(rng.uniform(0.01, 0.06)), int(rng.integers(1, 3000))
+        if only is not None and pose not in only:
+            # FUZZ_ONLY=<pose>[,<pose>..]: the other poses only draw their random numbers (the same stream as a full run)
+            if not depth_in and F > 1:
+                rng.integers(1, F)
+            continue
+        det = ssd.Detector(cfg, trans, 0)
         if risers:
             det.set_risers(True, r_tol, r_min)
         if depth_in:
