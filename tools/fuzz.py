@@ -26,6 +26,7 @@ def main():
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     mixed = len(sys.argv) > 4 and sys.argv[4] == "mixed"
     rng = np.random.default_rng(seed)
+    sab_rng = np.random.default_rng(seed + 1) if os.environ.get("FUZZ_SABOTAGE") else None
     only = set(int(x) for x in os.environ["FUZZ_ONLY"].split(",")) if os.environ.get("FUZZ_ONLY") else None
     oracle = ob.load_oracle()
     cores = len(os.sched_getaffinity(0))
@@ -70,6 +71,17 @@ def main():
                 rng.integers(1, F)
             continue
         det = ssd.Detector(cfg, trans, 0)
+        # FUZZ_SABOTAGE=1: per pose, the single pass's predictor left alone, sabotaged (planes in the wrong bins / none: every frame must
+        # come out through k_raster) or the single pass forced on whatever the batch - drawn from a stream of its own, so that the poses
+        # stay those of a plain run
+        sab_note = ""
+        if sab_rng is not None:
+            mode, sab = [(-1, 0), (-1, 1), (-1, 2), (1, 0), (1, 1), (0, 0)][int(sab_rng.integers(0, 6))]
+            try:
+                det.single_pass(mode, sab)
+                sab_note = " sp(%d,%d)" % (mode, sab)
+            except ssd.SsdError:
+                sab_note = " sp(refused)"
         if risers:
             det.set_risers(True, r_tol, r_min)
         if depth_in:
@@ -120,7 +132,7 @@ def main():
                                                                                "min_height_above_ground", "min_step_depth")}, "error": err[:300]})
         det.close()
         buf.free()
-        print("pose %d %dx%d x%d%s: cam %.2f m, pitch %.1f, roll %.1f -> %d mismatches so far" % (pose, W, H, F, (" depth16" if depth_in else "") + (" risers" if risers else ""), cam_height, pitch, roll, bad), flush=True)
+        print("pose %d %dx%d x%d%s: cam %.2f m, pitch %.1f, roll %.1f -> %d mismatches so far" % (pose, W, H, F, (" depth16" if depth_in else "") + (" risers" if risers else "") + sab_note, cam_height, pitch, roll, bad), flush=True)
     out = {"frames": total, "mismatches": bad, "would_have_thrown": thrown, "steps_histogram": hist, **worst, "failures": failures[:20]}
     print(json.dumps(out))
     return 1 if bad else 0
