@@ -8,3 +8,5 @@ PMC_BENCH_ARGS="--batches-in-flight 1" bash tools/pmc.sh $TAG "SQ_INSTS_VALU SQ_
 bash tools/profile.sh $TAG > gpurun_out/$TAG/profile.txt 2>&1
 python3 tools/fuzz.py 176 384 20264 mixed > gpurun_out/$TAG/fuzz.txt 2>&1; tail -1 gpurun_out/$TAG/fuzz.txt | cut -c1-400
 python3 tools/fuzz_slabs.py > gpurun_out/$TAG/fuzz_slabs.txt 2>&1; tail -1 gpurun_out/$TAG/fuzz_slabs.txt | cut -c1-300
+# a GPU fault anywhere above fails the run, whatever the steps' exit codes were
+if grep -l -a "Memory access fault\|GPU core dump" gpurun_out/$TAG/*.txt gpurun_out/prof_$TAG/*.log gpurun_out/pmc_$TAG/*.log 2>/dev/null; then echo "GPU fault reported in the files above"; exit 1; fi
