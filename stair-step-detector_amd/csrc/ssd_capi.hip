@@ -452,14 +452,14 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
     {
       HIP_TRY_H(hipMalloc(&L.dPlaneImg, planeBytes));
       HIP_TRY_H(hipMemset(L.dPlaneImg, 0, planeBytes));
-      HIP_TRY_H(hipMalloc(&L.dFallback, sizeof(int) * (1 + static_cast<size_t>(h->F))));
-      HIP_TRY_H(hipMemset(L.dFallback, 0, sizeof(int) * (1 + static_cast<size_t>(h->F))));
+      HIP_TRY_H(hipMalloc(&L.dFallback, sizeof(int) * (kFallbackList + static_cast<size_t>(h->F))));
+      HIP_TRY_H(hipMemset(L.dFallback, 0, sizeof(int) * (kFallbackList + static_cast<size_t>(h->F))));
     }
   }
   if(planeBytes)
   {
-    HIP_TRY_H(hipHostMalloc(&h->hFallback, sizeof(int) * kMaxLanes, hipHostMallocDefault));
-    std::memset(h->hFallback, 0, sizeof(int) * kMaxLanes);
+    HIP_TRY_H(hipHostMalloc(&h->hFallback, sizeof(int) * 2 * kMaxLanes, hipHostMallocDefault));
+    std::memset(h->hFallback, 0, sizeof(int) * 2 * kMaxLanes);
   }
   const size_t resBytes = sizeof(ssd_frame_result) * h->F * h->nSlots;
   HIP_TRY_H(hipMalloc(&h->dResults, resBytes));
@@ -880,7 +880,7 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
     h->resultsFallback[slot] = -1;
     if(planeImg && h->hFallback)
     {
-      HIP_TRY(hipMemcpyAsync(h->hFallback + slot, L.dFallback, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(h->hFallback + 2 * slot, L.dFallback, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
       h->resultsFallback[slot] = 0;
     }
     HIP_TRY(hipEventRecord(h->resultsReady[slot], s));
@@ -1021,13 +1021,16 @@ int ssd_fetch_back(ssd_handle *h, ssd_frame_result *results, int nframes, int ba
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipEventSynchronize(h->resultsReady[slot]));
   std::memcpy(results, h->hResults + static_cast<size_t>(slot) * h->F, sizeof(ssd_frame_result) * nframes);
-  /* The single pass pays when its predictor covers the frames.  A batch of which k_raster had to do more than half (scenes
-   * without a sharp peak per tread, or far more treads than planes) says the input is of the other kind: the next
-   * kSinglePassBackoff qualifying batches run two passes, then one batch probes again.  Results do not depend on it. */
+  /* The single pass pays when there are step plateaus to raster and its predictor covers them.  A batch of which k_raster had to
+   * do more than half of the frames (scenes without a sharp peak per tread, or far more treads than planes), or of which fewer
+   * than a quarter of the frames had a step plateau at all (no stairs in sight: k_predict and K1's idle raster code cost 7 % and
+   * k_raster would have had nothing to do anyway), says the input is of the other kind: the next kSinglePassBackoff qualifying
+   * batches run two passes, then one batch probes again.  Results do not depend on it. */
   if(h->resultsFallback[slot] == 0)
   {
     h->resultsFallback[slot] = 1;                       /* counted once */
-    if(2 * h->hFallback[slot] > h->resultsFrames[slot])
+    const int listed = h->hFallback[2 * slot], withSteps = h->hFallback[2 * slot + 1], frames = h->resultsFrames[slot];
+    if(2 * listed > frames || 4 * withSteps < frames)
       h->singlePassBackoff = kSinglePassBackoff;
   }
   return SSD_OK;

@@ -1212,7 +1212,10 @@ __global__ __launch_bounds__(kThreads) void k_predict(const float *__restrict__ 
     fs.nPlanes = fits ? total : 0;
     fs.predDone = 0u;
     if(frame == 0)
-      fallback[0] = 0;                     /* k_raster's work list of this batch starts empty (k_peaks appends) */
+    {
+      fallback[0] = 0;                   /* k_raster's work list of this batch starts empty (k_peaks appends) */
+      fallback[1] = 0;                   /* frames with step plateaus (k_peaks counts) */
+    }
   }
 }
 
@@ -1475,7 +1478,9 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
   if(lane == 0)
   {
     if(spec && !specOk && nImg > 0)
-      fallback[1 + atomicAdd(&fallback[0], 1)] = frame;          /* k_raster's work list (k_predict zeroed the count) */
+      fallback[kFallbackList + atomicAdd(&fallback[0], 1)] = frame;          /* k_raster's work list (k_predict zeroed the count) */
+    if(spec && nImg > 0)
+      atomicAdd(&fallback[1], 1);                                            /* what the single pass can gain on this batch: ssd_fetch_back */
     fs.specOk = specOk ? 1 : 0;
     fs.slotCovered = covered;
     fs.nNonZero = fs.nNonZeroAcc;
@@ -1706,7 +1711,7 @@ __global__ __launch_bounds__(kThreads, SSD_K2_WAVES) void k_raster(const float *
     const int n = fallback[0];
     for(int e = blockIdx.x; e < n; e += gridDim.x)
     {
-      raster_block<SRC>(L, xyz, strideFloats, P, X, st, stepImg, tileMasks, tileMaskStride, chunkPoints, D, fallback[1 + e], blockIdx.y);
+      raster_block<SRC>(L, xyz, strideFloats, P, X, st, stepImg, tileMasks, tileMaskStride, chunkPoints, D, fallback[kFallbackList + e], blockIdx.y);
       __syncthreads();
     }
     return;

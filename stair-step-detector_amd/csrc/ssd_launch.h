@@ -19,7 +19,7 @@ constexpr int kCellHost = 64;               /* points per cell (one gating mask 
  * frames, FHD around 24-64): by points */
 constexpr long long kSinglePassMinPoints = 64ll * 1024 * 768;
 inline bool single_pass_batch(int nframes, int nPoints) { return static_cast<long long>(nframes) * nPoints >= kSinglePassMinPoints; }
-constexpr int kSinglePassBackoff = 63;      /* batches run in two passes after one the predictor covered less than half of */
+constexpr int kSinglePassBackoff = 63;      /* batches run in two passes after one the single pass could not pay on (ssd_fetch_back) */
 constexpr int kPredictParts = 4;            /* blocks of k_predict per frame */
 inline bool single_pass_geometry(int W, int H) { return W >= 64 && W <= 8192 && H >= 16 && H <= 4096; }
 

@@ -276,8 +276,8 @@ int ssd_test_single_pass(ssd_handle *h, int mode, int sabotage)
       {
         HIP_TRY(hipMalloc(&h->lane[k].dPlaneImg, planeBytes));
         HIP_TRY(hipMemset(h->lane[k].dPlaneImg, 0, planeBytes));
-        HIP_TRY(hipMalloc(&h->lane[k].dFallback, sizeof(int) * (1 + static_cast<size_t>(h->F))));
-        HIP_TRY(hipMemset(h->lane[k].dFallback, 0, sizeof(int) * (1 + static_cast<size_t>(h->F))));
+        HIP_TRY(hipMalloc(&h->lane[k].dFallback, sizeof(int) * (kFallbackList + static_cast<size_t>(h->F))));
+        HIP_TRY(hipMemset(h->lane[k].dFallback, 0, sizeof(int) * (kFallbackList + static_cast<size_t>(h->F))));
       }
   }
   h->singlePassMode = mode;
@@ -285,8 +285,8 @@ int ssd_test_single_pass(ssd_handle *h, int mode, int sabotage)
   h->singlePassBackoff = 0;
   if(mode == 1 && !h->hFallback)
   {
-    HIP_TRY(hipHostMalloc(&h->hFallback, sizeof(int) * kMaxLanes, hipHostMallocDefault));
-    std::memset(h->hFallback, 0, sizeof(int) * kMaxLanes);
+    HIP_TRY(hipHostMalloc(&h->hFallback, sizeof(int) * 2 * kMaxLanes, hipHostMallocDefault));
+    std::memset(h->hFallback, 0, sizeof(int) * 2 * kMaxLanes);
   }
   return SSD_OK;
 }

@@ -250,3 +250,20 @@ def test_the_kernels_table_is_the_host_statements(ssd, gpu_device, W, H, n, sabo
     assert total_planes >= n
     det.close()
     buf.free()
+
+
+def test_batches_without_stairs_switch_to_two_passes(ssd, gpu_device):
+    """No step plateau in sight: nothing for the single pass to gain (k_raster has nothing to do either way) - after one such batch
+    the handle runs two passes; results equal either way."""
+    W, H, n = 1024, 768, 64
+    sc = [scenes.make(ssd, "xga_no_stairs")] * n
+    buf = ssd.DeviceBuffer(W * H * 12 * n, gpu_device)
+    ssd.synth_device(sc, buf.ptr, device=gpu_device)
+    det = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=n), ssd.transformation_for_scene(sc[0]), gpu_device)
+    first = _run(det, buf, n)
+    st = det.single_pass_stats(n)
+    assert st["ran"] and st["with_steps"] == 0 and st["dirty_words"] == 0
+    for _ in range(2):
+        assert _run(det, buf, n) == first and not det.single_pass_stats(n)["ran"]
+    det.close()
+    buf.free()
