@@ -670,7 +670,7 @@ static int choose_chunk(const ssd_tuning &tune, int nPoints, int nframes)
   /* a block should stream at least 32 tiles (its prologue copies the frame's tables, its epilogue flushes the LDS
    * histogram / windows): measured +0.5 % on the XGA batch, +6.5 % on the FHD stress batch (tools/target_blocks.sh) —
    * as long as that leaves the machine at least 8192 blocks (small batches, single frames: latency first) */
-  long long minChunk = 32 * kTileHost;
+  long long minChunk = static_cast<long long>(kMaxTilesPerBlockHost) * kTileHost;
   const long long total = static_cast<long long>(nPoints) * nframes;
   if(total / minChunk < 8192)
     minChunk = total / 8192 / kTileHost * kTileHost;

@@ -219,7 +219,10 @@ constexpr int kCellsPerTile = kTile / kCell;      /* 16 */
  * chunk's cell masks in LDS, K2 / K4 / K6 the list of its wanted cells.  K2 gets tall chunks: its waves walk down cell
  * columns and pay a window flush at every column change (measured, XGA batch: 2.5 ms with 8-row chunks, 1.5 with 16,
  * 1.0 with 32) */
-constexpr int kMaxTilesPerBlock = 32;
+#ifndef SSD_MAX_TILES
+#define SSD_MAX_TILES 32
+#endif
+constexpr int kMaxTilesPerBlock = SSD_MAX_TILES;
 constexpr int kMaxCellsPerBlock = kMaxTilesPerBlock * kCellsPerTile;
 constexpr int kMaxTilesPerBlockRaster = 128;
 constexpr int kMaxCellsPerBlockRaster = kMaxTilesPerBlockRaster * kCellsPerTile;

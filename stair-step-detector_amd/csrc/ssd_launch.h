@@ -9,7 +9,10 @@ namespace ssd
 constexpr int kTileHost = 1024;
 /* kTileHost = kThreads * kPts of ssd_kernels.hip: chunk sizes are multiples of it; a block's chunk is at most
  * kMaxTilesPerBlockHost tiles (K1 keeps the chunk's cell masks, K2/K4/K6 the list of its wanted cells, in LDS) */
-constexpr int kMaxTilesPerBlockHost = 32;
+#ifndef SSD_MAX_TILES
+#define SSD_MAX_TILES 32
+#endif
+constexpr int kMaxTilesPerBlockHost = SSD_MAX_TILES;
 constexpr int kMaxTilesPerBlockRasterHost = 128;   /* K2 only */
 constexpr int kMaxTilesPerBlockInquadHost = 128;   /* K4 only */
 constexpr int kCellHost = 64;               /* points per cell (one gating mask each) */
