@@ -34,4 +34,4 @@ PY
 ASANRT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 make -C $ROOT/stair-step-detector_amd/csrc OUT=$OUT EXTRA="-fsanitize=address,undefined -fno-gpu-sanitize -g" $OUT/libssd_hip.so $OUT/libssd_source.so $OUT/libssd_testhooks.so > /dev/null 2>&1
 cd $ROOT
-LD_PRELOAD=$ASANRT ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 SSD_HIP_LIB=$OUT/libssd_hip.so python -m pytest tests/test_capi.py tests/test_oracle.py -q -x -m "not gpu" -k "not plain_c_and_links" 2>&1 | tail -2     # (that test links a plain gcc program against the libraries: no sanitizer runtime there)
+LD_PRELOAD=$ASANRT ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 SSD_HIP_LIB=$OUT/libssd_hip.so python -m pytest tests/test_capi.py tests/test_oracle.py tests/test_predict.py -q -x -m "not gpu" -k "not plain_c_and_links" 2>&1 | tail -2     # (that test links a plain gcc program against the libraries: no sanitizer runtime there)
