@@ -72,7 +72,10 @@ typedef struct
   double height_interval;                            /* 0.01 */
   double min_height_above_ground;                    /* 0.05 */
   double min_step_depth;                             /* 0.1 */
-  int32_t max_frames_per_batch;                      /* a workspace is sized for this many frames per call */
+  int32_t max_frames_per_batch;                      /* a workspace is sized for this many frames per call (ssd_workspace_bytes: about 1.75 MB per XGA
+                                                        frame; 4.1 MB from 64 XGA frames' worth of points per batch on - such batches, as
+                                                        vertices, run K1 and the step plateaus' raster as ONE pass over the input, with
+                                                        SSD_MAX_PLANES more bit images per frame; results are the same either way) */
   int32_t max_step_plateaus;                         /* <= SSD_MAX_STEP_IMAGES */
   /* Workspaces of the handle = batches it keeps in flight (1..8; 0 = 1).
    * 1 (the default): every call runs on the caller's stream, strictly in stream order — enqueue, then refill the same frames
