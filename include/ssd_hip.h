@@ -86,7 +86,8 @@ typedef struct
    *      (profiles/r03_depths.json): 1024 frames per call 272 k / 290 k / 301 k / 294 k / 307 k, 256: 237 k / 286 k / 306 k /
    *      295 k / 314 k, 64: 188 k / 248 k / 270 k / 251 k / 284 k, 16: 94 k / 165 k / 214 k / 170 k / 228 k (3 and 6 sit better
    *      than 4 and 5) — provided the caller enqueues ahead of its fetches.  Memory = batches_in_flight x 1.75 MB per XGA frame
-   *      of max_frames_per_batch (1024 frames, 3 in flight: 5.4 GB beside 9.7 GB of frames).  Stream contract then: a batch
+   *      of max_frames_per_batch (1024 frames, 3 in flight: 5.4 GB beside 9.7 GB of frames; 4.1 MB per frame and 12.6 GB with the
+   *      planes of the single pass, ssd_set_single_pass).  Stream contract then: a batch
    *      starts behind the work `stream` holds at the time of the call, but work put on `stream` afterwards is NOT ordered
    *      behind the batch — its frames must stay untouched until its results were fetched, or until a stream was made to wait
    *      for it with ssd_stream_wait.  ssd_process_host / ssd_process_depth_host gain nothing from it (their slices are
@@ -141,6 +142,12 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
 int ssd_destroy(ssd_handle *h);
 const char *ssd_last_error(void);
 size_t ssd_workspace_bytes(const ssd_handle *h);
+/* Batches of 64 XGA frames' worth of points and more, given as vertices, run K1 and the raster of the step plateaus as ONE pass over
+ * the input ("The single pass"): about 10 % more frames/s for 2.4 MB more per XGA frame and workspace
+ * (SSD_MAX_PLANES bit images per frame), the results the same bit for bit.  enable = 0 gives that memory back and keeps the
+ * handle on two passes; enable != 0 (the default of a handle whose max_frames_per_batch qualifies) takes it again.  Waits for the
+ * handle's batches in flight.  No reference counterpart (a deployment knob). */
+int ssd_set_single_pass(ssd_handle *h, int enable);
 
 /* ---- processing ------------------------------------------------------------
  * A frame is width*height points, AoS float x,y,z (rs2::vertex layout), row-major, invalid = (0,0,0).

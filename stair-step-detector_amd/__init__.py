@@ -135,7 +135,7 @@ EXPORTS = [
     "ssd_create", "ssd_destroy", "ssd_last_error", "ssd_workspace_bytes",
     "ssd_process_host", "ssd_enqueue", "ssd_fetch", "ssd_enqueue_stages",
     "ssd_set_intrinsics", "ssd_process_depth_host", "ssd_enqueue_depth", "ssd_deproject_host",
-    "ssd_fetch_back", "ssd_stream_wait", "ssd_batches_in_flight", "ssd_set_risers", "ssd_fetch_risers", "ssd_set_timing", "ssd_get_stage_times", "ssd_get_stage_times_back", "ssd_get_predict_time_back", "ssd_serialize",
+    "ssd_fetch_back", "ssd_stream_wait", "ssd_batches_in_flight", "ssd_set_risers", "ssd_set_single_pass", "ssd_fetch_risers", "ssd_set_timing", "ssd_get_stage_times", "ssd_get_stage_times_back", "ssd_get_predict_time_back", "ssd_serialize",
     "ssd_set_debug", "ssd_get_debug", "ssd_get_debug_image",
     "ssd_device_count", "ssd_device_alloc", "ssd_device_free", "ssd_device_upload", "ssd_device_download",
     "ssd_device_sync", "ssd_host_alloc", "ssd_host_free", "ssd_device_info_get", "ssd_bind_thread_to_device",
@@ -193,6 +193,7 @@ def lib():
     L.ssd_stream_wait.argtypes = [vp, i32, vp]
     L.ssd_batches_in_flight.argtypes = [vp]
     L.ssd_set_risers.argtypes = [vp, i32, C.c_double, i32]
+    L.ssd_set_single_pass.argtypes = [vp, i32]
     L.ssd_fetch_risers.argtypes = [vp, C.POINTER(FrameRisers), i32, vp]
     L.ssd_get_stage_times.argtypes = [vp, C.POINTER(C.c_float)]
     L.ssd_get_stage_times_back.argtypes = [vp, i32, C.POINTER(C.c_float)]
@@ -466,6 +467,10 @@ class Detector:
     def fetch_list(self, nframes, stream=None):
         """fetch() as a list of independent FrameResult copies."""
         return [FrameResult.from_buffer_copy(r) for r in self.fetch(nframes, stream)]
+
+    def set_single_pass(self, on=True):
+        """ssd_set_single_pass: off = the handle gives the planes' memory back and stays on two passes; on = the default again"""
+        _check(lib().ssd_set_single_pass(self._h, 1 if on else 0))
 
     def set_risers(self, on=True, tolerance=0.03, min_support=200):
         """extension: also gather the evidence of the vertical faces (ssd_set_risers)"""

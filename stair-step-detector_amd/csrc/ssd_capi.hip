@@ -526,6 +526,68 @@ size_t ssd_workspace_bytes(const ssd_handle *h)
   return h ? h->bytes : 0;
 }
 
+int ssd_set_single_pass(ssd_handle *h, int enable)
+{
+  if(!h)
+    return fail(SSD_E_ARG, "ssd_set_single_pass: null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());            /* the planes of batches in flight are in use */
+  const size_t planeBytes = static_cast<size_t>(h->F) * kMaxPlanes * h->imgWords * 8;
+  const size_t listBytes = sizeof(int) * (kFallbackList + static_cast<size_t>(h->F));
+  if(!enable)
+  {
+    for(int k = 0; k < h->depth; k++)
+    {
+      ssd_lane &L = h->lane[k];
+      if(L.dPlaneImg)
+      {
+        (void)hipFree(L.dPlaneImg);
+        L.dPlaneImg = nullptr;
+        h->bytes -= planeBytes;
+      }
+      if(L.dFallback)
+      {
+        (void)hipFree(L.dFallback);
+        L.dFallback = nullptr;
+      }
+    }
+    h->singlePassMode = 0;
+    return SSD_OK;
+  }
+  if(single_pass_geometry(h->P.W, h->P.H) && single_pass_batch(h->F, h->P.nPoints))
+  {
+    for(int k = 0; k < h->depth; k++)
+    {
+      ssd_lane &L = h->lane[k];
+      if(!L.dPlaneImg)
+      {
+        const hipError_t e = hipMalloc(&L.dPlaneImg, planeBytes);
+        if(e != hipSuccess)
+        {
+          L.dPlaneImg = nullptr;
+          return fail(e == hipErrorOutOfMemory ? SSD_E_NOMEM : SSD_E_HIP, std::string("ssd_set_single_pass: ") + hipGetErrorString(e));
+        }
+        HIP_TRY(hipMemset(L.dPlaneImg, 0, planeBytes));
+        h->bytes += planeBytes;
+      }
+      if(!L.dFallback)
+      {
+        HIP_TRY(hipMalloc(&L.dFallback, listBytes));
+        HIP_TRY(hipMemset(L.dFallback, 0, listBytes));
+      }
+    }
+    if(!h->hFallback)
+    {
+      HIP_TRY(hipHostMalloc(&h->hFallback, sizeof(int) * 2 * kMaxLanes, hipHostMallocDefault));
+      std::memset(h->hFallback, 0, sizeof(int) * 2 * kMaxLanes);
+    }
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  h->singlePassMode = -1;
+  h->singlePassBackoff = 0;
+  return SSD_OK;
+}
+
 int ssd_set_debug(ssd_handle *h, int enable)
 {
   if(!h)

@@ -267,3 +267,29 @@ def test_batches_without_stairs_switch_to_two_passes(ssd, gpu_device):
         assert _run(det, buf, n) == first and not det.single_pass_stats(n)["ran"]
     det.close()
     buf.free()
+
+
+def test_the_planes_memory_can_be_given_back(ssd, gpu_device):
+    """ssd_set_single_pass(0): 2.4 MB per XGA frame and workspace back, two passes from then on; (1): the default again"""
+    W, H, n = 1024, 768, 64
+    sc, buf = _batch(ssd, gpu_device, W, H, n, 49000, 49)
+    det = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=n), ssd.transformation_for_scene(sc[0]), gpu_device)
+    with_planes = det.workspace_bytes
+    single = _run(det, buf, n)
+    assert det.single_pass_stats(n)["ran"]
+    det.set_single_pass(False)
+    plane_bytes = n * ssd.MAX_PLANES * H * (W // 64) * 8
+    assert det.workspace_bytes == with_planes - plane_bytes
+    assert _run(det, buf, n) == single and not det.single_pass_stats(n)["ran"]
+    det.set_single_pass(True)
+    assert det.workspace_bytes == with_planes
+    assert _run(det, buf, n) == single and det.single_pass_stats(n)["ran"]
+    det.close()
+    buf.free()
+    # a handle too small for it: nothing to give or take
+    small = ssd.Detector(ssd.default_config(W, H, max_frames_per_batch=8), ssd.transformation_for_scene(sc[0]), gpu_device)
+    b = small.workspace_bytes
+    small.set_single_pass(True)
+    small.set_single_pass(False)
+    assert small.workspace_bytes == b
+    small.close()
