@@ -259,7 +259,7 @@ def main():
     det = ssd.Detector(cfg, trans, device)
     depth = det.batches_in_flight
     if args.two_pass:
-        det.single_pass(0)
+        det.set_single_pass(False)           # ssd_set_single_pass: the planes' memory back, two passes
     if args.risers:
         det.set_risers(True, tolerance=0.03, min_support=200)
     intr = ssd.intrinsics_for_scene(sc_list[0])
