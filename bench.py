@@ -203,7 +203,7 @@ def main():
                     help="workspaces of the handle (ssd_config::batches_in_flight), asked for explicitly: 3 = SSD_BATCHES_IN_FLIGHT_THROUGHPUT "
                          "(the bench enqueues ahead of its fetches); 1 (or 0, the library's default) = strictly one batch at a time in stream "
                          "order — what the profiling passes use, so that a kernel's traced duration is its own")
-    ap.add_argument("--two-pass", action="store_true", help="A/B: switch the single pass off (test hook; K1 then k_raster over every frame, as before round 4's single pass)")
+    ap.add_argument("--two-pass", action="store_true", help="A/B: ssd_set_single_pass(h, 0): K1 then k_raster over every frame, as before round 4's single pass")
     ap.add_argument("--prewarm-seconds", type=float, default=0.5,
                     help="untimed load in front of the W warm-up steps (an idle device needs more than a few steps to reach its clocks)")
     ap.add_argument("--no-cpu", action="store_true")
