@@ -557,11 +557,12 @@ def test_host_build_of_the_kernels_closing_against_the_oracle(ssd, oracle):
     """csrc/ssd_closing.h — the 3x3 closing on bit images as k_outline / k_final compute it, word by word (closed_word: probe
     rows, debug capture) and by pixel column from the raw 5 x 5 neighbourhood (closed_scan_column: the scans) — is host + device
     code.  Its host build against the oracle's closing (checked against scipy.ndimage and the border behaviour of
-    cv::morphologyEx in test_oracle.py): blobs, noise, lit borders, widths that are no multiple of 64 or 32, every band
+    cv::morphologyEx in test_oracle.py): blobs, noise, lit borders, widths that are no multiple of 64 or 32, widths on both sides of 1024, every band
     height the kernels use; the first and last closed row of every 25th column must be those of the closed image."""
     rng = np.random.default_rng(4711)
-    for case in range(40):
-        w = int(rng.choice([64, 65, 97, 128, 200, 427, 600]))
+    for case in range(64):
+        # (above 1024 pixels the column scan fetches a row's five pixels with one 8-byte load and a 64-bit shift: ColumnStrip)
+        w = int(rng.choice([64, 65, 97, 128, 200, 427, 600, 1025, 1057, 1100, 1920, 2049]))
         h = int(rng.integers(12, 90))
         img = np.zeros((h, w), np.uint8)
         for _ in range(int(rng.integers(1, 6))):                      # rectangles, some touching the borders
