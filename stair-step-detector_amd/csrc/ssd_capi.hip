@@ -1091,7 +1091,7 @@ int ssd_fetch_back(ssd_handle *h, ssd_frame_result *results, int nframes, int ba
   if(h->resultsFallback[slot] == 0)
   {
     h->resultsFallback[slot] = 1;                       /* counted once */
-    const int listed = h->hFallback[2 * slot], withSteps = h->hFallback[2 * slot + 1], frames = h->resultsFrames[slot];
+    const int listed = h->hFallback[2 * slot], frames = h->resultsFrames[slot], withSteps = frames - h->hFallback[2 * slot + 1];
     if(2 * listed > frames || 4 * withSteps < frames)
       h->singlePassBackoff = kSinglePassBackoff;
   }

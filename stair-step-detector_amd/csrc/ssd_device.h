@@ -35,7 +35,7 @@ constexpr int kMaxPlanes = SSD_MAX_PLANES;
 #define SSD_SPEC_SAMPLE 16
 #endif
 constexpr int kSpecSample = SSD_SPEC_SAMPLE;
-/* the batch's list for k_raster (single pass): [0] = frames listed, [1] = frames with step plateaus, the frame indices from [kFallbackList] */
+/* the batch's list for k_raster (single pass): [0] = frames listed, [1] = frames without step plateaus, the frame indices from [kFallbackList] */
 constexpr int kFallbackList = 2;
 constexpr int kMaxGroundStrips = 168;              /* pixel strips of the ground image the bottom scan reads: one per 50 columns (+ 2), width <= 8192 */
 

@@ -32,7 +32,7 @@ struct ssd_lane
   ssd::FrameState *dState = nullptr;
   unsigned long long *dStepImg = nullptr;
   unsigned long long *dGroundImg = nullptr;
-  int *dFallback = nullptr;                 /* single pass: kFallbackList + F ints: frames listed for k_raster, frames with step plateaus, the list */
+  int *dFallback = nullptr;                 /* single pass: kFallbackList + F ints: frames listed for k_raster, frames without step plateaus, the list */
   unsigned long long *dPlaneImg = nullptr;  /* single pass: [F][kMaxPlanes] bit images, one per candidate height bin (null: the handle never runs it) */
   uint2 *dTileMasks = nullptr;             /* per cell (64 points): which groups of 4 height bins occur; K1 -> K2, K4, K6 */
   uint2 *dTileMasksBase = nullptr;         /* the allocation dTileMasks lies in (the tools' placement hooks put the records elsewhere in a larger one) */
@@ -95,7 +95,7 @@ struct ssd_handle
    * hooks set both) */
   int singlePassMode = -1, singlePassSabotage = 0;
   bool lastSinglePass = false;    /* the last enqueue ran it */
-  int *hFallback = nullptr;       /* pinned, two per result slot: frames of that batch k_raster had to do, frames with step plateaus (copied with the results) */
+  int *hFallback = nullptr;       /* pinned, two per result slot: frames of that batch k_raster had to do, frames without step plateaus (copied with the results) */
   int resultsFallback[kMaxLanes] = {};      /* -1: that slot's batch ran two passes; 0: count on its way; 1: seen by ssd_fetch_back */
   int singlePassBackoff = 0;      /* qualifying batches still to run two passes after a batch the predictor did not cover */
   size_t bytes = 0;

@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(kThreads) void k_predict(const float *__restrict__ 
     if(frame == 0)
     {
       fallback[0] = 0;                   /* k_raster's work list of this batch starts empty (k_peaks appends) */
-      fallback[1] = 0;                   /* frames with step plateaus (k_peaks counts) */
+      fallback[1] = 0;                   /* frames without step plateaus (k_peaks counts) */
     }
   }
 }
@@ -1482,8 +1482,8 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
   {
     if(spec && !specOk && nImg > 0)
       fallback[kFallbackList + atomicAdd(&fallback[0], 1)] = frame;          /* k_raster's work list (k_predict zeroed the count) */
-    if(spec && nImg > 0)
-      atomicAdd(&fallback[1], 1);                                            /* what the single pass can gain on this batch: ssd_fetch_back */
+    if(spec && nImg == 0)
+      atomicAdd(&fallback[1], 1);                                            /* frames WITHOUT a step plateau (the rare kind where stairs are in sight: a thousand adds to one address cost k_peaks 10 us): what the single pass cannot gain on, ssd_fetch_back */
     fs.specOk = specOk ? 1 : 0;
     fs.slotCovered = covered;
     fs.nNonZero = fs.nNonZeroAcc;
