@@ -838,7 +838,7 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
               curT = plane;
               accT = 0;
             }
-            accT += static_cast<unsigned long long>(z_to_fixed(wz));
+            accT += static_cast<unsigned long long>(z_plus_magic_bits(wz));      /* the bits of z + 6144; k_peaks takes the constant's share off (count x kMagicBits): two instructions fewer per point than z_to_fixed */
             if(!inside)
               atomicAdd(&SL.oob[plane], 1u);                   /* quirk Q5, rare */
             key[j] = inside ? pixel_key(plane, iy, ix) : kNoPixel;
@@ -1458,6 +1458,10 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
         tz += fs.planeTotZ[p];
         oobSum += fs.planeOob[p];
       }
+      /* the planes hold sums of the bits of (z + 6144) over exactly the plateau's points (covered: every bin of it with
+       * points has a plane, and no plane of it a point of another bin): minus the constant's bits per point, modulo 2^64,
+       * this is the sum of round(z * 2^40) k_raster would have left (z_plus_magic_bits) */
+      tz = static_cast<long long>(static_cast<unsigned long long>(tz) - static_cast<unsigned long long>(kMagicBits) * static_cast<unsigned long long>(plN[firstStep + lane]));
     }
     fs.imgYMin[lane] = y0; fs.imgYMax[lane] = y1;
     fs.imgXMin[lane] = x0; fs.imgXMax[lane] = x1;
