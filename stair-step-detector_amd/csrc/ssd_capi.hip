@@ -7,6 +7,7 @@
  */
 #include "ssd_launch.h"
 #include "ssd_handle.h"
+#include "ssd_prexy.h"
 
 #include <charconv>
 #include <cmath>
@@ -350,6 +351,7 @@ static int make_params(const ssd_config &c, const ssd_calibration &k, Params &P)
   P.pt.boxY = 256.0 / (c.y_max - c.y_min);
   P.pt.nPoints = P.nPoints;
   P.pt.nBins = P.nBins;
+  P.pre = make_pre_xy(P.pt);                  /* K1's single-precision pre-filter of the x / y range test (ssd_prexy.h) */
   P.px.xToImage = P.xToImage; P.px.yToImage = P.yToImage;
   P.px.W = P.W; P.px.H = P.H; P.px.W64 = P.W64;
   P.px.maxStepImages = P.maxStepImages;

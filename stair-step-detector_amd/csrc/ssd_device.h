@@ -54,6 +54,21 @@ struct PointParams
   int nPoints, nBins;
 };
 
+/* K1's single-precision pre-filter of the x / y range test (round 5).  The reference decides "x and y in range" on doubles
+ * (pointcloud.cpp:150-165); K1 first evaluates d = ((x, y) - centre of the range) / (extent of the range) with three packed
+ * single-precision FMAs, whose distance from the exact value is bounded by `e` for inputs of magnitude <= maxInput: a point
+ * with max(|dx|, |dy|) < lo = 0.5 - e is inside whatever the doubles say, one with max(..) > hi = 0.5 + e outside; only the
+ * band between them (and inputs beyond maxInput, NaNs) takes the double-precision rows.  d also gives the cells' bounding
+ * boxes (grid cell = (d + 0.5 -+ e) * 256).  make_pre_xy() derives the constants and the bound (ssd_capi.hip). */
+struct PreXY
+{
+  float c[4][2];                              /* (d.x, d.y) = c[0] * x + c[1] * y + c[2] * z + c[3], pairs (x row, y row): one packed FMA per input */
+  float lo, hi;
+  float maxInput;
+  float boxLo, boxHi;                         /* the cell of a minimum is rn(d * 256 + boxLo), of a maximum rn(d * 256 + boxHi), saturated to 0 .. 255 */
+  float pad;
+};
+
 struct PixelParams
 {
   double xToImage, yToImage;                  /* Projection2D (pointcloud.cpp:73-74) */
@@ -93,6 +108,7 @@ struct Params
 {
   PointParams pt;
   PixelParams px;
+  PreXY pre;
   int W, H, W64;
   int nPoints;
   double r2[4], t2[2], worldZ;

@@ -29,6 +29,7 @@
 #include "ssd_closing.h"
 #include "ssd_bestline.h"
 #include "ssd_sort.h"
+#include <type_traits>
 
 namespace ssd
 {
@@ -430,19 +431,22 @@ __device__ __forceinline__ void wavemiss_flush(unsigned int *wm, ImageBox *boxes
   }
 }
 
+/* signed minimum / maximum over the wave: rows by DPP, the four rows by v_readlane */
 __device__ __forceinline__ int wave_min_i(int v)
 {
-#pragma unroll
-  for(int o = 32; o > 0; o >>= 1)
-    v = min(v, __shfl_xor(v, o));
-  return v;
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x128, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x124, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x122, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x121, 0xf, 0xf, false));
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ int wave_max_i(int v)
 {
-#pragma unroll
-  for(int o = 32; o > 0; o >>= 1)
-    v = max(v, __shfl_xor(v, o));
-  return v;
+  v = max(v, __builtin_amdgcn_update_dpp(static_cast<int>(0x80000000u), v, 0x128, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(static_cast<int>(0x80000000u), v, 0x124, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(static_cast<int>(0x80000000u), v, 0x122, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(static_cast<int>(0x80000000u), v, 0x121, 0xf, 0xf, false));
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
 /* writes the wave's window out (non-zero words only), clears it, extends the image's bounding box; all 64 lanes */
@@ -487,12 +491,13 @@ __device__ __forceinline__ unsigned int pixel_key(int slot, int iy, int ix)
   return (static_cast<unsigned int>(slot) << 26) | (static_cast<unsigned int>(iy) << 13) | static_cast<unsigned int>(ix);
 }
 
+/* minimum over the wave, the same in every lane (and uniform to the compiler): the rows by DPP, the four rows by v_readlane
+ * (round 4: six ds_bpermute steps per value) */
 __device__ __forceinline__ unsigned int wave_min_u32(unsigned int v)
 {
-#pragma unroll
-  for(int o = 32; o > 0; o >>= 1)
-    v = min(v, static_cast<unsigned int>(__shfl_xor(static_cast<int>(v), o)));
-  return v;
+  v = row_min_u32(v);
+  return min(min(static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(v), 0)), static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(v), 16))),
+             min(static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(v), 32)), static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(v), 48))));
 }
 
 /* The window's origin as a pixel_key (slot, row0, 64 * col0): for a pixel key k of the same image at or beyond the origin,
@@ -728,12 +733,125 @@ __device__ __forceinline__ void specwin_emit(unsigned long long *ww, SpecMiss &m
   }
 }
 
+/* one pixel per lane (K1's queue hands the window 64 real pixels at a time) */
+__device__ __forceinline__ void specwin_emit1(unsigned long long *ww, SpecMiss &miss, SpecWindow &w, unsigned long long *__restrict__ planes,
+                                              unsigned int imgWords, int W64, ImageBox *boxes, const unsigned int k, int lane)
+{
+  specwin_prepare(ww, w, planes, imgWords, W64, boxes, k, lane);
+  const unsigned int d = k - specwin_base(w);
+  const unsigned int bit = 1u << (k & 31u);
+  unsigned int *ww32 = reinterpret_cast<unsigned int *>(ww);
+  if(specwin_hit(d))
+    atomicOr(&ww32[((d >> 26) << (kSpecRowBits + 4)) | (((d >> 13) & (kSpecWinRows - 1u)) << 4) | ((d & 0x1fffu) >> 5)], bit);     /* (plane, row, half word) */
+  else if(k != kNoPixel)
+  {
+    const unsigned int slot = k >> 26, iy = (k >> 13) & 0x1fffu, ix = k & 0x1fffu, xw = ix >> 6;
+    atomicOr(reinterpret_cast<unsigned int *>(planes + (slot * imgWords + iy * static_cast<unsigned int>(W64) + xw)) + ((ix >> 5) & 1u), bit);
+    miss.y0 = min(miss.y0, static_cast<int>(iy)); miss.y1 = max(miss.y1, static_cast<int>(iy));
+    miss.x0 = min(miss.x0, static_cast<int>(xw)); miss.x1 = max(miss.x1, static_cast<int>(xw));
+    miss.planes |= 1u << slot;
+  }
+}
+
 /* The streaming kernels are written as block bodies over an explicit LDS struct, (frame, chunk) given by the caller:
  * the kernels below pass blockIdx (tools and experiments have paired two bodies in one launch: DESIGN.md section 3). */
+
+/* ---- round 5: K1's x / y range test in single precision first (PreXY, ssd_device.h; the bound: ssd_prexy.h) ---- */
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+/* (d.x, d.y): the point's world x / y, centred on the measuring range and divided by its extent - three packed FMAs */
+__device__ __forceinline__ f32x2 pre_xy(const PreXY &Q, float x, float y, float z)
+{
+  f32x2 d = __builtin_elementwise_fma(f32x2{ Q.c[2][0], Q.c[2][1] }, f32x2{ z, z }, f32x2{ Q.c[3][0], Q.c[3][1] });
+  d = __builtin_elementwise_fma(f32x2{ Q.c[1][0], Q.c[1][1] }, f32x2{ y, y }, d);
+  d = __builtin_elementwise_fma(f32x2{ Q.c[0][0], Q.c[0][1] }, f32x2{ x, x }, d);
+  return d;
+}
+/* single instructions with |.| on the operands (as builtins the compiler canonicalises fmaxf's operands first: v_max x, x) */
+__device__ __forceinline__ float absmax2(float a, float b)
+{
+  float r;
+  asm("v_max_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float absmax3(float a, float b, float c)
+{
+  float r;
+  asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float min_f32(float a, float b)
+{
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float max_f32(float a, float b)
+{
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+/* the cell's five reductions over the 16 lanes of a DPP row (groups: OR; the box: two minima, two maxima of the lanes' d), in one
+ * block of twenty instructions, the five chains interleaved so that no DPP operand is read within two instructions of its write
+ * (the wait states the hardware asks for; the compiler does not see into the block) */
+__device__ __forceinline__ void row_reduce_cell(unsigned int &groups, float &x0, float &x1, float &y0, float &y1)
+{
+  asm("v_or_b32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_or_b32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_or_b32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_f32_dpp %3, %3, %3 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %4, %4, %4 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_or_b32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_f32_dpp %3, %3, %3 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %4, %4, %4 row_ror:1 row_mask:0xf bank_mask:0xf"
+      : "+v"(groups), "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
+}
+/* the cell's box from the extremes of d: rn(d * 256 + boxLo / boxHi) saturated to 0 .. 255, one byte each (ssd_prexy.h) */
+__device__ __forceinline__ unsigned int cell_box_from_d(const PreXY &Q, float x0, float x1, float y0, float y1)
+{
+  unsigned int box = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(x0, 256.0f, Q.boxLo), 0u, 0u);
+  box = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(x1, 256.0f, Q.boxHi), 1u, box);
+  box = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(y0, 256.0f, Q.boxLo), 2u, box);
+  box = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(y1, 256.0f, Q.boxHi), 3u, box);
+  return box;
+}
+
+/* ---- round 5, single pass: the points of the candidate bins wait in a per-wave LDS queue and are rastered 64 at a time ----
+ * Rastering inside the point loop ran its instructions for every wave tile that held one candidate point, at 55 % lane use (a
+ * wave's 256 pixels straddle the tread's edge).  Now the loop only appends a candidate - its three floats, its exact world z
+ * and its plane - to the wave's queue (a ballot, two v_mbcnt, five LDS stores), and whenever 64 have gathered the wave
+ * takes them off together: the x / y rows in doubles, pixel, z sum, the bit into the wave's window - every lane busy, the
+ * window vote once per 64 real pixels.  The queue is drained after every kQDrainPts points per lane, so it never holds more
+ * than 63 + 64 * kQDrainPts entries. */
+#ifndef SSD_Q_DRAIN_PTS
+#define SSD_Q_DRAIN_PTS 1
+#endif
+constexpr int kQDrainPts = SSD_Q_DRAIN_PTS;
+static_assert(kQDrainPts == 1 || kQDrainPts == 2 || kQDrainPts == 4, "the tile's four points per lane in equal parts");
+constexpr int kQCap = 64 * (kQDrainPts + 1);
+struct CandQueue
+{
+  float x[kQCap], y[kQCap], z[kQCap];
+  unsigned int plane[kQCap];
+};
+
 /* what the single pass adds to K1's LDS */
 struct SpecLds
 {
   unsigned long long wins[kThreads / 64][kSpecWinWords];
+  CandQueue queue[kThreads / 64];
   ImageBox boxes[kMaxPlanes];
   unsigned char plane[kMaxBins];                 /* FrameState::specPlane */
   unsigned char order[kMaxTilesPerBlock * (kTile / 256)];   /* STRIPS: the chunk's 256-point strips by (column band, index) */
@@ -742,8 +860,30 @@ struct SpecLds
 };
 struct NoSpecLds {};
 
+/* The constants of K1's two seldom-run pieces - the double-precision x / y rows of a point the pre-filter cannot call, and the
+ * queue's consumer - live in LDS, copied there once per block: as kernel arguments they would sit in scalar registers through
+ * the whole point loop, which has none to spare (with them the loop's own constants were spilled and came back through a dozen
+ * v_readlane per point). */
+struct K1Consts
+{
+  double a[6], b[2];                              /* the x and y rows of CameraToWorld */
+  double xMin, xMax, yMin, yMax;
+  double boxX, boxY;
+  double xToImage, yToImage;
+};
+/* the address of the block's copy, opaque to the compiler at every use: loads from it stay where they are written (hoisted
+ * out of the point loop they would occupy thirty-two vector registers for its whole length) */
+typedef const K1Consts __attribute__((address_space(3))) *K1ConstsLds;
+__device__ __forceinline__ K1ConstsLds k1_consts(const K1Consts &c)
+{
+  K1ConstsLds p = (K1ConstsLds)(&c);
+  asm volatile("" : "+v"(p));
+  return p;
+}
+
 struct HistLds
 {
+  K1Consts kc;
   uint2 lInfo[kMaxCellsPerBlock];
   /* [bin][copy]: a vote goes to copy = lane & 31, i.e. LDS bank = copy: the 32 lanes the LDS serves per
    * cycle never collide, whatever their bins (a camera row sweeping one plateau puts all 64 lanes in one bin) */
@@ -755,7 +895,7 @@ struct HistLds
  * the frame's planes, as k_raster does for the plateaus' bins: pixel (image_pixel), the plane's z sum and out-of-image count. */
 template<int SRC, bool SPEC, bool STRIPS, typename SPECLDS>
 __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float *__restrict__ xyz, size_t strideFloats, const PointParams &P,
-                                           const PixelParams &X, FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
+                                           const PreXY &Q, const PixelParams &X, FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
                                            unsigned long long *__restrict__ planeImg,
                                            size_t tileMaskStride, int chunkPoints, const DepthSrc &D, const int frame, const int chunkIdx)
 {
@@ -768,6 +908,7 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
   SpecMiss missed;
   int curT = -1;
   unsigned long long accT = 0;
+  int qHead = 0, qCount = 0;                    /* wave-uniform: the queue's first entry and its length */
   const unsigned int imgWords = static_cast<unsigned int>(X.H) * static_cast<unsigned int>(X.W64);
   unsigned long long *frameImg = nullptr;
   if constexpr(SPEC)
@@ -796,70 +937,137 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
   for(int i = tid; i < kMaxBins * kHistCopies; i += kThreads)
     lh[i] = 0;
   if(tid == 0)
+  {
     lNonZero = 0;
+    K1Consts &c = L.kc;
+#pragma unroll
+    for(int i = 0; i < 6; i++)
+      c.a[i] = P.a[i];
+    c.b[0] = P.b[0]; c.b[1] = P.b[1];
+    c.xMin = P.xMin; c.xMax = P.xMax; c.yMin = P.yMin; c.yMax = P.yMax;
+    c.boxX = P.boxX; c.boxY = P.boxY;
+    c.xToImage = X.xToImage; c.yToImage = X.yToImage;
+  }
   __syncthreads();
 
   unsigned int *mine = lh + (lane & (kHistCopies - 1));
   unsigned int nz = 0;                                               /* wave-uniform: the count of the whole wave (scalar popcounts) */
   int it = 0;
   int nStore = -1;                                                    /* cell records to store (STRIPS), else it * kCellsPerTile */
+
+  /* single pass: the wave takes n (<= 64) candidates off its queue, lane i the i-th (see CandQueue) */
+  auto drain = [&](const int n, auto full)
+  {
+    if constexpr(SPEC)
+    {
+      CandQueue &q = SL.queue[tid >> 6];
+      unsigned int slot = static_cast<unsigned int>(qHead + lane);
+      slot = min(slot, slot - static_cast<unsigned int>(kQCap));            /* wraps: slot - kQCap is huge unless slot >= kQCap */
+      const float px = q.x[slot], py = q.y[slot], pz = q.z[slot];
+      const int plane = static_cast<int>(q.plane[slot]);
+      unsigned int key = kNoPixel;
+      if(decltype(full)::value || lane < n)
+      {
+        /* as k_raster's body: projectToBinaryImage (pointcloud.cpp:458-471) for a bin that may turn out a plateau's; the point
+         * is in range (the loop decided), its x / y rows are world_point_flat's */
+        const K1ConstsLds c = k1_consts(L.kc);
+        const double x = px, y = py, z = pz;
+        double wx = (c->a[0] * x + c->a[1] * y) + c->a[2] * z;
+        double wy = (c->a[3] * x + c->a[4] * y) + c->a[5] * z;
+        wx = wx + c->b[0];
+        wy = wy + c->b[1];
+        const double wz = ((P.a[6] * x + P.a[7] * y) + P.a[8] * z) + P.b[2];       /* world_z_flat's row once more: 8 bytes per entry cost a block per CU */
+        /* Projection2D::worldToImage (pointcloud.cpp:79-83) as image_pixel */
+        const int ix = static_cast<int>((wx - c->xMin) * c->xToImage);
+        const int iy = static_cast<int>((c->yMax - wy) * c->yToImage);
+        const bool inside = (static_cast<unsigned int>(ix) < static_cast<unsigned int>(X.W)) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(X.H));
+        if(plane != curT)
+        {
+          if(curT >= 0)
+            atomicAdd(&SL.ltot[curT][lane & 7], accT);
+          curT = plane;
+          accT = 0;
+        }
+        accT += static_cast<unsigned long long>(z_plus_magic_bits(wz));      /* the bits of z + 6144; k_peaks takes the constant's share off (count x kMagicBits) */
+        if(!inside)
+          atomicAdd(&SL.oob[plane], 1u);                   /* quirk Q5, rare */
+        key = inside ? pixel_key(plane, iy, ix) : kNoPixel;
+      }
+      specwin_emit1(SL.wins[tid >> 6], missed, win, frameImg, imgWords, X.W64, SL.boxes, key, lane);
+      qHead += n;
+      qHead = qHead >= kQCap ? qHead - kQCap : qHead;
+      qCount -= n;
+    }
+  };
+
   auto tileBody = [&](const F3 (&v)[kPts], const int cellAt)
   {
     unsigned int groups = 0u;
-    /* extremes of (x - xMin, y - yMin) over the lane's in-range points, as the high dwords of the doubles (see row_min_u32) */
-    unsigned int x0 = 0xffffffffu, x1 = 0u, y0 = 0xffffffffu, y1 = 0u;
-    unsigned int key[kPts];
+    /* extremes of d (pre_xy) over the lane's in-range points: the cell's box */
+    float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
 #pragma unroll
     for(int j = 0; j < kPts; j++)
     {
-      double wx, wy, wz;
-      key[j] = kNoPixel;
-      nz += static_cast<unsigned int>(__popcll(__ballot(v[j].z > 0.0f)));    /* pointcloud.cpp:143-146, counted per wave on the scalar unit */
-      if(world_point_flat(P, v[j], wx, wy, wz))
+      const F3 p{ v[j].x, v[j].y, v[j].z };
+      /* z: the reference's doubles (the bin hangs on them); pointcloud.cpp:143-146 counted per wave on the scalar unit */
+      double wz;
+      const bool inz = world_z_flat(P, p, wz);
+      nz += static_cast<unsigned int>(__popcll(__ballot(p.z > 0.0f)));
+      /* x / y: single precision first */
+      f32x2 d = pre_xy(Q, p.x, p.y, p.z);
+      const float M = absmax2(d.x, d.y);
+      bool inxy = M < Q.lo;
+      const bool sure = (inxy | (M > Q.hi)) & (absmax3(p.x, p.y, p.z) <= Q.maxInput);
+      if(inz & !sure)
+      {
+        /* the band around the range's edges, inputs beyond maxInput, NaNs: the doubles decide (rare: one lane in thousands) */
+        const K1ConstsLds c = k1_consts(L.kc);
+        const double x = p.x, y = p.y, z = p.z;
+        double wx = (c->a[0] * x + c->a[1] * y) + c->a[2] * z;         /* world_point_flat's rows */
+        double wy = (c->a[3] * x + c->a[4] * y) + c->a[5] * z;
+        wx = wx + c->b[0];
+        wy = wy + c->b[1];
+        inxy = (wx > c->xMin) & (wx < c->xMax) & (wy > c->yMin) & (wy < c->yMax);
+        d.x = static_cast<float>((wx - c->xMin) * c->boxX * 0.00390625 - 0.5);
+        d.y = static_cast<float>((wy - c->yMin) * c->boxY * 0.00390625 - 0.5);
+      }
+      int plane = 0xff;
+      if(inz & inxy)
       {
         const unsigned int b = static_cast<unsigned int>(height_bin(P, wz));     /* in [0, nBins) for a point in range */
         atomicAdd(mine + b * kHistCopies, 1u);                          /* ++hist[bin], pointcloud.cpp:199-202 */
         groups |= 1u << (b / static_cast<unsigned int>(kBinsPerGroup));
-        const unsigned int hx = static_cast<unsigned int>(__double2hiint(wx - P.xMin)), hy = static_cast<unsigned int>(__double2hiint(wy - P.yMin));
-        x0 = min(x0, hx); x1 = max(x1, hx);
-        y0 = min(y0, hy); y1 = max(y1, hy);
+        x0 = min_f32(x0, d.x); x1 = max_f32(x1, d.x);
+        y0 = min_f32(y0, d.y); y1 = max_f32(y1, d.y);
         if constexpr(SPEC)
+          plane = SL.plane[b];
+      }
+      if constexpr(SPEC)
+      {
+        /* a candidate joins the wave's queue (most tiles hold none: ground, risers, background) */
+        const bool cand = plane != 0xff;
+        const unsigned long long cm = __ballot(cand);
+        if(cm != 0ull)
         {
-          const int plane = SL.plane[b];
-          if(plane != 0xff)
+          if(cand)
           {
-            /* as k_raster's body: projectToBinaryImage (pointcloud.cpp:458-471) for a bin that may turn out a plateau's */
-            int ix, iy;
-            const bool inside = image_pixel(P, X, wx, wy, ix, iy);
-            if(plane != curT)
-            {
-              if(curT >= 0)
-                atomicAdd(&SL.ltot[curT][lane & 7], accT);
-              curT = plane;
-              accT = 0;
-            }
-            accT += static_cast<unsigned long long>(z_plus_magic_bits(wz));      /* the bits of z + 6144; k_peaks takes the constant's share off (count x kMagicBits): two instructions fewer per point than z_to_fixed */
-            if(!inside)
-              atomicAdd(&SL.oob[plane], 1u);                   /* quirk Q5, rare */
-            key[j] = inside ? pixel_key(plane, iy, ix) : kNoPixel;
+            CandQueue &q = SL.queue[tid >> 6];
+            unsigned int slot = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned int>(cm >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo(static_cast<unsigned int>(cm), static_cast<unsigned int>(qHead + qCount)));
+            slot = min(slot, slot - static_cast<unsigned int>(kQCap));        /* qHead < kQCap and the queue never holds kQCap entries: one wrap */
+            q.x[slot] = p.x; q.y[slot] = p.y; q.z[slot] = p.z;
+            q.plane[slot] = static_cast<unsigned int>(plane);
           }
+          qCount += __popcll(cm);
         }
+        if((j + 1) % kQDrainPts == 0)
+          while(qCount >= 64)
+            drain(64, std::true_type{});
       }
     }
-    groups = row_or_u32(groups);
-    x0 = row_min_u32(x0); x1 = row_max_u32(x1);
-    y0 = row_min_u32(y0); y1 = row_max_u32(y1);
-    /* the reductions end here, in all lanes: left to itself the compiler moves their last step into the branch below, where a
-     * DPP operand cannot be folded into the min / max (ten instructions instead of five per tile) */
-    asm volatile("" : "+v"(groups), "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
+    row_reduce_cell(groups, x0, x1, y0, y1);
     if((lane & 15) == 0)                                         /* cell = 64 consecutive points = lanes 16q .. 16q+15 */
-      lInfo[cellAt] = make_uint2(groups, cell_box_from_high_dwords(x0, x1, y0, y1, P.boxX, P.boxY));
-    if constexpr(SPEC)
-    {
-      /* most tiles hold no point of a candidate bin (ground, risers, background): one ballot */
-      if(__ballot((key[0] & key[1] & key[2] & key[3]) != kNoPixel) != 0ull)
-        specwin_emit(SL.wins[tid >> 6], missed, win, frameImg, imgWords, X.W64, SL.boxes, key, lane);
-    }
+      lInfo[cellAt] = make_uint2(groups, cell_box_from_d(Q, x0, x1, y0, y1));
   };
   if constexpr(STRIPS)
   {
@@ -898,22 +1106,20 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
       load_points<SRC>(base, begin + (sa << 8) + kPts * lane, end, va, D);
       while(true)
       {
-        if(k + 1 < kEnd)
+        const bool more = k + 1 < kEnd;
+        if(more)
         {
           sb = SL.order[k + 1];
           load_points<SRC>(base, begin + (sb << 8) + kPts * lane, end, vb, D);
         }
         tileBody(va, sa * 4 + (lane >> 4));
-        if(++k >= kEnd)
+        if(!more)
           break;
-        if(k + 1 < kEnd)
-        {
-          sa = SL.order[k + 1];
-          load_points<SRC>(base, begin + (sa << 8) + kPts * lane, end, va, D);
-        }
-        tileBody(vb, sb * 4 + (lane >> 4));
-        if(++k >= kEnd)
-          break;
+        k++;
+        sa = sb;
+#pragma unroll
+        for(int j = 0; j < kPts; j++)
+          va[j] = vb[j];
       }
     }
     nStore = nStrips * (256 / kCell);           /* every strip's four cells were written */
@@ -966,11 +1172,36 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
       tileBody(v, it * kCellsPerTile + (tid >> 4));
       it++;
     };
-    SSD_STREAM_LOOP(tileInOrder)
+    if constexpr(SPEC)
+    {
+      /* one copy of the body (it holds the queue's consumer kPts / kQDrainPts times): the next tile's loads go out before the
+       * current tile is processed, as in SSD_STREAM_LOOP, and are moved into place after it (twelve moves per tile) */
+      F3 va[kPts], vb[kPts];
+      load_points<SRC>(base, begin + kPts * tid, end, va, D);
+      for(int i0 = begin; i0 < end; i0 += kTile)
+      {
+        const bool more = i0 + kTile < end;
+        if(more)
+          load_points<SRC>(base, i0 + kTile + kPts * tid, end, vb, D);
+        tileInOrder(va);
+        if(more)
+        {
+#pragma unroll
+          for(int j = 0; j < kPts; j++)
+            va[j] = vb[j];
+        }
+      }
+    }
+    else
+    {
+      SSD_STREAM_LOOP(tileInOrder)
+    }
   }
 
   if constexpr(SPEC)
   {
+    while(qCount > 0)
+      drain(min(qCount, 64), std::false_type{});
     specwin_flush(SL.wins[tid >> 6], win, frameImg, imgWords, X.W64, SL.boxes, lane);
     specmiss_flush(missed, SL.boxes, lane);
     if(curT >= 0)
@@ -1021,29 +1252,29 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
 }
 
 template<int SRC>
-__global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
+__global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ xyz, size_t strideFloats, PointParams P, PreXY Q,
                                                    FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
                                                    size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
   __shared__ HistLds L;
   NoSpecLds none;
-  hist_block<SRC, false, false>(L, none, xyz, strideFloats, P, PixelParams{}, st, tileMasks, nullptr, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);   /* frame on the fast grid axis: see launch note on XCD balance */
+  hist_block<SRC, false, false>(L, none, xyz, strideFloats, P, Q, PixelParams{}, st, tileMasks, nullptr, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);   /* frame on the fast grid axis: see launch note on XCD balance */
 }
 
 /* K1 of a single-pass batch: histogram, cell records AND the planes of the candidate bins.  31 KiB of LDS: five blocks per CU
  * (4 .. 6 measure the same). */
 #ifndef SSD_K1S_WAVES
-#define SSD_K1S_WAVES 5
+#define SSD_K1S_WAVES 4
 #endif
 template<int SRC, bool STRIPS>
-__global__ __launch_bounds__(kThreads, SSD_K1S_WAVES) void k_hist_planes(const float *__restrict__ xyz, size_t strideFloats, PointParams P, PixelParams X,
+__global__ __launch_bounds__(kThreads, SSD_K1S_WAVES) void k_hist_planes(const float *__restrict__ xyz, size_t strideFloats, PointParams P, PreXY Q, PixelParams X,
                                                    FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
                                                    unsigned long long *__restrict__ planeImg,
                                                    size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
   __shared__ HistLds L;
   __shared__ SpecLds SL;
-  hist_block<SRC, true, STRIPS>(L, SL, xyz, strideFloats, P, X, st, tileMasks, planeImg, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
+  hist_block<SRC, true, STRIPS>(L, SL, xyz, strideFloats, P, Q, X, st, tileMasks, planeImg, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
 }
 
 /* K0 of a single-pass batch: which height bins may belong to a step plateau?  A histogram of one cell in every kSpecSample (a
@@ -3573,9 +3804,9 @@ void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameSt
     const bool strips = kTile % P.W != 0;
 #define SSD_LAUNCH_PLANES(SRC, DEPTH)                                                                                                    \
     if(strips)                                                                                                                             \
-      hipLaunchKernelGGL((k_hist_planes<SRC, true>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, DEPTH); \
+      hipLaunchKernelGGL((k_hist_planes<SRC, true>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, DEPTH); \
     else                                                                                                                                   \
-      hipLaunchKernelGGL((k_hist_planes<SRC, false>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, DEPTH);
+      hipLaunchKernelGGL((k_hist_planes<SRC, false>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, DEPTH);
     if(depth)
     {
       SSD_LAUNCH_PLANES(kSrcDepth16, *depth)
@@ -3592,11 +3823,11 @@ void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameSt
     return;
   }
   if(depth)
-    hipLaunchKernelGGL(k_hist<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, tileMasks, tileMaskStride, chunkPoints, *depth);
+    hipLaunchKernelGGL(k_hist<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, st, tileMasks, tileMaskStride, chunkPoints, *depth);
   else if(aligned16(xyz, strideFloats, P.nPoints))
-    hipLaunchKernelGGL(k_hist<kSrcF3Aligned>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
+    hipLaunchKernelGGL(k_hist<kSrcF3Aligned>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, st, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
   else
-    hipLaunchKernelGGL(k_hist<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
+    hipLaunchKernelGGL(k_hist<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, st, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
 }
 void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, int *fallback, hipStream_t s)
 {
