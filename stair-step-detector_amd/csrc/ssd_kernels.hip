@@ -29,7 +29,6 @@
 #include "ssd_closing.h"
 #include "ssd_bestline.h"
 #include "ssd_sort.h"
-#include <type_traits>
 
 namespace ssd
 {
@@ -733,26 +732,6 @@ __device__ __forceinline__ void specwin_emit(unsigned long long *ww, SpecMiss &m
   }
 }
 
-/* one pixel per lane (K1's queue hands the window 64 real pixels at a time) */
-__device__ __forceinline__ void specwin_emit1(unsigned long long *ww, SpecMiss &miss, SpecWindow &w, unsigned long long *__restrict__ planes,
-                                              unsigned int imgWords, int W64, ImageBox *boxes, const unsigned int k, int lane)
-{
-  specwin_prepare(ww, w, planes, imgWords, W64, boxes, k, lane);
-  const unsigned int d = k - specwin_base(w);
-  const unsigned int bit = 1u << (k & 31u);
-  unsigned int *ww32 = reinterpret_cast<unsigned int *>(ww);
-  if(specwin_hit(d))
-    atomicOr(&ww32[((d >> 26) << (kSpecRowBits + 4)) | (((d >> 13) & (kSpecWinRows - 1u)) << 4) | ((d & 0x1fffu) >> 5)], bit);     /* (plane, row, half word) */
-  else if(k != kNoPixel)
-  {
-    const unsigned int slot = k >> 26, iy = (k >> 13) & 0x1fffu, ix = k & 0x1fffu, xw = ix >> 6;
-    atomicOr(reinterpret_cast<unsigned int *>(planes + (slot * imgWords + iy * static_cast<unsigned int>(W64) + xw)) + ((ix >> 5) & 1u), bit);
-    miss.y0 = min(miss.y0, static_cast<int>(iy)); miss.y1 = max(miss.y1, static_cast<int>(iy));
-    miss.x0 = min(miss.x0, static_cast<int>(xw)); miss.x1 = max(miss.x1, static_cast<int>(xw));
-    miss.planes |= 1u << slot;
-  }
-}
-
 /* The streaming kernels are written as block bodies over an explicit LDS struct, (frame, chunk) given by the caller:
  * the kernels below pass blockIdx (tools and experiments have paired two bodies in one launch: DESIGN.md section 3). */
 
@@ -828,30 +807,10 @@ __device__ __forceinline__ unsigned int cell_box_from_d(const PreXY &Q, float x0
   return box;
 }
 
-/* ---- round 5, single pass: the points of the candidate bins wait in a per-wave LDS queue and are rastered 64 at a time ----
- * Rastering inside the point loop ran its instructions for every wave tile that held one candidate point, at 55 % lane use (a
- * wave's 256 pixels straddle the tread's edge).  Now the loop only appends a candidate - its three floats, its exact world z
- * and its plane - to the wave's queue (a ballot, two v_mbcnt, five LDS stores), and whenever 64 have gathered the wave
- * takes them off together: the x / y rows in doubles, pixel, z sum, the bit into the wave's window - every lane busy, the
- * window vote once per 64 real pixels.  The queue is drained after every kQDrainPts points per lane, so it never holds more
- * than 63 + 64 * kQDrainPts entries. */
-#ifndef SSD_Q_DRAIN_PTS
-#define SSD_Q_DRAIN_PTS 1
-#endif
-constexpr int kQDrainPts = SSD_Q_DRAIN_PTS;
-static_assert(kQDrainPts == 1 || kQDrainPts == 2 || kQDrainPts == 4, "the tile's four points per lane in equal parts");
-constexpr int kQCap = 64 * (kQDrainPts + 1);
-struct CandQueue
-{
-  float x[kQCap], y[kQCap], z[kQCap];
-  unsigned int plane[kQCap];
-};
-
 /* what the single pass adds to K1's LDS */
 struct SpecLds
 {
   unsigned long long wins[kThreads / 64][kSpecWinWords];
-  CandQueue queue[kThreads / 64];
   ImageBox boxes[kMaxPlanes];
   unsigned char plane[kMaxBins];                 /* FrameState::specPlane */
   unsigned char order[kMaxTilesPerBlock * (kTile / 256)];   /* STRIPS: the chunk's 256-point strips by (column band, index) */
@@ -860,16 +819,15 @@ struct SpecLds
 };
 struct NoSpecLds {};
 
-/* The constants of K1's two seldom-run pieces - the double-precision x / y rows of a point the pre-filter cannot call, and the
- * queue's consumer - live in LDS, copied there once per block: as kernel arguments they would sit in scalar registers through
- * the whole point loop, which has none to spare (with them the loop's own constants were spilled and came back through a dozen
+/* The constants of K1's seldom-run piece - the double-precision x / y rows of a point the pre-filter cannot call - live in LDS,
+ * copied there once per block: as kernel arguments of the plain k_hist they would sit in scalar registers through the whole
+ * point loop for one lane in thousands (with them the loop's own constants were spilled and came back through a dozen
  * v_readlane per point). */
 struct K1Consts
 {
   double a[6], b[2];                              /* the x and y rows of CameraToWorld */
   double xMin, xMax, yMin, yMax;
   double boxX, boxY;
-  double xToImage, yToImage;
 };
 /* the address of the block's copy, opaque to the compiler at every use: loads from it stay where they are written (hoisted
  * out of the point loop they would occupy thirty-two vector registers for its whole length) */
@@ -908,7 +866,6 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
   SpecMiss missed;
   int curT = -1;
   unsigned long long accT = 0;
-  int qHead = 0, qCount = 0;                    /* wave-uniform: the queue's first entry and its length */
   const unsigned int imgWords = static_cast<unsigned int>(X.H) * static_cast<unsigned int>(X.W64);
   unsigned long long *frameImg = nullptr;
   if constexpr(SPEC)
@@ -946,7 +903,6 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
     c.b[0] = P.b[0]; c.b[1] = P.b[1];
     c.xMin = P.xMin; c.xMax = P.xMax; c.yMin = P.yMin; c.yMax = P.yMax;
     c.boxX = P.boxX; c.boxY = P.boxY;
-    c.xToImage = X.xToImage; c.yToImage = X.yToImage;
   }
   __syncthreads();
 
@@ -955,56 +911,13 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
   int it = 0;
   int nStore = -1;                                                    /* cell records to store (STRIPS), else it * kCellsPerTile */
 
-  /* single pass: the wave takes n (<= 64) candidates off its queue, lane i the i-th (see CandQueue) */
-  auto drain = [&](const int n, auto full)
-  {
-    if constexpr(SPEC)
-    {
-      CandQueue &q = SL.queue[tid >> 6];
-      unsigned int slot = static_cast<unsigned int>(qHead + lane);
-      slot = min(slot, slot - static_cast<unsigned int>(kQCap));            /* wraps: slot - kQCap is huge unless slot >= kQCap */
-      const float px = q.x[slot], py = q.y[slot], pz = q.z[slot];
-      const int plane = static_cast<int>(q.plane[slot]);
-      unsigned int key = kNoPixel;
-      if(decltype(full)::value || lane < n)
-      {
-        /* as k_raster's body: projectToBinaryImage (pointcloud.cpp:458-471) for a bin that may turn out a plateau's; the point
-         * is in range (the loop decided), its x / y rows are world_point_flat's */
-        const K1ConstsLds c = k1_consts(L.kc);
-        const double x = px, y = py, z = pz;
-        double wx = (c->a[0] * x + c->a[1] * y) + c->a[2] * z;
-        double wy = (c->a[3] * x + c->a[4] * y) + c->a[5] * z;
-        wx = wx + c->b[0];
-        wy = wy + c->b[1];
-        const double wz = ((P.a[6] * x + P.a[7] * y) + P.a[8] * z) + P.b[2];       /* world_z_flat's row once more: 8 bytes per entry cost a block per CU */
-        /* Projection2D::worldToImage (pointcloud.cpp:79-83) as image_pixel */
-        const int ix = static_cast<int>((wx - c->xMin) * c->xToImage);
-        const int iy = static_cast<int>((c->yMax - wy) * c->yToImage);
-        const bool inside = (static_cast<unsigned int>(ix) < static_cast<unsigned int>(X.W)) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(X.H));
-        if(plane != curT)
-        {
-          if(curT >= 0)
-            atomicAdd(&SL.ltot[curT][lane & 7], accT);
-          curT = plane;
-          accT = 0;
-        }
-        accT += static_cast<unsigned long long>(z_plus_magic_bits(wz));      /* the bits of z + 6144; k_peaks takes the constant's share off (count x kMagicBits) */
-        if(!inside)
-          atomicAdd(&SL.oob[plane], 1u);                   /* quirk Q5, rare */
-        key = inside ? pixel_key(plane, iy, ix) : kNoPixel;
-      }
-      specwin_emit1(SL.wins[tid >> 6], missed, win, frameImg, imgWords, X.W64, SL.boxes, key, lane);
-      qHead += n;
-      qHead = qHead >= kQCap ? qHead - kQCap : qHead;
-      qCount -= n;
-    }
-  };
-
   auto tileBody = [&](const F3 (&v)[kPts], const int cellAt)
   {
     unsigned int groups = 0u;
     /* extremes of d (pre_xy) over the lane's in-range points: the cell's box */
     float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+    unsigned int keys[kPts] = { kNoPixel, kNoPixel, kNoPixel, kNoPixel };
+    bool anyKey = false;                                          /* wave-uniform */
 #pragma unroll
     for(int j = 0; j < kPts; j++)
     {
@@ -1044,26 +957,46 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
       }
       if constexpr(SPEC)
       {
-        /* a candidate joins the wave's queue (most tiles hold none: ground, risers, background) */
+        /* a point of a candidate bin: its pixel key, its share of the plane's z sum */
         const bool cand = plane != 0xff;
         const unsigned long long cm = __ballot(cand);
         if(cm != 0ull)
         {
+          unsigned int key = kNoPixel;
           if(cand)
           {
-            CandQueue &q = SL.queue[tid >> 6];
-            unsigned int slot = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned int>(cm >> 32),
-                                                          __builtin_amdgcn_mbcnt_lo(static_cast<unsigned int>(cm), static_cast<unsigned int>(qHead + qCount)));
-            slot = min(slot, slot - static_cast<unsigned int>(kQCap));        /* qHead < kQCap and the queue never holds kQCap entries: one wrap */
-            q.x[slot] = p.x; q.y[slot] = p.y; q.z[slot] = p.z;
-            q.plane[slot] = static_cast<unsigned int>(plane);
+            /* as k_raster's body: projectToBinaryImage (pointcloud.cpp:458-471) for a bin that may turn out a plateau's; the
+             * point is in range, its x / y rows are world_point_flat's */
+            const double x = p.x, y = p.y, z = p.z;
+            double wx = (P.a[0] * x + P.a[1] * y) + P.a[2] * z;
+            double wy = (P.a[3] * x + P.a[4] * y) + P.a[5] * z;
+            wx = wx + P.b[0];
+            wy = wy + P.b[1];
+            const int ix = static_cast<int>((wx - P.xMin) * X.xToImage);         /* Projection2D::worldToImage (pointcloud.cpp:79-83) as image_pixel */
+            const int iy = static_cast<int>((P.yMax - wy) * X.yToImage);
+            const bool inside = (static_cast<unsigned int>(ix) < static_cast<unsigned int>(X.W)) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(X.H));
+            if(plane != curT)
+            {
+              if(curT >= 0)
+                atomicAdd(&SL.ltot[curT][lane & 7], accT);
+              curT = plane;
+              accT = 0;
+            }
+            accT += static_cast<unsigned long long>(z_plus_magic_bits(wz));      /* the bits of z + 6144; k_peaks takes the constant's share off (count x kMagicBits) */
+            if(!inside)
+              atomicAdd(&SL.oob[plane], 1u);                   /* quirk Q5, rare */
+            key = inside ? pixel_key(plane, iy, ix) : kNoPixel;
           }
-          qCount += __popcll(cm);
+          keys[j] = key;
+          anyKey = true;
         }
-        if((j + 1) % kQDrainPts == 0)
-          while(qCount >= 64)
-            drain(64, std::true_type{});
       }
+    }
+    if constexpr(SPEC)
+    {
+      /* most tiles hold no point of a candidate bin (ground, risers, background) */
+      if(anyKey)
+        specwin_emit(SL.wins[tid >> 6], missed, win, frameImg, imgWords, X.W64, SL.boxes, keys, lane);
     }
     row_reduce_cell(groups, x0, x1, y0, y1);
     if((lane & 15) == 0)                                         /* cell = 64 consecutive points = lanes 16q .. 16q+15 */
@@ -1172,10 +1105,11 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
       tileBody(v, it * kCellsPerTile + (tid >> 4));
       it++;
     };
+#ifndef SSD_K1_TWO_BODIES
     if constexpr(SPEC)
     {
-      /* one copy of the body (it holds the queue's consumer kPts / kQDrainPts times): the next tile's loads go out before the
-       * current tile is processed, as in SSD_STREAM_LOOP, and are moved into place after it (twelve moves per tile) */
+      /* one copy of the body: the next tile's loads go out before the current tile is processed, as in SSD_STREAM_LOOP, and
+       * are moved into place after it (twelve moves per tile) */
       F3 va[kPts], vb[kPts];
       load_points<SRC>(base, begin + kPts * tid, end, va, D);
       for(int i0 = begin; i0 < end; i0 += kTile)
@@ -1193,6 +1127,7 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
       }
     }
     else
+#endif
     {
       SSD_STREAM_LOOP(tileInOrder)
     }
@@ -1200,8 +1135,6 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
 
   if constexpr(SPEC)
   {
-    while(qCount > 0)
-      drain(min(qCount, 64), std::false_type{});
     specwin_flush(SL.wins[tid >> 6], win, frameImg, imgWords, X.W64, SL.boxes, lane);
     specmiss_flush(missed, SL.boxes, lane);
     if(curT >= 0)
@@ -1252,7 +1185,7 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
 }
 
 template<int SRC>
-__global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ xyz, size_t strideFloats, PointParams P, PreXY Q,
+__global__ __launch_bounds__(kThreads, 6) void k_hist(const float *__restrict__ xyz, size_t strideFloats, PointParams P, PreXY Q,
                                                    FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
                                                    size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
@@ -1264,7 +1197,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_hist(const float *__restrict__ 
 /* K1 of a single-pass batch: histogram, cell records AND the planes of the candidate bins.  31 KiB of LDS: five blocks per CU
  * (4 .. 6 measure the same). */
 #ifndef SSD_K1S_WAVES
-#define SSD_K1S_WAVES 4
+#define SSD_K1S_WAVES 5
 #endif
 template<int SRC, bool STRIPS>
 __global__ __launch_bounds__(kThreads, SSD_K1S_WAVES) void k_hist_planes(const float *__restrict__ xyz, size_t strideFloats, PointParams P, PreXY Q, PixelParams X,

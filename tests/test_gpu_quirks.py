@@ -264,3 +264,78 @@ def test_ground_quadrilateral_without_points_reads_minus_nan(ssd, oracle, gpu_de
     want = ssd.Stairs(good).serialize()
     cut = want.index('["height",') + len('["height",')
     assert ssd.Stairs(fr).serialize() == want[:cut] + "-nan" + want[want.index("]", cut):]
+
+
+def _band_cloud(cfg, a, b, rng, n_per):
+    """camera-frame float points whose world x or y lies on / next to a limit of the measuring range (see the test below)"""
+    inv = np.linalg.inv(a)
+    deltas = np.concatenate([[0.0], *[[d, -d] for d in (2.2e-16, 1e-15, 1e-12, 1e-10, 1e-9, 1e-8, 3e-8, 1e-7, 3e-7, 1e-6, 3e-6, 1e-5, 3e-5, 4.5e-5, 5.5e-5, 7e-5, 1e-4)]])
+    pts = []
+    for lim, axis in ((cfg.x_min, 0), (cfg.x_max, 0), (cfg.y_min, 1), (cfg.y_max, 1)):
+        for d in list(deltas) + [None]:
+            w = np.empty((n_per, 3))
+            w[:, 0] = rng.uniform(cfg.x_min + 0.05, cfg.x_max - 0.05, n_per)
+            w[:, 1] = rng.uniform(cfg.y_min + 0.05, cfg.y_max - 0.05, n_per)
+            w[:, 2] = rng.choice([0.0034, 0.1712, 0.3391], n_per) + rng.normal(0.0, 0.0007, n_per)
+            w[:, axis] = lim + (rng.uniform(-2e-4, 2e-4, n_per) if d is None else d)     # None: anywhere around the band's own edges
+            pts.append((w - b) @ inv.T)
+    # corners of the range: both coordinates in the band at once
+    for xl in (cfg.x_min, cfg.x_max):
+        for yl in (cfg.y_min, cfg.y_max):
+            w = np.stack([xl + rng.normal(0, 2e-7, n_per), yl + rng.normal(0, 2e-7, n_per), np.full(n_per, 0.1712)], 1)
+            pts.append((w - b) @ inv.T)
+    return np.concatenate(pts).astype(np.float32)
+
+
+def test_points_in_the_prefilters_band_take_the_doubles(ssd, oracle, gpu_device):
+    """K1 decides the x / y range test in single precision first (csrc/ssd_prexy.h) and hands the band around the four limits -
+    and inputs beyond 64 m - to the reference's doubles.  A pitched, rolled, yawed camera and a cloud made for that band:
+    world points whose x or y is a limit plus or minus nothing, a few double ulps, 1e-12 .. 1e-4 m (the band's own edges lie
+    at +- 4.5e-5 m here), taken back to camera coordinates and rounded to float (which scatters them by ~1e-7 m to either
+    side of the limit), on two plateaus' heights; far points (70 .. 5000 m out) along all axes; everything else a plain
+    two-step cloud.  Then the same rotation seen from 40 m away, where single precision is off by 4e-7 of the range instead
+    of 6e-8 (a band of one float ulp gets a thousand of these points wrong; the bound must hold them all).  Histogram,
+    counts, images, results: the oracle's, bit for bit - one point called wrongly moves a bin's count."""
+    sc = ssd.make_scene(W, H, n_steps=2, seed=77, pitch_deg=47.0, roll_deg=3.5, yaw_deg=12.0, sigma=0.001)
+    trans = ssd.transformation_for_scene(sc)
+    cfg = ssd.default_config(W, H, max_frames_per_batch=1)
+    a = np.array(list(trans.constants.a), dtype=np.float64).reshape(3, 3)
+    b = np.array(list(trans.constants.b), dtype=np.float64)
+    rng = np.random.default_rng(5)
+    xyz = ssd.synth_host([sc])[0].reshape(-1, 3).copy()
+    band = _band_cloud(cfg, a, b, rng, 300)
+    far = []
+    for r in (70.0, 300.0, 5000.0):
+        for ax in range(3):
+            for sgn in (1.0, -1.0):
+                v = np.zeros(3); v[ax] = sgn * r
+                far.append(v + rng.normal(0, 0.3, (40, 3)))
+    far = np.concatenate(far).astype(np.float32)
+    extra = np.concatenate([band, far])
+    assert len(extra) < W * H // 2
+    idx = np.sort(rng.permutation(W * H)[:len(extra)])
+    xyz[idx] = extra
+    xyz = xyz.reshape(H, W, 3)
+    det = ssd.Detector(cfg, trans, gpu_device)
+    rep = parity.check_frame(ssd, oracle, det, cfg, trans.constants, xyz, images=True)
+    ref = oracle.process(ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants), xyz)[0]
+    assert ref.n_inrange < ref.n_nonzero and rep["n_steps"] >= 1
+    # the same cloud through the single pass (forced: K1 then also rasters the candidate bins' points itself)
+    det.single_pass(1)
+    rep1 = parity.check_frame(ssd, oracle, det, cfg, trans.constants, xyz, images=True)
+    assert det.single_pass_stats(1)["ran"] and rep1["line"] == rep["line"]
+    det.close()
+    # 40 m away: a calibration with the same rotation whose camera stands far off (inputs still below the pre-filter's 64 m)
+    far_trans = ssd.GeometricTransformation()
+    for i in range(9):
+        far_trans.constants.a[i] = trans.constants.a[i]
+    b_far = b + a @ np.array([3.0, -2.0, -40.0])
+    for i in range(3):
+        far_trans.constants.b[i] = b_far[i]
+    band_far = _band_cloud(cfg, a, b_far, rng, 300)
+    assert 30.0 < np.abs(band_far).max() < 60.0
+    cloud_far = np.zeros((W * H, 3), dtype=np.float32)
+    cloud_far[np.sort(rng.permutation(W * H)[:len(band_far)])] = band_far
+    det = ssd.Detector(cfg, far_trans, gpu_device)
+    parity.check_frame(ssd, oracle, det, cfg, far_trans.constants, cloud_far.reshape(H, W, 3), images=True)
+    det.close()
