@@ -46,6 +46,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec; ~6.3 TB/s achievable by a float4 copy)
+VALU_CYCLES = 4.5         # SIMD cycles per wave64 vector instruction of this path, measured (tools/instr_rate.hip, profiles/r05_instr_rate.txt:
+                          # fp64 add / mul / fma 4.6-4.7, conversions and compares 4.4-4.5, DPP 4.5, v_pk_fma_f32 4.6; only plain f32 add / mul,
+                          # 32-bit add / and and v_mov run at 2.4-2.5)
 METRIC = "point-cloud frames/sec (1024×768 pts) at 1/2/4/8 GPUs; step height/corner max-abs err"
 METRIC_FHD = "point-cloud frames/sec (1920×1080 pts, stress); step height/corner max-abs err"
 
@@ -188,6 +191,109 @@ def host_fed_leg(ssd, scenes, n_frames=256, reps=3, device=0):
     return out
 
 
+def file_sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for block in iter(lambda: f.read(1 << 20), b""):
+            h.update(block)
+    return h.hexdigest()
+
+
+def counters_stamp(name, lib_sha):
+    """The stamp of a committed counter file (profiles/<name>: written by tools/r05_final.sh with the git revision and the
+    sha256 of the libssd_hip.so its passes ran) against the library this process loaded: -> (source string, stale)."""
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        st = json.load(open(path)).get("stamp") or {}
+    except Exception:
+        return None, None
+    src = "profiles/%s (rocprofv3 --pmc passes of this command, committed; not re-measured in this run; git %s, libssd_hip.so sha256 %s)" % (
+        name, st.get("git_head", "unknown"), (st.get("lib_sha256") or "unknown")[:16])
+    return src, (st.get("lib_sha256") != lib_sha)
+
+
+def secondary_leg(ssd, scenes, torch, device, workload, steps, warmup, check_frames, with_cpu):
+    """One of the other BASELINE configurations timed in the same run: `fhd_stress` = configs[4], 256
+    frames of 1920x1080 (8 noisy steps, 5 % outliers); `depth16` = the metric's 1024 XGA frames as 16-bit depth (SURVEY 8(f)
+    rank 1).  Same procedure as the primary region - frames resident in HBM, three batches in flight, warm-up, K timed steps
+    between synchronisations, then a few passes one at a time with events for K1's own duration - and a few frames of the last
+    pass against the CPU oracle."""
+    import numpy as np
+    fhd = workload == "fhd_stress"
+    depth_in = workload == "depth16"
+    W, H = (1920, 1080) if fhd else (1024, 768)
+    F = 256 if fhd else 1024
+    sc = scenes.fhd_stress_scenes(ssd, F, base_seed=9000) if fhd else scenes.batch_scenes(ssd, W, H, F, base_seed=100000, rng_seed=1000)
+    trans = ssd.transformation_for_scene(sc[0])
+    cfg = ssd.default_config(W, H, max_frames_per_batch=F, batches_in_flight=3)
+    frame_bytes = W * H * (2 if depth_in else 12)
+    frames = torch.empty(F * frame_bytes, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    det = ssd.Detector(cfg, trans, device)
+    intr = ssd.intrinsics_for_scene(sc[0])
+    if depth_in:
+        ssd.synth_depth_device(sc, frames.data_ptr(), device=device, stream=stream)
+        det.set_intrinsics(intr)
+    else:
+        ssd.synth_device(sc, frames.data_ptr(), device=device, stream=stream)
+    enqueue = (lambda: det.enqueue_depth(frames.data_ptr(), F, stream=stream)) if depth_in else (lambda: det.enqueue(frames.data_ptr(), F, stream=stream))
+    ahead = max(det.batches_in_flight, 2) - 1
+
+    def run(n):
+        res = None
+        for i in range(n):
+            enqueue()
+            if i >= ahead:
+                res = det.fetch(F, back=ahead)
+        for back in range(min(ahead, n) - 1, -1, -1):
+            res = det.fetch(F, back=back)
+        return res
+
+    run(max(warmup, 4))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    det.set_timing(True)
+    stage = {k: 0.0 for k in ssd.STAGE_NAMES}
+    n_extra = 4
+    for b in range(n_extra + 1):
+        enqueue()
+        det.fetch(F)
+        if b > 0:
+            for k, v in det.stage_times_ms().items():
+                stage[k] += v / n_extra
+    det.set_timing(False)
+    alg = float(frame_bytes) * F
+    k1 = stage["hist"]
+    out = {"workload": ("BASELINE configs[4]: %d synthetic %dx%d frames (8 noisy steps, 5 %% outliers) resident in HBM" % (F, W, H)) if fhd else
+                       ("the metric's %d XGA frames as 16-bit depth images resident in HBM, deprojected on the fly (SURVEY.md section 8(f) rank 1)" % F),
+           "value": F * steps / dt, "unit": "frames/s", "steps": steps, "ms_per_step": dt / steps * 1e3, "frames_per_step": F,
+           "width": W, "height": H, "input": "depth16" if depth_in else "float3", "batches_in_flight": det.batches_in_flight,
+           "stage_ms": stage, "k1_ms": k1, "algorithmic_bytes_per_launch": alg,
+           "k1_frac_of_hbm_peak": (alg / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS) if k1 > 0 else None,
+           "whole_path_frac_of_hbm_peak": alg * steps / dt / 1e9 / HBM_PEAK_GBS,
+           "steps_found": int(sum(r.n_steps for r in res))}
+    if with_cpu and check_frames > 0:
+        import oracle_binding as ob
+        import parity
+        oracle = ob.load_oracle()
+        rep = {}
+        idx = sorted(set(int(i) for i in np.linspace(0, F - 1, check_frames)))
+        for i in idx:
+            x = frames[i * frame_bytes:(i + 1) * frame_bytes].cpu().numpy()
+            x = oracle.deproject(intr, x.view(np.uint16).reshape(H, W)) if depth_in else x.view(np.float32)
+            parity.check_results_only(ssd, oracle, cfg, trans.constants, x, res[i], rep)
+        out["parity"] = {"frames_checked_against_oracle": len(idx), "max_abs_height_err_m": rep.get("max_height_err", 0.0),
+                         "max_abs_corner_err_m": rep.get("max_corner_err", 0.0), "bar_m": 1e-4}
+    det.close()
+    del frames
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +316,8 @@ def main():
     ap.add_argument("--no-hostfed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg reported beside `value`")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (profiling passes: its 56 one-frame "
                                                                "launches would be averaged into the per-kernel statistics)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary legs (BASELINE configs[4] = FHD stress, and 16-bit depth input) the default run times after the primary region")
     ap.add_argument("--risers", action="store_true",
                     help="also gather the evidence of the vertical faces (extension beyond the reference, SURVEY 8f rank 4); off for the metric")
     args = ap.parse_args()
@@ -360,6 +468,7 @@ def main():
     shards = ranks.gather(mine)
 
     if rank == 0:
+        lib_sha = file_sha256(ssd.LIB_PATH)
         value = world * F * args.steps / dt_max
         achieved = alg_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         plain_ms = sum(stream_ms) / len(stream_ms) if stream_ms else None
@@ -381,8 +490,8 @@ def main():
             try:
                 j = json.load(open(pm))
                 pipeline_moved = {"hbm_read_bytes": j["hbm_read_bytes"], "hbm_write_bytes": j["hbm_write_bytes"],
-                                  "over_algorithmic": j["bytes_moved_over_algorithmic"],
-                                  "source": "profiles/pmc_pipeline.json (PMC passes of this command, committed; not re-measured in this run)"}
+                                  "over_algorithmic": j["bytes_moved_over_algorithmic"]}
+                pipeline_moved["source"], pipeline_moved["stale"] = counters_stamp("pmc_pipeline.json", lib_sha)
             except Exception:
                 pipeline_moved = None
         # The two-sided floor of the whole pass, from the committed counters of this command (profiles/pmc_issue.json: vector
@@ -397,13 +506,15 @@ def main():
                 kernels = json.load(open(pi))["kernels"]
                 valu = sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in kernels.items() if "k_stream_read" not in k and "synth" not in k)
                 simds, clock_hz = 1024, 2.4e9
-                floors = {"valu_instructions_per_launch": valu, "valu_floor_ms": valu * 4.0 / (simds * clock_hz) * 1e3,
+                floors = {"valu_instructions_per_launch": valu, "valu_floor_ms": valu * VALU_CYCLES / (simds * clock_hz) * 1e3,
                           "hbm_floor_ms": None if plain_ms is None else (pipeline_moved["hbm_read_bytes"] + pipeline_moved["hbm_write_bytes"]) / (alg_bytes / plain_ms),
                           "hbm_floor_ms_at_peak": (pipeline_moved["hbm_read_bytes"] + pipeline_moved["hbm_write_bytes"]) / (HBM_PEAK_GBS * 1e9) * 1e3,
                           "measured_ms": dt_max / args.steps * 1e3,
-                          "note": "valu floor = vector instructions x 4 cycles / (1024 SIMDs x 2.4 GHz); hbm floor = HBM bytes of the pass / "
+                          "note": "valu floor = vector instructions x %.1f cycles / (1024 SIMDs x 2.4 GHz) (what a wave64 instruction of this path costs a SIMD: "
+                                  "fp64, conversions, compares, DPP, packed fp32 alike - profiles/r05_instr_rate.txt); hbm floor = HBM bytes of the pass / "
                                   "the plain read stream's rate measured in this run; counters: profiles/pmc_issue.json, profiles/pmc_pipeline.json "
-                                  "(committed rocprofv3 --pmc passes of this command, not re-measured here)"}
+                                  "(committed rocprofv3 --pmc passes of this command, not re-measured here)" % VALU_CYCLES}
+                floors["source"], floors["stale"] = counters_stamp("pmc_issue.json", lib_sha)
             except Exception:
                 floors = None
         out = {
@@ -422,8 +533,8 @@ def main():
                                                     "the step plateaus into planes)" if single_pass["ran"] else "k_hist (K1: transform+crop+bin+histogram)"),
                          "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": None if traffic is None else "profiles/pmc_k_hist.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                           "of this command, committed; not re-measured in this run)",
+                         "traffic_source": None if traffic is None else counters_stamp("pmc_k_hist.json", lib_sha)[0],
+                         "stale": None if traffic is None else counters_stamp("pmc_k_hist.json", lib_sha)[1],
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,
                          "plain_stream_GBps": None if plain_ms is None else alg_bytes / (plain_ms * 1e-3) / 1e9,
                          "k1_over_plain_stream": None if plain_ms is None or k1_ms <= 0 else plain_ms / k1_ms,
@@ -452,24 +563,27 @@ def main():
                 want = "k_hist_planes" if single_pass["ran"] else "k_hist<"
                 hit = [v for k, v in kernels.items() if want in k and "SQ_INSTS_VALU" in v]
                 if hit and k1_ms > 0 and not depth_in and not fhd and F == 1024:
-                    vf = hit[0]["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9) * 1e3
+                    vf = hit[0]["SQ_INSTS_VALU"] * VALU_CYCLES / (1024 * 2.4e9) * 1e3
                     out["roofline"]["issue"] = {"valu_instructions_per_launch": hit[0]["SQ_INSTS_VALU"], "valu_floor_ms": vf, "frac_of_issue_peak": vf / k1_ms,
                                                 "valu_busy_percent_one_batch_at_a_time": hit[0].get("VALUBusy"),
-                                                "note": "the kernel's vector instructions x 4 cycles / (1024 SIMDs x 2.4 GHz) over its measured launch time; counters: "
-                                                        "profiles/pmc_issue.json (committed pass of this command)"}
+                                                "note": "the kernel's vector instructions x %.1f cycles / (1024 SIMDs x 2.4 GHz) over its measured launch time; counters: "
+                                                        "profiles/pmc_issue.json (committed pass of this command)" % VALU_CYCLES,
+                                                "stale": counters_stamp("pmc_issue.json", lib_sha)[1]}
             except Exception:
                 pass
         if floors is not None:           # the whole pass's floors beside the dominant kernel's roofline
             out["roofline"]["valu_floor_ms"] = floors["valu_floor_ms"]
             out["roofline"]["hbm_floor_ms"] = floors["hbm_floor_ms"]
             out["roofline"]["pass_ms"] = floors["measured_ms"]
+        out["library"] = {"path": os.path.relpath(ssd.LIB_PATH, ROOT), "sha256": lib_sha}
         out["devices"] = [sh["where"] for sh in shards]
         out["distinct_devices"] = distinct_devices(out["devices"])
         if world > 1:
             out["ranks"] = shards
-            if out["distinct_devices"] != world and not os.environ.get("SSD_BENCH_DEVICE"):
+            if out["distinct_devices"] != world:
                 # said in the line, not raised: the other ranks are already waiting in the closing barrier
-                out["warning"] = "%d ranks on %d distinct GPUs: this is not an %d-GPU measurement" % (world, out["distinct_devices"], world)
+                out["warning"] = "%d ranks on %d distinct GPU(s)%s: this is not an %d-GPU measurement" % (
+                    world, out["distinct_devices"], " (SSD_BENCH_DEVICE puts every rank on one device: a test of the launcher)" if os.environ.get("SSD_BENCH_DEVICE") else "", world)
         steps_hist = [r.n_steps for r in res]
         out["steps_histogram"] = {str(k): int(sum(1 for n in steps_hist if n == k)) for k in sorted(set(steps_hist))}
 
@@ -514,7 +628,11 @@ def main():
                     list(pool.map(lambda a: oracle.process_lean(ocfg, ocal, a), work))
                     adt = time.perf_counter() - c0
                 out["cpu_baseline_all_cores"] = {"value": len(work) / adt, "unit": "frames/s", "cores": cores, "kind": "port",
-                                                 "sample": "%d frames (%d distinct), one frame per thread, %.1f s wall" % (len(work), len(keep), adt)}
+                                                 "sample": "%d frames (%d distinct), one frame per thread, %.1f s wall" % (len(work), len(keep), adt),
+                                                 "limited_by": "not by the cores: a pool of Python threads calling the oracle through ctypes, every frame's 9.4 MB cloud and the "
+                                                               "oracle's per-frame allocations (point lists, byte images) through one allocator and the sockets' memory - %.1f frames/s "
+                                                               "per core here against the single thread's rate above; it understates what the host could do and is a stated baseline, "
+                                                               "never the target" % (len(work) / adt / cores)}
             out["parity"] = {"frames_checked_against_oracle": checked, "max_abs_height_err_m": rep.get("max_height_err", 0.0),
                              "max_abs_corner_err_m": rep.get("max_corner_err", 0.0), "bar_m": 1e-4}
         if world == 1 and not depth_in and not args.no_latency:
@@ -565,6 +683,12 @@ def main():
                 odt = time.perf_counter() - c0
                 pipe.close()
                 out["pipelined"]["depth%d" % depth] = {"value": F * args.steps / odt, "ms_per_step": odt / args.steps * 1e3}
+        if world == 1 and not fhd and not depth_in and not args.no_secondary:
+            # the other BASELINE configurations, timed by the same run; the primary region above is untouched
+            out["secondary"] = {}
+            for wl in ("fhd_stress", "depth16"):
+                out["secondary"][wl] = secondary_leg(ssd, scenes, torch, device, wl, steps=10, warmup=args.warmup, check_frames=4 if wl == "fhd_stress" else 9,
+                                                     with_cpu=not args.no_cpu)
         if world == 1 and not args.no_hostfed and not fhd:
             det.close()
             del frames

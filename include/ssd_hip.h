@@ -44,7 +44,8 @@ extern "C" {
 #define SSD_MAX_PLATEAUS 32       /* filtered histogram peaks per frame */
 #define SSD_MAX_STEP_IMAGES 16    /* plateaus at or above minHeight per frame (each owns a bit image) */
 #define SSD_MAX_STEPS (SSD_MAX_STEP_IMAGES + 1)
-#define SSD_MAX_PLANES 24         /* single-pass batches: bit images of candidate height bins per frame (workspace size) */
+#define SSD_MAX_PLANES 24         /* single-pass batches: bit images of candidate height bins a frame can have */
+#define SSD_POOL_PLANES_PER_FRAME 10   /* ... and how many the workspace holds per frame of max_frames_per_batch (a pool: frames draw what they need) */
 #define SSD_MAX_SCANS 128
 #define SSD_MAX_EDGE_PTS 256
 #define SSD_LINE_CAP 4096
@@ -90,8 +91,11 @@ typedef struct
    *      planes of the single pass, ssd_set_single_pass).  Stream contract then: a batch
    *      starts behind the work `stream` holds at the time of the call, but work put on `stream` afterwards is NOT ordered
    *      behind the batch — its frames must stay untouched until its results were fetched, or until a stream was made to wait
-   *      for it with ssd_stream_wait.  ssd_process_host / ssd_process_depth_host gain nothing from it (their slices are
-   *      double-buffered on streams of their own and use the first workspace only). */
+   *      for it with ssd_stream_wait.  ssd_process_host / ssd_process_depth_host cut a host batch into slices of at most 32
+   *      frames, copied through two staging buffers on a copy stream of the handle's own; with one workspace the slices'
+   *      kernels follow each other on the handle's compute stream, with several they take the workspaces in turn like any other
+   *      batches and overlap (a staging buffer is refilled only after the kernels of the slice that read it have finished on
+   *      THEIR stream).  Both calls return when every slice's results are in `results`; they use no stream of the caller's. */
   int32_t batches_in_flight;
 } ssd_config;
 

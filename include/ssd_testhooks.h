@@ -52,6 +52,10 @@ int ssd_test_empty_quadrilateral(ssd_handle *h, int frame, int surface);
  * geometry allows (a handle without planes gets them).  sabotage: 0 = none, 1 = the predictor's planes three bins above the right
  * ones, 2 = no planes at all - either way every frame with steps must come out through k_raster, bit-equal. */
 int ssd_test_single_pass(ssd_handle *h, int mode, int sabotage);
+/* The planes k_predict may hand out per batch (round 5: a pool per workspace, ssd_device.h plane_pool_size): planes = 0 .. the
+ * pool's size lowers it (frames the pool cannot serve come out through k_raster, bit-equal), -1 restores it.  Returns the
+ * pool's size. */
+int ssd_test_plane_pool(ssd_handle *h, int planes);
 /* of the last enqueue (synchronises): returns 1 when it ran the single pass, else 0 (counts zero); counts[0] = frames whose step
  * plateaus the planes covered (k_raster skipped them), [1] = frames with step plateaus, [2] = planes over all frames,
  * [3] = 64-bit words of the lane's plane images that are not zero (the invariant between batches: 0) */

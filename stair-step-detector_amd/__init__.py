@@ -26,6 +26,13 @@ MAX_BINS = 128
 MAX_PLATEAUS = 32
 MAX_STEP_IMAGES = 16
 MAX_PLANES = 24
+POOL_PLANES_PER_FRAME = 10
+
+
+def plane_pool_size(frames, points_per_frame):
+    """planes a workspace holds for batches of up to `frames` frames (csrc/ssd_device.h: plane_pool_size)"""
+    per = 16 if points_per_frame < 600000 else POOL_PLANES_PER_FRAME
+    return max(frames * per + 2 * MAX_PLANES, min(frames, 8) * MAX_PLANES)
 MAX_STEPS = MAX_STEP_IMAGES + 1
 MAX_SCANS = 128
 MAX_EDGE_PTS = 256
@@ -150,7 +157,7 @@ SOURCE_EXPORTS = [
 # libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
 HOOK_EXPORTS = [
     "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_ground_image", "ssd_test_line_host", "ssd_test_intersect_host", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_best_line_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
-    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_test_single_pass", "ssd_test_single_pass_stats", "ssd_test_single_pass_frame", "ssd_test_single_pass_sample", "ssd_test_predict_table_host", "ssd_test_record_offset", "ssd_test_record_realloc", "ssd_test_record_realloc_sized", "ssd_test_record_release", "ssd_testhooks_last_error",
+    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_test_single_pass", "ssd_test_plane_pool", "ssd_test_single_pass_stats", "ssd_test_single_pass_frame", "ssd_test_single_pass_sample", "ssd_test_predict_table_host", "ssd_test_record_offset", "ssd_test_record_realloc", "ssd_test_record_realloc_sized", "ssd_test_record_release", "ssd_testhooks_last_error",
 ]
 SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
 HOOKS_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_testhooks.so")
@@ -270,6 +277,7 @@ def hooks_lib():
     L.ssd_test_ground_image.argtypes = [vp, i32, vp]
     L.ssd_test_empty_quadrilateral.argtypes = [vp, i32, i32]
     L.ssd_test_single_pass.argtypes = [vp, i32, i32]
+    L.ssd_test_plane_pool.argtypes = [vp, i32]
     L.ssd_test_single_pass_stats.argtypes = [vp, i32, i32, vp]
     L.ssd_test_single_pass_frame.argtypes = [vp, i32, vp, vp]
     L.ssd_test_single_pass_sample.argtypes = [vp, i32, vp]
@@ -523,6 +531,10 @@ class Detector:
         """test hook: the single pass (K1 rasters the step plateaus itself) -1 = as the product decides, 0 = never, 1 = whenever the
         geometry allows; sabotage 1 / 2 = the predictor's planes in the wrong bins / none (every frame must fall back to k_raster)"""
         _check(hooks_lib().ssd_test_single_pass(self._h, mode, sabotage), "hooks")
+
+    def plane_pool(self, planes=-1):
+        """test hook: the planes k_predict may hand out per batch (-1: all the workspace holds); returns the pool's size"""
+        return _check(hooks_lib().ssd_test_plane_pool(self._h, planes), "hooks")
 
     def single_pass_stats(self, frames, scan_planes=True):
         """test hook, of the last enqueue: {'ran': it ran the single pass, 'covered': frames whose step plateaus the planes covered,

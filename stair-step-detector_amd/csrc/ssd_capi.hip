@@ -419,7 +419,8 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   const size_t groundBytes = static_cast<size_t>(h->F) * h->imgWords * 8;
   /* the planes of the single pass, for handles whose batches can qualify (ssd_launch.h) */
   const size_t planeBytes = single_pass_geometry(P.W, P.H) && single_pass_batch(h->F, P.nPoints)
-                            ? static_cast<size_t>(h->F) * kMaxPlanes * h->imgWords * 8 : 0;
+                            ? static_cast<size_t>(plane_pool_size(h->F, h->P.nPoints)) * h->imgWords * 8 : 0;
+  h->planePool = static_cast<int>(plane_pool_size(h->F, h->P.nPoints));
   auto cleanup = [&]() { ssd_destroy(h); };
 #define HIP_TRY_H(expr)                                                                                 \
   do                                                                                                    \
@@ -450,18 +451,44 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
     HIP_TRY_H(hipMemset(L.dState, 0, sizeof(FrameState) * h->F));
     HIP_TRY_H(hipMemset(L.dStepImg, 0, stepBytes));
     HIP_TRY_H(hipMemset(L.dGroundImg, 0, groundBytes));
-    if(planeBytes)
-    {
-      HIP_TRY_H(hipMalloc(&L.dPlaneImg, planeBytes));
-      HIP_TRY_H(hipMemset(L.dPlaneImg, 0, planeBytes));
-      HIP_TRY_H(hipMalloc(&L.dFallback, sizeof(int) * (kFallbackList + static_cast<size_t>(h->F))));
-      HIP_TRY_H(hipMemset(L.dFallback, 0, sizeof(int) * (kFallbackList + static_cast<size_t>(h->F))));
-    }
   }
+  /* The planes of the single pass are an optimisation (results are the same without them): when they do not fit beside the
+   * rest - a larger batch, more workspaces, memory shared with the caller's frames - the handle gives up the planes of ALL its
+   * workspaces and runs two passes, as ssd_set_single_pass(h, 0) would; it does not fail. */
+  size_t planeBytesHeld = 0;
   if(planeBytes)
   {
-    HIP_TRY_H(hipHostMalloc(&h->hFallback, sizeof(int) * 2 * kMaxLanes, hipHostMallocDefault));
-    std::memset(h->hFallback, 0, sizeof(int) * 2 * kMaxLanes);
+    bool ok = true;
+    for(int k = 0; k < depth && ok; k++)
+    {
+      ssd_lane &L = h->lane[k];
+      ok = hipMalloc(&L.dPlaneImg, planeBytes) == hipSuccess
+           && hipMalloc(&L.dFallback, sizeof(int) * (kFallbackList + static_cast<size_t>(h->F))) == hipSuccess;
+    }
+    if(ok && hipHostMalloc(&h->hFallback, sizeof(int) * 2 * kMaxLanes, hipHostMallocDefault) != hipSuccess)
+      ok = false;
+    if(!ok)
+    {
+      (void)hipGetLastError();                   /* the failed allocation's error is not the handle's */
+      for(int k = 0; k < depth; k++)
+      {
+        ssd_lane &L = h->lane[k];
+        if(L.dPlaneImg) { (void)hipFree(L.dPlaneImg); L.dPlaneImg = nullptr; }
+        if(L.dFallback) { (void)hipFree(L.dFallback); L.dFallback = nullptr; }
+      }
+      if(h->hFallback) { (void)hipHostFree(h->hFallback); h->hFallback = nullptr; }
+      h->singlePassMode = 0;
+    }
+    else
+    {
+      for(int k = 0; k < depth; k++)
+      {
+        HIP_TRY_H(hipMemset(h->lane[k].dPlaneImg, 0, planeBytes));
+        HIP_TRY_H(hipMemset(h->lane[k].dFallback, 0, sizeof(int) * (kFallbackList + static_cast<size_t>(h->F))));
+      }
+      std::memset(h->hFallback, 0, sizeof(int) * 2 * kMaxLanes);
+      planeBytesHeld = planeBytes;
+    }
   }
   const size_t resBytes = sizeof(ssd_frame_result) * h->F * h->nSlots;
   HIP_TRY_H(hipMalloc(&h->dResults, resBytes));
@@ -473,7 +500,7 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
   HIP_TRY_H(hipMemset(h->dResults, 0, resBytes));
   HIP_TRY_H(hipDeviceSynchronize());
 #undef HIP_TRY_H
-  h->bytes = static_cast<size_t>(depth) * (sizeof(FrameState) * h->F + stepBytes + groundBytes + planeBytes + maskBytes) + resBytes;
+  h->bytes = static_cast<size_t>(depth) * (sizeof(FrameState) * h->F + stepBytes + groundBytes + planeBytesHeld + maskBytes) + resBytes;
   *out = h;
   return SSD_OK;
 }
@@ -534,7 +561,7 @@ int ssd_set_single_pass(ssd_handle *h, int enable)
     return fail(SSD_E_ARG, "ssd_set_single_pass: null handle");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());            /* the planes of batches in flight are in use */
-  const size_t planeBytes = static_cast<size_t>(h->F) * kMaxPlanes * h->imgWords * 8;
+  const size_t planeBytes = static_cast<size_t>(plane_pool_size(h->F, h->P.nPoints)) * h->imgWords * 8;
   const size_t listBytes = sizeof(int) * (kFallbackList + static_cast<size_t>(h->F));
   if(!enable)
   {
@@ -566,8 +593,11 @@ int ssd_set_single_pass(ssd_handle *h, int enable)
         const hipError_t e = hipMalloc(&L.dPlaneImg, planeBytes);
         if(e != hipSuccess)
         {
+          /* asked for explicitly, so said loudly - but the handle stays whole: on two passes, with no plane of any workspace */
           L.dPlaneImg = nullptr;
-          return fail(e == hipErrorOutOfMemory ? SSD_E_NOMEM : SSD_E_HIP, std::string("ssd_set_single_pass: ") + hipGetErrorString(e));
+          (void)hipGetLastError();
+          (void)ssd_set_single_pass(h, 0);
+          return fail(e == hipErrorOutOfMemory ? SSD_E_NOMEM : SSD_E_HIP, std::string("ssd_set_single_pass: ") + hipGetErrorString(e) + " (the handle stays on two passes)");
         }
         HIP_TRY(hipMemset(L.dPlaneImg, 0, planeBytes));
         h->bytes += planeBytes;
@@ -706,10 +736,21 @@ int ssd_set_timing(ssd_handle *h, int enable)
       }
       ev.push_back(e);
     }
-    h->ev.swap(ev);
+    /* k_predict's events before anything is handed to the handle: a failure leaves it as it was (no half-made set that a later
+     * call would take for complete) */
+    hipEvent_t pred[SSD_TIMING_SLOTS] = {};
     for(int i = 0; i < SSD_TIMING_SLOTS; i++)
-      if(hipEventCreate(&h->evPredict[i]) != hipSuccess)
+      if(hipEventCreate(&pred[i]) != hipSuccess)
+      {
+        for(int k = 0; k < i; k++)
+          (void)hipEventDestroy(pred[k]);
+        for(hipEvent_t made : ev)
+          (void)hipEventDestroy(made);
         return fail(SSD_E_HIP, "hipEventCreate (predict)");
+      }
+    for(int i = 0; i < SSD_TIMING_SLOTS; i++)
+      h->evPredict[i] = pred[i];
+    h->ev.swap(ev);
   }
   h->timing = enable != 0;
   h->timedFrom = h->enqueueCount;
@@ -851,6 +892,14 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
     else
       h->singlePassBackoff--;                            /* see ssd_fetch_back */
   }
+  /* the optional device buffers the kernels dereference without a test of their own: a handle that lacks one
+   * fails here, loudly, instead of faulting on the device at a null address */
+  if(planeImg && !L.dFallback)
+    return fail(SSD_E_HIP, "ssd_enqueue: the single pass's planes without their work list (internal)");
+  if(depthInput && (!depthSrc.xmap || !depthSrc.ymap))
+    return fail(SSD_E_HIP, "ssd_enqueue_depth: the deprojection maps are missing (ssd_set_intrinsics did not complete)");
+  if(!L.dState || !L.dStepImg || !L.dGroundImg || !L.dTileMasks)
+    return fail(SSD_E_HIP, "ssd_enqueue: the handle's workspace is incomplete (internal)");
   h->lastSinglePass = planeImg != nullptr;
   h->predictTimed[h->enqueueCount % SSD_TIMING_SLOTS] = planeImg != nullptr;
   const bool timing = h->timing && !h->ev.empty();
@@ -870,7 +919,7 @@ static int enqueue_impl(ssd_handle *h, const void *d_xyz, size_t frame_stride_by
     {
       /* k_predict in front of the seven stages, timed by itself (ssd_get_predict_time_back) */
       if(marks) (void)hipEventRecord(h->evPredict[timingSlot], cs);
-      launch_predict(xyz, strideFloats, P, L.dState, nframes, depth, L.dFallback, h->singlePassSabotage, cs);
+      launch_predict(xyz, strideFloats, P, L.dState, nframes, depth, L.dFallback, h->planePool, h->singlePassSabotage, cs);
     }
     mk();
     if(stages & SSD_STAGE_HIST)
@@ -1432,7 +1481,8 @@ std::vector<int> parse_cpu_list(const std::string &list)
 } // namespace
 } // extern "C++"
 
-int ssd_device_info_get(int device, ssd_device_info *out)
+/* the device's report, and (full != nullptr) its local CPU list as sysfs spells it - the report's field holds 255 characters of it */
+static int device_info_impl(int device, ssd_device_info *out, std::string *full)
 {
   if(!out)
     return fail(SSD_E_ARG, "ssd_device_info_get: null");
@@ -1468,16 +1518,24 @@ int ssd_device_info_get(int device, ssd_device_info *out)
   const std::string cpus = sysfs_line(dir + "local_cpulist");
   std::snprintf(out->cpu_list, sizeof(out->cpu_list), "%s", cpus.c_str());
   out->n_local_cpus = static_cast<int32_t>(parse_cpu_list(cpus).size());
+  if(full)
+    *full = cpus;
   return SSD_OK;
+}
+
+int ssd_device_info_get(int device, ssd_device_info *out)
+{
+  return device_info_impl(device, out, nullptr);
 }
 
 int ssd_bind_thread_to_device(int device)
 {
   ssd_device_info info;
-  const int rc = ssd_device_info_get(device, &info);
+  std::string list;               /* the whole sysfs line: the report's copy may end in the middle of a number ("128-143" cut to "12") */
+  const int rc = device_info_impl(device, &info, &list);
   if(rc != SSD_OK)
     return rc;
-  const std::vector<int> cpus = parse_cpu_list(info.cpu_list);
+  const std::vector<int> cpus = parse_cpu_list(list);
   if(cpus.empty())
     return 0;
   cpu_set_t *set = CPU_ALLOC(4096);

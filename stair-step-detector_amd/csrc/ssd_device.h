@@ -5,7 +5,7 @@
  *   FrameState  state[F]            per-frame histogram, plateau table, quad tests, accumulators, result
  *   uint32_t    step_img[F][S][H][W32]   raw top-down bit images of the step plateaus (1 bit / pixel)
  *   uint32_t    ground_img[F][H][W32]    raw bit image of the ground points inside the ground quadrilateral
- *   uint32_t    plane_img[F][kMaxPlanes][H][W32]   single-pass batches only: per HEIGHT BIN images of the bins k_predict expects
+ *   uint32_t    plane_img[plane_pool_size(F, W H)][H][W32]   single-pass batches only: per HEIGHT BIN images of the bins k_predict expects
  *                                   step plateaus in, rastered by k_hist itself; k_outline merges a plateau's (two) planes
  *                                   into its step image (section "single pass" of DESIGN.md)
  *   DebugFrame  debug[F]            only when debug capture is on
@@ -35,8 +35,22 @@ constexpr int kMaxPlanes = SSD_MAX_PLANES;
 #define SSD_SPEC_SAMPLE 16
 #endif
 constexpr int kSpecSample = SSD_SPEC_SAMPLE;
-/* the batch's list for k_raster (single pass): [0] = frames listed, [1] = frames without step plateaus, the frame indices from [kFallbackList] */
-constexpr int kFallbackList = 2;
+/* the batch's list for k_raster (single pass): [0] = frames listed, [1] = frames without step plateaus, [2] = planes drawn from the
+ * batch's pool so far (k_predict adds, k_peaks of the same batch leaves it zero), the frame indices from [kFallbackList] */
+constexpr int kFallbackList = 3;
+/* Planes come from a pool per workspace (round 5): a frame needs 6 (XGA bench scenes) to 9 (FHD stress) of the kMaxPlanes it may
+ * have - 15 at VGA, where the sample is a sixth of XGA's and more peaks have neighbours too alike to call (three planes each) -,
+ * so the pool holds kPoolPlanesPerFrame planes per frame of the largest batch (kPoolPlanesPerSmallFrame below
+ * kPoolSmallFramePoints points, where a plane is small), + kPoolPlanesExtra, and never fewer than what a few frames could ask
+ * for in full; k_predict draws a frame's planes with one atomic add, and a frame the pool cannot serve gets none - k_raster
+ * does it, as any frame the predictor does not cover. */
+constexpr int kPoolPlanesPerFrame = SSD_POOL_PLANES_PER_FRAME, kPoolPlanesPerSmallFrame = 16, kPoolSmallFramePoints = 600000, kPoolPlanesExtra = 2 * kMaxPlanes;
+__host__ __device__ constexpr long long plane_pool_size(long long frames, long long pointsPerFrame)
+{
+  const long long per = pointsPerFrame < kPoolSmallFramePoints ? kPoolPlanesPerSmallFrame : kPoolPlanesPerFrame;
+  const long long byShare = frames * per + kPoolPlanesExtra, few = (frames < 8 ? frames : 8) * kMaxPlanes;
+  return byShare > few ? byShare : few;
+}
 constexpr int kMaxGroundStrips = 168;              /* pixel strips of the ground image the bottom scan reads: one per 50 columns (+ 2), width <= 8192 */
 
 /* the four horizontal edges of a plateau outline, in this order everywhere (segmentation.cpp:585-589) */
@@ -219,6 +233,7 @@ struct FrameState
   unsigned char specPlane[kMaxBins];
   unsigned int predSample[kMaxBins];   /* the sample histogram the table was made of (kept for the tests: ssd_predict.h) */
   int nPlanes;
+  int planeBase;                   /* the frame's first plane in the workspace's pool (k_predict; meaningless while nPlanes == 0) */
   int specOk;                      /* every step plateau of the frame covered */
   unsigned int slotCovered;        /* bit s: step image s is made of planes (k_peaks); the others are k_raster's */
   int planeYMin[kMaxPlanes], planeYMax[kMaxPlanes], planeXMin[kMaxPlanes], planeXMax[kMaxPlanes];

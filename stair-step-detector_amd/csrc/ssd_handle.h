@@ -94,6 +94,7 @@ struct ssd_handle
    * kSinglePassMinPoints points, vertex input, geometry), 0 = never, 1 = whenever the geometry allows; sabotage: k_predict's (test
    * hooks set both) */
   int singlePassMode = -1, singlePassSabotage = 0;
+  int planePool = 0;               /* planes k_predict may hand out per batch (plane_pool_size(F), what each workspace holds; a test hook lowers it) */
   bool lastSinglePass = false;    /* the last enqueue ran it */
   int *hFallback = nullptr;       /* pinned, two per result slot: frames of that batch k_raster had to do, frames without step plateaus (copied with the results) */
   int resultsFallback[kMaxLanes] = {};      /* -1: that slot's batch ran two passes; 0: count on its way; 1: seen by ssd_fetch_back */

@@ -35,6 +35,27 @@ namespace ssd
 
 #include "ssd_phase.h"      /* tools builds: clocks at the marks below; product build: empty macros */
 
+/* Bounds-checked tools build (-DSSD_CHECKED, tools/checked.sh; GPU sanitizers are not available on this pool): the index of every
+ * store or atomic whose address comes from a point, a pixel, a window or a list is compared with the extent of what it writes
+ * into FIRST; a violation is reported from the device (one line, "SSD_CHECK site ...") and the access is dropped.  In the
+ * product build the macro is the constant `true`. */
+#ifdef SSD_CHECKED
+__device__ __noinline__ void ssd_chk_report(int site, unsigned long long idx, unsigned long long limit)
+{
+  printf("SSD_CHECK site %d index %llu limit %llu block (%u, %u) thread %u\n", site, idx, limit, blockIdx.x, blockIdx.y, threadIdx.x);
+}
+__device__ __forceinline__ bool ssd_chk(int site, unsigned long long idx, unsigned long long limit)
+{
+  if(idx < limit)
+    return true;
+  ssd_chk_report(site, idx, limit);
+  return false;
+}
+#define SSD_CHK(site, idx, limit) ssd_chk((site), static_cast<unsigned long long>(idx), static_cast<unsigned long long>(limit))
+#else
+#define SSD_CHK(site, idx, limit) (true)
+#endif
+
 /* ========================================================================= */
 /* shared per-point arithmetic                                                */
 
@@ -404,6 +425,7 @@ struct ImageBox { int yMin, yMax, xMin, xMax; };
 struct WaveWindow
 {
   int slot = -1, row0 = 0, col0 = 0;     /* wave-uniform */
+  unsigned int limitWords = 0xffffffffu; /* 64-bit words of the frame's images behind `images` (SSD_CHECKED builds compare) */
 };
 
 /* Bits that miss the window go straight to memory; their bounding box is kept per WAVE in LDS (wm[2..5] = row min /
@@ -464,7 +486,8 @@ __device__ __forceinline__ void wavewin_flush(unsigned long long *ww, const Wave
     if(v)
     {
       const int y = w.row0 + (i >> winShift), x = w.col0 + (i & ((1 << winShift) - 1));
-      atomicOr(img + static_cast<size_t>(y) * W64 + x, v);
+      if(SSD_CHK(1, static_cast<size_t>(w.slot) * imgWords + static_cast<size_t>(y) * W64 + x, w.limitWords) && SSD_CHK(2, x, W64))
+        atomicOr(img + static_cast<size_t>(y) * W64 + x, v);
       ww[i] = 0ull;
       y0 = min(y0, y); y1 = max(y1, y);
       x0 = min(x0, x); x1 = max(x1, x);
@@ -553,11 +576,15 @@ __device__ __forceinline__ void wavewin_emit(unsigned long long *ww, unsigned in
     const unsigned int k = key[j], d = k - base;
     const unsigned int bit = 1u << (k & 31u);
     if(window_hit(d, winShift))
-      atomicOr(&ww32[((d >> 13) << (winShift + 1)) + ((d & 0x1fffu) >> 5)], bit);
+    {
+      if(SSD_CHK(3, ((d >> 13) << (winShift + 1)) + ((d & 0x1fffu) >> 5), 2 * kWinWords))
+        atomicOr(&ww32[((d >> 13) << (winShift + 1)) + ((d & 0x1fffu) >> 5)], bit);
+    }
     else if(k != kNoPixel)
     {
       const unsigned int slot = k >> 26, iy = (k >> 13) & 0x1fffu, ix = k & 0x1fffu, xw = ix >> 6;
-      atomicOr(reinterpret_cast<unsigned int *>(images + (slot * imgWords + iy * static_cast<unsigned int>(W64) + xw)) + ((ix >> 5) & 1u), bit);
+      if(SSD_CHK(4, static_cast<unsigned long long>(slot) * imgWords + iy * static_cast<unsigned int>(W64) + xw, w.limitWords) && SSD_CHK(5, xw, W64))
+        atomicOr(reinterpret_cast<unsigned int *>(images + (slot * imgWords + iy * static_cast<unsigned int>(W64) + xw)) + ((ix >> 5) & 1u), bit);
       int *b = reinterpret_cast<int *>(wm);
       atomicMin(&b[2], static_cast<int>(iy)); atomicMax(&b[3], static_cast<int>(iy));
       atomicMin(&b[4], static_cast<int>(xw)); atomicMax(&b[5], static_cast<int>(xw));
@@ -652,7 +679,8 @@ __device__ __forceinline__ void specwin_flush(unsigned long long *ww, const Spec
       if(v)
       {
         const int y = w.row0 + (i >> 3), x = w.col0 + (i & 7);
-        atomicOr(img + static_cast<size_t>(y) * W64 + x, v);
+        if(SSD_CHK(6, static_cast<size_t>(w.plane0 + pl) * imgWords + static_cast<size_t>(y) * W64 + x, static_cast<size_t>(kMaxPlanes) * imgWords) && SSD_CHK(7, x, W64))
+          atomicOr(img + static_cast<size_t>(y) * W64 + x, v);
         ww[pl * (kSpecWinRows * kSpecWinCols) + i] = 0ull;
         seen |= (1ull << (i >> 3)) | (0x100000000ull << (i & 7));
       }
@@ -720,11 +748,15 @@ __device__ __forceinline__ void specwin_emit(unsigned long long *ww, SpecMiss &m
     const unsigned int k = key[j], d = k - base;
     const unsigned int bit = 1u << (k & 31u);
     if(specwin_hit(d))
-      atomicOr(&ww32[((d >> 26) << (kSpecRowBits + 4)) | (((d >> 13) & (kSpecWinRows - 1u)) << 4) | ((d & 0x1fffu) >> 5)], bit);     /* (plane, row, half word) */
+    {
+      if(SSD_CHK(8, ((d >> 26) << (kSpecRowBits + 4)) | (((d >> 13) & (kSpecWinRows - 1u)) << 4) | ((d & 0x1fffu) >> 5), 2 * kSpecWinWords))
+        atomicOr(&ww32[((d >> 26) << (kSpecRowBits + 4)) | (((d >> 13) & (kSpecWinRows - 1u)) << 4) | ((d & 0x1fffu) >> 5)], bit);     /* (plane, row, half word) */
+    }
     else if(k != kNoPixel)
     {
       const unsigned int slot = k >> 26, iy = (k >> 13) & 0x1fffu, ix = k & 0x1fffu, xw = ix >> 6;
-      atomicOr(reinterpret_cast<unsigned int *>(planes + (slot * imgWords + iy * static_cast<unsigned int>(W64) + xw)) + ((ix >> 5) & 1u), bit);
+      if(SSD_CHK(9, static_cast<unsigned long long>(slot) * imgWords + iy * static_cast<unsigned int>(W64) + xw, static_cast<unsigned long long>(kMaxPlanes) * imgWords) && SSD_CHK(10, xw, W64))
+        atomicOr(reinterpret_cast<unsigned int *>(planes + (slot * imgWords + iy * static_cast<unsigned int>(W64) + xw)) + ((ix >> 5) & 1u), bit);
       miss.y0 = min(miss.y0, static_cast<int>(iy)); miss.y1 = max(miss.y1, static_cast<int>(iy));
       miss.x0 = min(miss.x0, static_cast<int>(xw)); miss.x1 = max(miss.x1, static_cast<int>(xw));
       miss.planes |= 1u << slot;
@@ -870,7 +902,7 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
   unsigned long long *frameImg = nullptr;
   if constexpr(SPEC)
   {
-    frameImg = planeImg + static_cast<size_t>(frame) * kMaxPlanes * imgWords;
+    frameImg = planeImg + static_cast<size_t>(st[frame].planeBase) * imgWords;          /* the frame's planes in the pool (k_predict) */
     const unsigned char planeMine = tid < kMaxBins ? st[frame].specPlane[tid] : static_cast<unsigned char>(0xff);
     if(tid < kMaxBins)
       SL.plane[tid] = planeMine;
@@ -948,12 +980,13 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
       if(inz & inxy)
       {
         const unsigned int b = static_cast<unsigned int>(height_bin(P, wz));     /* in [0, nBins) for a point in range */
-        atomicAdd(mine + b * kHistCopies, 1u);                          /* ++hist[bin], pointcloud.cpp:199-202 */
+        if(SSD_CHK(11, b, P.nBins))
+          atomicAdd(mine + b * kHistCopies, 1u);                          /* ++hist[bin], pointcloud.cpp:199-202 */
         groups |= 1u << (b / static_cast<unsigned int>(kBinsPerGroup));
         x0 = min_f32(x0, d.x); x1 = max_f32(x1, d.x);
         y0 = min_f32(y0, d.y); y1 = max_f32(y1, d.y);
         if constexpr(SPEC)
-          plane = SL.plane[b];
+          plane = SSD_CHK(12, b, kMaxBins) ? SL.plane[b] : 0xff;
       }
       if constexpr(SPEC)
       {
@@ -977,13 +1010,13 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
             const bool inside = (static_cast<unsigned int>(ix) < static_cast<unsigned int>(X.W)) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(X.H));
             if(plane != curT)
             {
-              if(curT >= 0)
+              if(curT >= 0 && SSD_CHK(13, curT, kMaxPlanes))
                 atomicAdd(&SL.ltot[curT][lane & 7], accT);
               curT = plane;
               accT = 0;
             }
             accT += static_cast<unsigned long long>(z_plus_magic_bits(wz));      /* the bits of z + 6144; k_peaks takes the constant's share off (count x kMagicBits) */
-            if(!inside)
+            if(!inside && SSD_CHK(14, plane, kMaxPlanes))
               atomicAdd(&SL.oob[plane], 1u);                   /* quirk Q5, rare */
             key = inside ? pixel_key(plane, iy, ix) : kNoPixel;
           }
@@ -999,7 +1032,7 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
         specwin_emit(SL.wins[tid >> 6], missed, win, frameImg, imgWords, X.W64, SL.boxes, keys, lane);
     }
     row_reduce_cell(groups, x0, x1, y0, y1);
-    if((lane & 15) == 0)                                         /* cell = 64 consecutive points = lanes 16q .. 16q+15 */
+    if((lane & 15) == 0 && SSD_CHK(15, cellAt, kMaxCellsPerBlock))    /* cell = 64 consecutive points = lanes 16q .. 16q+15 */
       lInfo[cellAt] = make_uint2(groups, cell_box_from_d(Q, x0, x1, y0, y1));
   };
   if constexpr(STRIPS)
@@ -1137,7 +1170,7 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
   {
     specwin_flush(SL.wins[tid >> 6], win, frameImg, imgWords, X.W64, SL.boxes, lane);
     specmiss_flush(missed, SL.boxes, lane);
-    if(curT >= 0)
+    if(curT >= 0 && SSD_CHK(18, curT, kMaxPlanes))
       atomicAdd(&SL.ltot[curT][lane & 7], accT);
   }
   if(lane == 0 && nz)
@@ -1180,7 +1213,8 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
     uint2 *dst = tileMasks + static_cast<size_t>(frame) * tileMaskStride + static_cast<size_t>(begin / kCell);
     const int n = nStore >= 0 ? nStore : it * kCellsPerTile;
     for(int i = tid; i < n; i += kThreads)
-      dst[i] = lInfo[i];
+      if(SSD_CHK(16, static_cast<size_t>(begin / kCell) + i, tileMaskStride) && SSD_CHK(17, i, kMaxCellsPerBlock))
+        dst[i] = lInfo[i];
   }
 }
 
@@ -1219,7 +1253,7 @@ __global__ __launch_bounds__(kThreads, SSD_K1S_WAVES) void k_hist_planes(const f
  * and leaves the accumulators zero.  sabotage (tests): 1 = planes three bins above the right ones, 2 = no planes. */
 template<int SRC>
 __global__ __launch_bounds__(kThreads) void k_predict(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
-                                                      FrameState *__restrict__ st, DepthSrc D, int minHeight, int sabotage, int *__restrict__ fallback)
+                                                      FrameState *__restrict__ st, DepthSrc D, int minHeight, int sabotage, int *__restrict__ fallback, int poolPlanes)
 {
   __shared__ unsigned int sh[kMaxBins + 2];
   __shared__ unsigned int shc[kMaxBins * kHistCopies];        /* [bin][copy], as K1's: the lanes of a wave mostly vote for ONE bin */
@@ -1276,6 +1310,14 @@ __global__ __launch_bounds__(kThreads) void k_predict(const float *__restrict__ 
     }
   }
   __syncthreads();
+  /* (Relaxed atomics throughout: the hand-over rests on returning device-scope atomics being performed at the memory side of
+   * THIS part - gfx950, one L2 per XCD in front of the fabric's atomics -, not on the HIP memory model.  The build is pinned
+   * to that part below, and the kernel's table is held against ssd_predict.h on every frame of four batches in the default
+   * GPU tier: tests/test_gpu_single_pass.py::test_the_kernels_table_is_the_host_statements.  A table that differed would
+   * cost the frame its planes - k_peaks checks them and k_raster steps in -, never a result.) */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_predict's hand-over between blocks is written for gfx950 (see the comment above)"
+#endif
   if(tid == 0)
     sLast = atomicAdd(&fs.predDone, 1u) == static_cast<unsigned int>(nParts - 1) ? 1 : 0;
   __syncthreads();
@@ -1358,7 +1400,23 @@ __global__ __launch_bounds__(kThreads) void k_predict(const float *__restrict__ 
   }
   __syncthreads();
   const int total = __popcll(sStart[0]) + __popcll(sStart[1]);
-  const bool fits = total <= kMaxPlanes;
+  /* the frame's planes out of the workspace's pool: one returning add on the batch's counter (fallback[2]; k_peaks of this batch
+   * leaves it zero again).  A frame the pool cannot serve - more candidates per frame than kPoolPlanesPerFrame over a whole
+   * batch - gets no planes: k_peaks will find its plateaus uncovered and k_raster does it. */
+  __shared__ int sBase;
+  if(tid == 0)
+  {
+    int base = -1;
+    if(total > 0 && total <= kMaxPlanes)
+    {
+      base = atomicAdd(&fallback[2], total);
+      if(base + total > poolPlanes)
+        base = -1;
+    }
+    sBase = base;
+  }
+  __syncthreads();
+  const bool fits = sBase >= 0;
   if(tid < kMaxBins)
   {
     /* plane = starts at or below this bin, minus one */
@@ -1377,6 +1435,7 @@ __global__ __launch_bounds__(kThreads) void k_predict(const float *__restrict__ 
   if(tid == 0)
   {
     fs.nPlanes = fits ? total : 0;
+    fs.planeBase = fits ? sBase : 0;
     fs.predDone = 0u;
     if(frame == 0)
     {
@@ -1649,7 +1708,13 @@ __global__ __launch_bounds__(64) void k_peaks(Params P, FrameState *__restrict__
   if(lane == 0)
   {
     if(spec && !specOk && nImg > 0)
-      fallback[kFallbackList + atomicAdd(&fallback[0], 1)] = frame;          /* k_raster's work list (k_predict zeroed the count) */
+    {
+      const int at = atomicAdd(&fallback[0], 1);
+      if(SSD_CHK(25, at, nframes))
+        fallback[kFallbackList + at] = frame;          /* k_raster's work list (k_predict zeroed the count) */
+    }
+    if(spec && frame == 0)
+      fallback[2] = 0;                                                       /* the plane pool's counter: every k_predict block of this batch is long done */
     if(spec && nImg == 0)
       atomicAdd(&fallback[1], 1);                                            /* frames WITHOUT a step plateau (the rare kind where stairs are in sight: a thousand adds to one address cost k_peaks 10 us): what the single pass cannot gain on, ssd_fetch_back */
     fs.specOk = specOk ? 1 : 0;
@@ -1771,6 +1836,7 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
   unsigned long long *ww = wins[tid >> 6];
   unsigned int *wm = wmiss[tid >> 6];
   WaveWindow win;
+  win.limitWords = static_cast<unsigned int>(X.maxStepImages) * imgWords;
   unsigned int oob = 0;
   /* The z sum of EVERY point of each step plateau, in and out of its outline (the count is the histogram's): k_inquad
    * then only has to visit the cells that can hold points OUTSIDE the quadrilateral and take those off again.  A lane
@@ -1811,7 +1877,8 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
       key[j] = kNoPixel;
       double wx, wy, wz;
       const bool ok = world_point_flat(P, v[j], wx, wy, wz);
-      const int slot = lut[ok ? height_bin(P, wz) : 0];
+      const int bin = ok ? height_bin(P, wz) : 0;
+      const int slot = SSD_CHK(30, bin, kMaxBins) ? lut[bin] : 0xff;
       if(!(ok & (slot != 0xff)))
         continue;
       int ix, iy;
@@ -1819,7 +1886,7 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
       if(slot != curT)
       {
         flushT();
-        curT = slot;
+        curT = SSD_CHK(31, slot, kMaxStepImages) ? slot : -1;
         accT = 0;
       }
       accT += static_cast<unsigned long long>(z_to_fixed(wz));
@@ -1867,17 +1934,21 @@ __device__ __forceinline__ void raster_block(RasterLds &L, const float *__restri
   ph.finish();
 }
 
-/* fallback != nullptr (single pass): the grid's x blocks share the frames k_peaks listed there (count, then frame indices) - the
- * frames whose step plateaus the planes did not cover; none, as a rule, and then every block leaves after one cached load */
-template<int SRC>
-__global__ __launch_bounds__(kThreads, SSD_K2_WAVES) void k_raster(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
+/* LIST (single pass): the grid's x blocks share the frames k_peaks listed in `fallback` (count, then frame indices) - the
+ * frames whose step plateaus the planes did not cover; none, as a rule, and then every block leaves after one cached load.
+ * A template flag, not a run-time test: with both forms in one kernel the two-pass instantiation - the one every depth-16,
+ * small, backed-off or partial call takes - paid for the list's loop with 13 - 17 vector registers in scratch (round 4).  The
+ * list's own instantiation runs a handful of frames per batch: built for five waves per SIMD, which leaves it the registers
+ * its loop wants (no scratch either). */
+template<int SRC, bool LIST>
+__global__ __launch_bounds__(kThreads, LIST ? 5 : SSD_K2_WAVES) void k_raster(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
                                                         PixelParams X, FrameState *__restrict__ st,
                                                         unsigned long long *__restrict__ stepImg,
                                                         const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D,
                                                         const int *__restrict__ fallback)
 {
   __shared__ RasterLds L;
-  if(fallback)
+  if constexpr(LIST)
   {
     const int n = fallback[0];
     for(int e = blockIdx.x; e < n; e += gridDim.x)
@@ -1885,9 +1956,9 @@ __global__ __launch_bounds__(kThreads, SSD_K2_WAVES) void k_raster(const float *
       raster_block<SRC>(L, xyz, strideFloats, P, X, st, stepImg, tileMasks, tileMaskStride, chunkPoints, D, fallback[kFallbackList + e], blockIdx.y);
       __syncthreads();
     }
-    return;
   }
-  raster_block<SRC>(L, xyz, strideFloats, P, X, st, stepImg, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
+  else
+    raster_block<SRC>(L, xyz, strideFloats, P, X, st, stepImg, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
 }
 
 /* ========================================================================= */
@@ -2036,12 +2107,13 @@ __global__ __launch_bounds__(T) void k_outline(Params P, FrameState *__restrict_
       const int y0 = fs.planeYMin[p], y1 = fs.planeYMax[p], c0 = fs.planeXMin[p], c1 = fs.planeXMax[p];
       if(y1 < y0)
         continue;
-      unsigned long long *pi = planeImg + (static_cast<size_t>(frame) * kMaxPlanes + p) * imgWords;
+      unsigned long long *pi = planeImg + (static_cast<size_t>(fs.planeBase) + p) * imgWords;
       const int bw = c1 - c0 + 1, n = bw * (y1 - y0 + 1);
       for(int t = tid; t < n; t += T)
       {
         const int y = y0 + t / bw, c = c0 + t % bw;
-        pi[static_cast<size_t>(y) * P.W64 + c] = 0ull;
+        if(SSD_CHK(20, static_cast<size_t>(y) * P.W64 + c, imgWords) && SSD_CHK(26, c, P.W64) && SSD_CHK(27, p, kMaxPlanes))
+          pi[static_cast<size_t>(y) * P.W64 + c] = 0ull;
       }
       __syncthreads();                               /* everybody has read the box */
       if(tid == 0)
@@ -2066,9 +2138,9 @@ __global__ __launch_bounds__(T) void k_outline(Params P, FrameState *__restrict_
   {
     const int pa = fs.imgPlane[slot][0], pb = fs.imgPlane[slot][1];
     if(pa != 0xff)
-      img = planeImg + (static_cast<size_t>(frame) * kMaxPlanes + pa) * imgWords;
+      img = planeImg + (static_cast<size_t>(fs.planeBase) + pa) * imgWords;
     if(pb != 0xff)
-      img2 = planeImg + (static_cast<size_t>(frame) * kMaxPlanes + pb) * imgWords;
+      img2 = planeImg + (static_cast<size_t>(fs.planeBase) + pb) * imgWords;
   }
   const BitImg im{ img, P.W, P.H, P.W64, img2 };
   SSD_PHASE(0, 0);
@@ -2566,6 +2638,8 @@ __global__ __launch_bounds__(T) void k_outline(Params P, FrameState *__restrict_
     {
       const int ry = idx / cw;
       const size_t o = static_cast<size_t>(cy0 + ry) * P.W64 + cc0 + (idx - ry * cw);
+      if(!SSD_CHK(21, o, imgWords))
+        continue;
       img[o] = 0ull;                                 /* unconditionally: a load first would make every word a round trip */
       if(img2)
         img2[o] = 0ull;
@@ -2932,6 +3006,7 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
   unsigned long long *ww = wins[FULL ? tid >> 6 : 0];
   unsigned int *wm = wmiss[FULL ? tid >> 6 : 0];
   WaveWindow win;
+  win.limitWords = imgWords;                   /* the ground image: one per frame */
   /* strips only (!FULL): the scan columns' offset, the first row of interest, the lane's rows written so far */
   const int stripX0 = ground_scan_x0(X.W), stripRow0 = ground_strip_row0(X.H);
   int gy0 = 0x7fffffff, gy1 = -1;
@@ -3057,10 +3132,11 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
              * function of the raw rows within two of it: a pixel more than two rows above a centre-column pixel already seen
              * in its strip cannot matter and stays unwritten (round 4: the blocks run from the bottom of the camera image up,
              * so after a frame's first blocks nearly nothing is written: 4.5 k -> a few hundred global atomics per frame). */
-            const int seen = L.stripMax[strip];
+            const int seen = SSD_CHK(24, strip, kMaxGroundStrips) ? L.stripMax[strip] : 0x7fffffff;
             if(iy >= seen - 2)
             {
-              atomicOr(gimg32 + (static_cast<unsigned int>(iy) * (2u * X.W64) + (static_cast<unsigned int>(ix) >> 5)), 1u << (ix & 31));
+              if(SSD_CHK(23, static_cast<unsigned int>(iy) * (2u * X.W64) + (static_cast<unsigned int>(ix) >> 5), 2u * static_cast<unsigned int>(X.H) * X.W64))
+                atomicOr(gimg32 + (static_cast<unsigned int>(iy) * (2u * X.W64) + (static_cast<unsigned int>(ix) >> 5)), 1u << (ix & 31));
               gy0 = min(gy0, iy);
               gy1 = max(gy1, iy);
               if(centre && iy > seen)
@@ -3527,7 +3603,8 @@ __global__ __launch_bounds__(T) void k_final(Params P, FrameState *__restrict__ 
       {
         const int ry = idx / cw;
         const size_t o = static_cast<size_t>(cy0 + ry) * P.W64 + cc0 + (idx - ry * cw);
-        img[o] = 0ull;                                 /* unconditionally: a load first would make every word a round trip */
+        if(SSD_CHK(22, o, static_cast<size_t>(P.H) * P.W64))
+          img[o] = 0ull;                                 /* unconditionally: a load first would make every word a round trip */
       }
     }
     else
@@ -3717,15 +3794,15 @@ static inline bool aligned16(const float *xyz, size_t strideFloats, int nPoints)
 }
 
 void launch_predict(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, int nframes, const DepthSrc *depth,
-                    int *fallback, int sabotage, hipStream_t s)
+                    int *fallback, int poolPlanes, int sabotage, hipStream_t s)
 {
   dim3 pgrid(nframes, kPredictParts);
   if(depth)
-    hipLaunchKernelGGL(k_predict<kSrcDepth16>, pgrid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, *depth, P.minHeight, sabotage, fallback);
+    hipLaunchKernelGGL(k_predict<kSrcDepth16>, pgrid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, *depth, P.minHeight, sabotage, fallback, poolPlanes);
   else if(aligned16(xyz, strideFloats, P.nPoints))
-    hipLaunchKernelGGL(k_predict<kSrcF3Aligned>, pgrid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, DepthSrc{}, P.minHeight, sabotage, fallback);
+    hipLaunchKernelGGL(k_predict<kSrcF3Aligned>, pgrid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, DepthSrc{}, P.minHeight, sabotage, fallback, poolPlanes);
   else
-    hipLaunchKernelGGL(k_predict<kSrcF3>, pgrid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, DepthSrc{}, P.minHeight, sabotage, fallback);
+    hipLaunchKernelGGL(k_predict<kSrcF3>, pgrid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, st, DepthSrc{}, P.minHeight, sabotage, fallback, poolPlanes);
 }
 void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, uint2 *tileMasks, size_t tileMaskStride,
                  int nframes, int chunkPoints, const DepthSrc *depth, unsigned long long *planeImg, hipStream_t s)
@@ -3770,12 +3847,21 @@ void launch_raster(const float *xyz, size_t strideFloats, const Params &P, Frame
                    const uint2 *tileMasks, size_t tileMaskStride, int nframes, int chunkPoints, const DepthSrc *depth, const int *fallback, hipStream_t s)
 {
   dim3 grid(fallback ? (nframes + 3) / 4 : nframes, chunks_for(P.nPoints, chunkPoints));
+  const DepthSrc D = depth ? *depth : DepthSrc{};
+#define SSD_LAUNCH_RASTER(SRC)                                                                                                                                           \
+  {                                                                                                                                                                      \
+    if(fallback)                                                                                                                                                         \
+      hipLaunchKernelGGL((k_raster<SRC, true>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints, D, fallback); \
+    else                                                                                                                                                                 \
+      hipLaunchKernelGGL((k_raster<SRC, false>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints, D, fallback); \
+  }
   if(depth)
-    hipLaunchKernelGGL(k_raster<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints, *depth, fallback);
+    SSD_LAUNCH_RASTER(kSrcDepth16)
   else if(aligned16(xyz, strideFloats, P.nPoints))
-    hipLaunchKernelGGL(k_raster<kSrcF3Aligned>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints, DepthSrc{}, fallback);
+    SSD_LAUNCH_RASTER(kSrcF3Aligned)
   else
-    hipLaunchKernelGGL(k_raster<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, stepImg, tileMasks, tileMaskStride, chunkPoints, DepthSrc{}, fallback);
+    SSD_LAUNCH_RASTER(kSrcF3)
+#undef SSD_LAUNCH_RASTER
 }
 void launch_outline(const Params &P, FrameState *st, unsigned long long *stepImg, unsigned long long *planeImg, int nframes, DebugFrame *dbg, unsigned long long *dbgImg, hipStream_t s)
 {

@@ -30,7 +30,7 @@ inline bool single_pass_geometry(int W, int H) { return W >= 64 && W <= 8192 && 
  * resets it, k_peaks appends, k_raster reads; sabotage: see k_predict), then launch_hist with planeImg != nullptr (K1 rastering the
  * candidate bins' planes), launch_peaks / launch_raster with the list, launch_outline with the planes. */
 void launch_predict(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, int nframes, const DepthSrc *depth,
-                    int *fallback, int sabotage, hipStream_t s);
+                    int *fallback, int poolPlanes, int sabotage, hipStream_t s);
 void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameState *st, uint2 *tileMasks, size_t tileMaskStride,
                  int nframes, int chunkPoints, const DepthSrc *depth, unsigned long long *planeImg, hipStream_t s);
 void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, int *fallback, hipStream_t s);

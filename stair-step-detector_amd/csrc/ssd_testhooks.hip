@@ -270,7 +270,8 @@ int ssd_test_single_pass(ssd_handle *h, int mode, int sabotage)
   {
     if(!single_pass_geometry(h->P.W, h->P.H))
       return fail(SSD_E_ARG, "ssd_test_single_pass: a tile of 1024 points is not a whole number of this geometry's camera rows");
-    const size_t planeBytes = static_cast<size_t>(h->F) * kMaxPlanes * h->imgWords * 8;
+    const size_t planeBytes = static_cast<size_t>(plane_pool_size(h->F, h->P.nPoints)) * h->imgWords * 8;
+    h->planePool = static_cast<int>(plane_pool_size(h->F, h->P.nPoints));
     for(int k = 0; k < h->depth; k++)
       if(!h->lane[k].dPlaneImg)
       {
@@ -291,6 +292,19 @@ int ssd_test_single_pass(ssd_handle *h, int mode, int sabotage)
   return SSD_OK;
 }
 
+int ssd_test_plane_pool(ssd_handle *h, int planes)
+{
+  if(!h)
+    return fail(SSD_E_ARG, "ssd_test_plane_pool: null handle");
+  const int size = static_cast<int>(plane_pool_size(h->F, h->P.nPoints));
+  if(planes > size)
+    return fail(SSD_E_ARG, "ssd_test_plane_pool: more planes than the pool holds");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  h->planePool = planes < 0 ? size : planes;
+  return size;
+}
+
 int ssd_test_single_pass_stats(ssd_handle *h, int frames, int scan_planes, long long counts[4])
 {
   if(!h || !counts || frames < 0 || frames > h->F)
@@ -303,7 +317,7 @@ int ssd_test_single_pass_stats(ssd_handle *h, int frames, int scan_planes, long 
     counts[3] = -1;
   else if(L.dPlaneImg)
   {
-    const size_t words = static_cast<size_t>(h->F) * kMaxPlanes * h->imgWords;
+    const size_t words = static_cast<size_t>(plane_pool_size(h->F, h->P.nPoints)) * h->imgWords;
     std::vector<unsigned long long> img(words);
     HIP_TRY(hipMemcpy(img.data(), L.dPlaneImg, words * 8, hipMemcpyDeviceToHost));
     for(const unsigned long long w : img)

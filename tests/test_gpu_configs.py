@@ -140,6 +140,36 @@ def test_bench_runs_two_ranks_on_this_gpu():
     assert "cpu_baseline" not in d                      # reported at N = 1 only
 
 
+def test_bench_launcher_with_four_ranks_on_this_gpu():
+    """The launcher end to end with more ranks than this box has GPUs: `bench.py --gpus 4 --frames 64`, every rank on device 0
+    (SSD_BENCH_DEVICE=0).  Four bindings to the device's socket, four disjoint shards of the global frame range, four shard
+    reports with their own oracle checks, `distinct_devices` 1 and the line's own `warning` that this is no 4-GPU measurement.
+    (Eight ranks on one card are more processes than this pool lets a job put on a GPU - six, the test runner included;
+    world size 8 itself runs on the CPU in tests/test_distributed_cpu.py.)"""
+    env = dict(os.environ, SSD_BENCH_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--frames", "64", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["scaling"] == "weak" and d["config"]["frames_per_gpu_per_step"] == 64
+    assert d["config"]["workload"].startswith("BASELINE configs[3]: 256-frame batch frame-sharded over 4 GPUs")
+    ranks = sorted(d["ranks"], key=lambda r: r["rank"])
+    assert [r["rank"] for r in ranks] == [0, 1, 2, 3] and [r["device"] for r in ranks] == [0, 0, 0, 0]
+    assert [r["frames"] for r in ranks] == [[0, 64], [64, 128], [128, 192], [192, 256]]
+    assert len(d["devices"]) == 4 and d["distinct_devices"] == 1
+    assert "not an 4-GPU measurement" in d["warning"] and "SSD_BENCH_DEVICE" in d["warning"]
+    for r in ranks:
+        assert r["where"]["pci_bus_id"] == ranks[0]["where"]["pci_bus_id"]
+        assert r["parity"]["frames_checked_against_oracle"] == 5
+        assert r["parity"]["max_abs_corner_err_m"] == 0.0 and r["parity"]["max_abs_height_err_m"] <= parity.TOL_HEIGHT
+        assert r["steps_found"] > 0
+    assert d["value"] == pytest.approx(4 * 64 * 2 / (d["ms_per_step"] * 2 * 1e-3), rel=1e-6)
+
+
 def test_bench_config4_two_ranks_at_their_full_share_on_this_gpu():
     """BASELINE configs[3] as far as one GPU can carry it: 2 of the 8 ranks, each with its full share of 2048 XGA frames
     (19.3 GB of frames + 3 x 3.6 GB of workspaces per rank, both on this one device via SSD_BENCH_DEVICE=0).  Frame ranges

@@ -278,7 +278,7 @@ def test_the_planes_memory_can_be_given_back(ssd, gpu_device):
     single = _run(det, buf, n)
     assert det.single_pass_stats(n)["ran"]
     det.set_single_pass(False)
-    plane_bytes = n * ssd.MAX_PLANES * H * (W // 64) * 8
+    plane_bytes = ssd.plane_pool_size(n, W * H) * H * (W // 64) * 8
     assert det.workspace_bytes == with_planes - plane_bytes
     assert _run(det, buf, n) == single and not det.single_pass_stats(n)["ran"]
     det.set_single_pass(True)
@@ -293,3 +293,88 @@ def test_the_planes_memory_can_be_given_back(ssd, gpu_device):
     small.set_single_pass(False)
     assert small.workspace_bytes == b
     small.close()
+
+
+def test_a_handle_whose_planes_do_not_fit_runs_two_passes(ssd, gpu_device):
+    """The planes are an optimisation: ssd_create on a device with room for the workspaces but not for the planes (here: the rest
+    of the card taken by other allocations) gives a handle that runs two passes - the same results - instead of failing with
+    SSD_E_NOMEM."""
+    W, H, n = 1024, 768, 128
+    sc, buf = _batch(ssd, gpu_device, W, H, n, 51000, 51)
+    trans = ssd.transformation_for_scene(sc[0])
+    cfg = ssd.default_config(W, H, max_frames_per_batch=n)
+    ref = ssd.Detector(cfg, trans, gpu_device)
+    plane_bytes = ssd.plane_pool_size(n, W * H) * H * (W // 64) * 8
+    rest = ref.workspace_bytes - plane_bytes                      # what a handle needs without its planes
+    want = _run(ref, buf, n)
+    assert ref.single_pass_stats(n)["ran"]
+    ref.close()
+    # the rest of the card taken, in pieces of 16 GB, 1 GB, 64 MB and 4 MB, each size until the device refuses
+    hogs = []
+    for piece in (16 << 30, 1 << 30, 64 << 20, 4 << 20):
+        if piece == 64 << 20:
+            hogs.pop().free()                  # a gigabyte back, to be taken again in small pieces
+        while len(hogs) < 900:
+            try:
+                hogs.append(ssd.DeviceBuffer(piece, gpu_device))
+            except ssd.SsdError:
+                break
+    assert len(hogs) < 900, "the device never refused an allocation"
+    # room for the workspaces and a quarter of the planes: the 4 MB pieces first (at most sixteen), then 64 MB ones
+    room = 0
+    while room < rest + plane_bytes // 4:
+        b = hogs.pop()
+        assert b.nbytes <= 64 << 20, "ran out of small pieces to make room with"
+        room += b.nbytes
+        b.free()
+    assert room + (4 << 20) < rest + plane_bytes
+
+    class _Hog:
+        def free(self):
+            for b in hogs:
+                b.free()
+    hog = _Hog()
+    try:
+        det = ssd.Detector(cfg, trans, gpu_device)                 # must not raise
+        assert det.workspace_bytes == rest
+        assert _run(det, buf, n) == want and not det.single_pass_stats(n)["ran"]
+        with pytest.raises(ssd.SsdError):                           # asked for explicitly while the memory is still not there: said loudly ..
+            det.set_single_pass(True)
+        assert det.workspace_bytes == rest                         # .. and the handle stays whole, on two passes
+        assert _run(det, buf, n) == want and not det.single_pass_stats(n)["ran"]
+        det.close()
+    finally:
+        hog.free()
+    buf.free()
+
+
+def test_frames_the_plane_pool_cannot_serve_come_out_through_k_raster(ssd, oracle, gpu_device):
+    """Planes are drawn from a pool per workspace (10 per frame of the largest batch, where a frame may ask for up to 24): a
+    frame the pool cannot serve gets none and is rastered by k_raster like any frame the predictor does not cover.  The pool
+    cut down to a third of what this batch draws, to nothing, and restored: results bit-equal each time, the planes zero
+    afterwards, fewer frames covered while the pool is short."""
+    W, H, n = 1024, 768, 96
+    sc, buf = _batch(ssd, gpu_device, W, H, n, 53000, 53)
+    cfg, trans = ssd.default_config(W, H, max_frames_per_batch=n), ssd.transformation_for_scene(sc[0])
+    det = ssd.Detector(cfg, trans, gpu_device)
+    want = _run(det, buf, n)
+    full = det.single_pass_stats(n)
+    assert full["ran"] and full["covered"] >= n * 9 // 10 and full["dirty_words"] == 0
+    size = det.plane_pool(-1)
+    assert size == ssd.plane_pool_size(n, W * H) and det.workspace_bytes <= 2.8e6 * n + 6e6
+    det.single_pass(1)                        # forced: a batch k_raster did most of would switch the next ones to two passes (ssd_fetch_back)
+    for planes in (full["planes"] // 3, 0):
+        det.plane_pool(planes)
+        assert _run(det, buf, n) == want
+        st = det.single_pass_stats(n)
+        assert st["ran"] and st["planes"] <= planes and st["covered"] < full["covered"] and st["dirty_words"] == 0
+    det.plane_pool(-1)
+    assert _run(det, buf, n) == want and det.single_pass_stats(n)["covered"] == full["covered"]
+    det.plane_pool(full["planes"] // 2)
+    det.enqueue(buf.ptr, n)
+    res = det.fetch_list(n)
+    rep = {}
+    assert parity.check_batch_against_oracle(ssd, oracle, cfg, trans.constants, buf, W * H * 12, res, W, H, report=rep) == n
+    assert rep.get("max_corner_err", 0.0) == 0.0
+    det.close()
+    buf.free()

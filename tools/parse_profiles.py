@@ -29,11 +29,28 @@ def per_kernel(path, counter):
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
+def load_stamp(src):
+    """the stamp the run wrote next to its outputs (tools/r05_final.sh: git revision of the build, sha256 of the libssd_hip.so the
+    passes loaded, checked on the GPU box against build/STAMP.json), or None for runs of earlier rounds"""
+    p = os.path.join(src, "stamp.json")
+    return json.load(open(p)) if os.path.exists(p) else None
+
+
+def dump(obj, path, stamp):
+    if stamp is not None:
+        obj = dict(obj)
+        obj["stamp"] = stamp
+    json.dump(obj, open(path, "w"), indent=1)
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
+    stamp = load_stamp(src)
+    if stamp is not None:
+        json.dump(stamp, open(os.path.join(dst, tag + "_stamp.json"), "w"), indent=1)       # for the csv summaries, which cannot carry it
     stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
@@ -49,21 +66,21 @@ def main():
         out["kernels"][k] = {"FETCH_SIZE_KiB_raw": f.get(k), "fetch_correction": corr,
                              "hbm_read_bytes": None if k not in f else f[k] * 1024 * corr,
                              "WRITE_SIZE_KiB_raw": w.get(k), "hbm_write_bytes": None if k not in w else w[k] * 1024}
-    json.dump(out, open(os.path.join(dst, tag + "_hbm_traffic.json"), "w"), indent=1)
+    dump(out, os.path.join(dst, tag + "_hbm_traffic.json"), stamp)
     for k, v in out["kernels"].items():
         if "k_hist" in k and v["hbm_read_bytes"]:
             total = v["hbm_read_bytes"] + (v["hbm_write_bytes"] or 0.0)
-            json.dump({"source": "profiles/%s_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % tag,
-                       "hbm_bytes_per_launch_at_1024x768x1024": total,
-                       "algorithmic_bytes_per_launch": 12.0 * 1024 * 768 * 1024,
-                       "ratio": total / (12.0 * 1024 * 768 * 1024)}, open(os.path.join(dst, "pmc_k_hist.json"), "w"), indent=1)
+            dump({"source": "profiles/%s_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % tag,
+                  "hbm_bytes_per_launch_at_1024x768x1024": total,
+                  "algorithmic_bytes_per_launch": 12.0 * 1024 * 768 * 1024,
+                  "ratio": total / (12.0 * 1024 * 768 * 1024)}, os.path.join(dst, "pmc_k_hist.json"), stamp)
     moved_r = sum((v["hbm_read_bytes"] or 0.0) for k, v in out["kernels"].items() if not any(n in k for n in NOT_PIPELINE))
     moved_w = sum((v["hbm_write_bytes"] or 0.0) for k, v in out["kernels"].items() if not any(n in k for n in NOT_PIPELINE))
     if moved_r:
-        json.dump({"source": "profiles/%s_hbm_traffic.json (all kernels of one pass over 1024 XGA frames; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % tag,
-                   "hbm_read_bytes": moved_r, "hbm_write_bytes": moved_w, "algorithmic_bytes": 12.0 * 1024 * 768 * 1024,
-                   "bytes_moved_over_algorithmic": (moved_r + moved_w) / (12.0 * 1024 * 768 * 1024)},
-                  open(os.path.join(dst, "pmc_pipeline.json"), "w"), indent=1)
+        dump({"source": "profiles/%s_hbm_traffic.json (all kernels of one pass over 1024 XGA frames; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % tag,
+              "hbm_read_bytes": moved_r, "hbm_write_bytes": moved_w, "algorithmic_bytes": 12.0 * 1024 * 768 * 1024,
+              "bytes_moved_over_algorithmic": (moved_r + moved_w) / (12.0 * 1024 * 768 * 1024)},
+             os.path.join(dst, "pmc_pipeline.json"), stamp)
     for name, to in (("bench.json", "_bench.json"), ("bench_fhd.json", "_bench_fhd_stress.json"), ("bench_depth16.json", "_bench_depth16.json"),
                      ("hostfed.json", "_hostfed.json"), ("latency.txt", "_latency.txt")):
         b = os.path.join(src, name)
@@ -95,7 +112,7 @@ def main():
             if "k_hist" in k and k in avg_ns:
                 e["algorithmic_frac_of_peak"] = alg / (avg_ns[k] * 1e-9) / 1e9 / 8000.0
             o["kernels"][k] = e
-        json.dump(o, open(os.path.join(dst, tag + "_hbm_traffic_fhd_stress.json"), "w"), indent=1)
+        dump(o, os.path.join(dst, tag + "_hbm_traffic_fhd_stress.json"), stamp)
     # instruction / issue counters of a tools/pmc.sh run (optional second argument: its tag)
     if len(sys.argv) > 2:
         agg = collections.defaultdict(dict)
@@ -110,9 +127,9 @@ def main():
                     agg[k][c] = round(sum(v) / len(v), 3)
         issue = {"note": "rocprofv3 --kernel-trace --pmc <set> -- python3 bench.py --steps 2 --warmup 1 --no-cpu (one pass per counter set, "
                          "tools/pmc.sh); per launch = 1024 XGA frames", "kernels": {k: dict(sorted(v.items())) for k, v in sorted(agg.items())}}
-        json.dump(issue, open(os.path.join(dst, tag + "_pmc_issue.json"), "w"), indent=1)
+        dump(issue, os.path.join(dst, tag + "_pmc_issue.json"), stamp)
         issue["source"] = "profiles/%s_pmc_issue.json" % tag
-        json.dump(issue, open(os.path.join(dst, "pmc_issue.json"), "w"), indent=1)      # what bench.py reads for `floors`
+        dump(issue, os.path.join(dst, "pmc_issue.json"), stamp)      # what bench.py reads for `floors`
     print(open(os.path.join(dst, tag + "_hbm_traffic.json")).read()[:1500])
 
 

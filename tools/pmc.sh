@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for set in "$@"; do
   name=$(echo $set | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $set -d $OUT/$name --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-hostfed --no-latency ${PMC_BENCH_ARGS} > $OUT/$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set -d $OUT/$name --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-hostfed --no-latency --no-secondary ${PMC_BENCH_ARGS} > $OUT/$name.log 2>&1
   python3 - "$OUT/$name" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/*/*counter_collection.csv")

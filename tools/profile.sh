@@ -10,11 +10,11 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --batches-in-flight 1 --no-cpu --no-hostfed --no-latency > $OUT/trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --batches-in-flight 1 --no-cpu --no-hostfed --no-latency > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --batches-in-flight 1 --no-cpu --no-hostfed --no-latency > $OUT/write.log 2>&1
-rocprofv3 --kernel-trace --stats -d $OUT/trace_fhd --output-format csv -- python3 $R/bench.py --workload fhd_stress --steps 5 --warmup 2 --batches-in-flight 1 --no-cpu --no-latency > $OUT/trace_fhd.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch_fhd --output-format csv -- python3 $R/bench.py --workload fhd_stress --steps 3 --warmup 1 --batches-in-flight 1 --no-cpu --no-latency > $OUT/fetch_fhd.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --batches-in-flight 1 --no-cpu --no-hostfed --no-latency --no-secondary > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --batches-in-flight 1 --no-cpu --no-hostfed --no-latency --no-secondary > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --batches-in-flight 1 --no-cpu --no-hostfed --no-latency --no-secondary > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace_fhd --output-format csv -- python3 $R/bench.py --workload fhd_stress --steps 5 --warmup 2 --batches-in-flight 1 --no-cpu --no-latency --no-secondary > $OUT/trace_fhd.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch_fhd --output-format csv -- python3 $R/bench.py --workload fhd_stress --steps 3 --warmup 1 --batches-in-flight 1 --no-cpu --no-latency --no-secondary > $OUT/fetch_fhd.log 2>&1
 cd $R
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 bench.py --workload fhd_stress --cpu-frames 48 > $OUT/bench_fhd.json 2> $OUT/bench_fhd.err
