@@ -78,9 +78,9 @@ struct PreXY
 {
   float c[4][2];                              /* (d.x, d.y) = c[0] * x + c[1] * y + c[2] * z + c[3], pairs (x row, y row): one packed FMA per input */
   float lo, hi;
-  float maxInput;
+  float maxInput;                             /* the bound behind lo / hi holds for inputs up to this magnitude ... */
   float boxLo, boxHi;                         /* the cell of a minimum is rn(d * 256 + boxLo), of a maximum rn(d * 256 + boxHi), saturated to 0 .. 255 */
-  float pad;
+  int checkInput;                             /* ... and K1 tests it per point (1) unless make_pre_xy() could show that a larger input cannot be called "inside" (0) */
 };
 
 struct PixelParams

@@ -962,8 +962,15 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
       f32x2 d = pre_xy(Q, p.x, p.y, p.z);
       const float M = absmax2(d.x, d.y);
       bool inxy = M < Q.lo;
-      const bool sure = (inxy | (M > Q.hi)) & (absmax3(p.x, p.y, p.z) <= Q.maxInput);
-      if(inz & !sure)
+      /* the band between lo and hi (a NaN reads "outside", and its point has failed the z test in doubles) and, unless
+       * make_pre_xy() showed that larger inputs cannot read "inside" (block-uniform: a scalar branch), inputs beyond maxInput */
+      bool unsure = (__float_as_uint(M) - __float_as_uint(Q.lo)) <= (__float_as_uint(Q.hi) - __float_as_uint(Q.lo));     /* lo <= M <= hi on the bits of non-negative floats: a cheap subtraction and one compare */
+      if(Q.checkInput)
+      {
+        asm volatile("" ::: "memory");         /* a branch on the scalar, not a select: the test is two vector instructions per point */
+        unsure = unsure | !(absmax3(p.x, p.y, p.z) <= Q.maxInput);
+      }
+      if(inz & unsure)
       {
         /* the band around the range's edges, inputs beyond maxInput, NaNs: the doubles decide (rare: one lane in thousands) */
         const K1ConstsLds c = k1_consts(L.kc);
