@@ -67,6 +67,11 @@ int ssd_test_single_pass_frame(ssd_handle *h, int frame, uint8_t *plane_of_bin, 
 int ssd_test_single_pass_sample(ssd_handle *h, int frame, uint32_t *sample);
 /* the predictor's table as csrc/ssd_predict.h states it (host; no GPU): sample[SSD_MAX_BINS] -> plane_of_bin[SSD_MAX_BINS], returns the planes */
 int ssd_test_predict_table_host(const uint32_t *sample, int n_bins, int min_height, int sabotage, uint8_t *plane_of_bin);
+/* The constants of K1's single-precision pre-filter of the x / y range test (csrc/ssd_prexy.h: make_pre_xy) for a measuring range and a
+ * calibration, on the host: out[0..7] = the four coefficient pairs (x row, y row), out[8] = lo, out[9] = hi, out[10] = the largest input
+ * the bound holds for, out[11] / out[12] = the boxes' two offsets, out[13] = 1 when K1 tests the input's magnitude per point, 0 when
+ * make_pre_xy showed that a larger input cannot read "inside".  tests/test_prexy.py checks the bound against double precision. */
+int ssd_test_prexy_host(const double range[6], const double a[9], const double b[3], float out[14]);
 /* tools hook (tools/k1place.py): places the first workspace's cell records `offset_bytes` (a multiple of 8, within the extra bytes a
  * preceding ssd_test_record_realloc_sized asked for) into their allocation; the records' content is undefined afterwards until the
  * next full enqueue */

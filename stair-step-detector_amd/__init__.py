@@ -157,7 +157,7 @@ SOURCE_EXPORTS = [
 # libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
 HOOK_EXPORTS = [
     "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_ground_image", "ssd_test_line_host", "ssd_test_intersect_host", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_best_line_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
-    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_test_single_pass", "ssd_test_plane_pool", "ssd_test_single_pass_stats", "ssd_test_single_pass_frame", "ssd_test_single_pass_sample", "ssd_test_predict_table_host", "ssd_test_record_offset", "ssd_test_record_realloc", "ssd_test_record_realloc_sized", "ssd_test_record_release", "ssd_testhooks_last_error",
+    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_test_single_pass", "ssd_test_plane_pool", "ssd_test_single_pass_stats", "ssd_test_single_pass_frame", "ssd_test_single_pass_sample", "ssd_test_predict_table_host", "ssd_test_prexy_host", "ssd_test_record_offset", "ssd_test_record_realloc", "ssd_test_record_realloc_sized", "ssd_test_record_release", "ssd_testhooks_last_error",
 ]
 SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
 HOOKS_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_testhooks.so")
@@ -282,6 +282,7 @@ def hooks_lib():
     L.ssd_test_single_pass_frame.argtypes = [vp, i32, vp, vp]
     L.ssd_test_single_pass_sample.argtypes = [vp, i32, vp]
     L.ssd_test_predict_table_host.argtypes = [vp, i32, i32, i32, vp]
+    L.ssd_test_prexy_host.argtypes = [vp, vp, vp, vp]
     L.ssd_test_record_offset.argtypes = [vp, C.c_size_t]
     L.ssd_test_record_realloc.argtypes = [vp]
     L.ssd_test_record_realloc.restype = C.c_ulonglong
@@ -854,6 +855,18 @@ def calibration_points(scene, marks=CALIBRATION_MARKS, world_offset=(0.0, 0.0, 0
 def transformation_for_scene(scene):
     world, cam = calibration_points(scene)
     return GeometricTransformation(world, cam)
+
+
+def prexy_host(x_min, x_max, y_min, y_max, z_min, z_max, a, b):
+    """test hook: the constants of K1's single-precision pre-filter (csrc/ssd_prexy.h) for a measuring range and a calibration:
+    dict(c = 4 x 2 float32 coefficients, lo, hi, max_input, box_lo, box_hi, check_input)"""
+    rng = (C.c_double * 6)(x_min, x_max, y_min, y_max, z_min, z_max)
+    aa = (C.c_double * 9)(*[float(v) for v in np.asarray(a, dtype=np.float64).reshape(9)])
+    bb = (C.c_double * 3)(*[float(v) for v in np.asarray(b, dtype=np.float64).reshape(3)])
+    out = (C.c_float * 14)()
+    _check(hooks_lib().ssd_test_prexy_host(rng, aa, bb, out), "hooks")
+    o = np.array(list(out), dtype=np.float32)
+    return dict(c=o[:8].reshape(4, 2), lo=o[8], hi=o[9], max_input=o[10], box_lo=o[11], box_hi=o[12], check_input=bool(o[13]))
 
 
 class PinnedArray:

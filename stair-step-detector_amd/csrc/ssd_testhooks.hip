@@ -6,6 +6,7 @@
 #include "ssd_handle.h"
 #include "ssd_launch.h"
 #include "ssd_predict.h"
+#include "ssd_prexy.h"
 #include "ssd_math.h"
 #include "ssd_quadtest.h"
 #include "ssd_closing.h"
@@ -364,6 +365,20 @@ int ssd_test_predict_table_host(const uint32_t *sample, int n_bins, int min_heig
   if(!sample || !plane_of_bin || n_bins < 2 || n_bins > kMaxBins || sabotage < 0 || sabotage > 2)
     return fail(SSD_E_ARG, "ssd_test_predict_table_host: bad argument");
   return predict_table(sample, n_bins, min_height, sabotage, plane_of_bin);
+}
+
+int ssd_test_prexy_host(const double range[6], const double a[9], const double b[3], float out[14])
+{
+  if(!range || !a || !b || !out)
+    return fail(SSD_E_ARG, "ssd_test_prexy_host: null");
+  PointParams P{};
+  for(int i = 0; i < 9; i++) P.a[i] = a[i];
+  for(int i = 0; i < 3; i++) P.b[i] = b[i];
+  P.xMin = range[0]; P.xMax = range[1]; P.yMin = range[2]; P.yMax = range[3]; P.zMin = range[4]; P.zMax = range[5];
+  const PreXY Q = make_pre_xy(P);
+  for(int i = 0; i < 4; i++) { out[2 * i] = Q.c[i][0]; out[2 * i + 1] = Q.c[i][1]; }
+  out[8] = Q.lo; out[9] = Q.hi; out[10] = Q.maxInput; out[11] = Q.boxLo; out[12] = Q.boxHi; out[13] = static_cast<float>(Q.checkInput);
+  return SSD_OK;
 }
 
 /* the kernels' line helpers (csrc/ssd_math.h: line_through_i / line_through_d = LineCoordinates(p, q), types.h:140-158; intersect60 =
