@@ -201,6 +201,31 @@ __device__ __forceinline__ void load_points(const float *__restrict__ base, int 
   }
 }
 
+/* The lane's four points of a tile that lies wholly inside the frame: no bounds, no branches, nothing between the loads and their
+ * first use.  Round 5: load_points() has two paths (this one, and point by point at the frame's end); where they join the compiler
+ * puts copies of the loaded registers INTO the fast path - an s_waitcnt vmcnt right behind the loads - and the "prefetch" of the
+ * next tile waited for its data before the current tile was touched (found in the ISA of the single pass's K1, which a build fed
+ * from the Infinity Cache had shown to be waiting for memory: 1.69 ms against 2.12 from HBM; tools/mkvariant.sh's SED_EXPR). */
+template<int SRC>
+__device__ __forceinline__ void load_points_full(const float *__restrict__ base, int idx0, F3 (&v)[kPts])
+{
+  if(SRC == kSrcDepth16)
+    return;                                     /* vertex input only: the depth stream has a loop of its own */
+  if(SRC == kSrcF3Aligned)
+  {
+    const float4 *q = reinterpret_cast<const float4 *>(base + 3 * static_cast<size_t>(idx0));
+    const float4 a = q[0], b = q[1], c = q[2];
+    v[0] = F3{ a.x, a.y, a.z };
+    v[1] = F3{ a.w, b.x, b.y };
+    v[2] = F3{ b.z, b.w, c.x };
+    v[3] = F3{ c.y, c.z, c.w };
+    return;
+  }
+#pragma unroll
+  for(int j = 0; j < kPts; j++)
+    v[j] = *reinterpret_cast<const F3 *>(base + 3 * static_cast<size_t>(idx0 + j));
+}
+
 /* The streaming kernels (K1, K2, K4) share one loop shape: a block owns a contiguous chunk of a frame and
  * walks it in tiles of 1024 points; the loads of the next tile are issued before the current tile is
  * processed (register double buffer), so that HBM requests stay in flight while the SIMDs do the fp64 work. */
@@ -1151,19 +1176,30 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
       /* one copy of the body: the next tile's loads go out before the current tile is processed, as in SSD_STREAM_LOOP, and
        * are moved into place after it (twelve moves per tile) */
       F3 va[kPts], vb[kPts];
-      load_points<SRC>(base, begin + kPts * tid, end, va, D);
-      for(int i0 = begin; i0 < end; i0 += kTile)
+      const int fullEnd = begin + (end - begin) / kTile * kTile;      /* the tiles wholly inside the chunk: all of them unless the frame ends in a part of one */
+      if(begin < fullEnd)
+        load_points_full<SRC>(base, begin + kPts * tid, va);
+      for(int i0 = begin; i0 < fullEnd; i0 += kTile)
       {
-        const bool more = i0 + kTile < end;
+        const bool more = i0 + kTile < fullEnd;
         if(more)
-          load_points<SRC>(base, i0 + kTile + kPts * tid, end, vb, D);
+          load_points_full<SRC>(base, i0 + kTile + kPts * tid, vb);
         tileInOrder(va);
         if(more)
         {
+          /* the loaded registers are first looked at HERE, behind the tile: without this the compiler builds the (x, y) register
+           * pairs of the next tile's points (v_pk_fma_f32 wants them aligned) right behind the loads - and waits for them there */
+          asm volatile("" : "+v"(vb[0].x), "+v"(vb[0].y), "+v"(vb[0].z), "+v"(vb[1].x), "+v"(vb[1].y), "+v"(vb[1].z),
+                            "+v"(vb[2].x), "+v"(vb[2].y), "+v"(vb[2].z), "+v"(vb[3].x), "+v"(vb[3].y), "+v"(vb[3].z));
 #pragma unroll
           for(int j = 0; j < kPts; j++)
             va[j] = vb[j];
         }
+      }
+      if(fullEnd < end)
+      {
+        load_points<SRC>(base, fullEnd + kPts * tid, end, va, D);
+        tileInOrder(va);
       }
     }
     else
