@@ -226,6 +226,41 @@ __device__ __forceinline__ void load_points_full(const float *__restrict__ base,
     v[j] = *reinterpret_cast<const F3 *>(base + 3 * static_cast<size_t>(idx0 + j));
 }
 
+/* The same without knowing that the tile is whole: the loads go to addresses clamped into [0, end) - no bounds, no branches, and so
+ * nothing that uses the data behind the loads - and zero_beyond(), called where the points are first used, blanks the points at or
+ * beyond `end` (z = 0: "no measurement", dropped by every consumer first).  end >= 4; vertex input only.  kSrcF3Aligned: idx0 and end
+ * are multiples of 4 (points_aligned()), so a lane's four points lie wholly inside or wholly beyond. */
+template<int SRC>
+__device__ __forceinline__ void load_points_clamped(const float *__restrict__ base, int idx0, int end, F3 (&v)[kPts])
+{
+  if(SRC == kSrcDepth16)
+    return;
+  if(SRC == kSrcF3Aligned)
+  {
+    load_points_full<SRC>(base, min(idx0, end - kPts), v);
+    return;
+  }
+#pragma unroll
+  for(int j = 0; j < kPts; j++)
+    v[j] = *reinterpret_cast<const F3 *>(base + 3 * static_cast<size_t>(min(idx0 + j, end - 1)));
+}
+__device__ __forceinline__ void zero_beyond(F3 (&v)[kPts], int idx0, int end)
+{
+#pragma unroll
+  for(int j = 0; j < kPts; j++)
+    if(idx0 + j >= end)
+      v[j] = F3{ 0.0f, 0.0f, 0.0f };
+}
+
+/* "The loaded registers are first looked at HERE": an empty asm that takes and returns the twelve registers of a lane's four points.
+ * Placed behind the tile the loads were issued in front of: without it the compiler builds the (x, y) register pairs of the next
+ * tile's points (v_pk_fma_f32 and the fp64 conversions want them aligned) right behind the loads - and waits for the data there. */
+__device__ __forceinline__ void first_use(F3 (&v)[kPts])
+{
+  asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[0].z), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[1].z),
+                    "+v"(v[2].x), "+v"(v[2].y), "+v"(v[2].z), "+v"(v[3].x), "+v"(v[3].y), "+v"(v[3].z));
+}
+
 /* The streaming kernels (K1, K2, K4) share one loop shape: a block owns a contiguous chunk of a frame and
  * walks it in tiles of 1024 points; the loads of the next tile are issued before the current tile is
  * processed (register double buffer), so that HBM requests stay in flight while the SIMDs do the fp64 work. */
@@ -234,17 +269,29 @@ __device__ __forceinline__ void load_points_full(const float *__restrict__ base,
 #define SSD_STREAM_LOOP(body)                                                                       \
   {                                                                                                 \
     F3 va[kPts], vb[kPts];                                                                          \
-    load_points<SRC>(base, begin + kPts * tid, end, va, D);                                        \
-    for(int i0 = begin; i0 < end; i0 += 2 * kTile)                                                  \
+    const int fullEnd = begin + (end - begin) / kTile * kTile;  /* tiles wholly inside the chunk */ \
+    if(begin < fullEnd)                                                                             \
+      load_points_full<SRC>(base, begin + kPts * tid, va);                                          \
+    for(int i0 = begin; i0 < fullEnd; i0 += 2 * kTile)                                              \
     {                                                                                               \
-      if(i0 + kTile < end)                                                                          \
-        load_points<SRC>(base, i0 + kTile + kPts * tid, end, vb, D);                               \
+      const bool more1 = i0 + kTile < fullEnd;                                                      \
+      if(more1)                                                                                     \
+        load_points_full<SRC>(base, i0 + kTile + kPts * tid, vb);                                   \
       body(va);                                                                                     \
-      if(i0 + kTile >= end)                                                                         \
+      if(!more1)                                                                                    \
         break;                                                                                      \
-      if(i0 + 2 * kTile < end)                                                                      \
-        load_points<SRC>(base, i0 + 2 * kTile + kPts * tid, end, va, D);                           \
+      first_use(vb);                                                                                \
+      const bool more2 = i0 + 2 * kTile < fullEnd;                                                  \
+      if(more2)                                                                                     \
+        load_points_full<SRC>(base, i0 + 2 * kTile + kPts * tid, va);                               \
       body(vb);                                                                                     \
+      if(more2)                                                                                     \
+        first_use(va);                                                                              \
+    }                                                                                               \
+    if(fullEnd < end)                                                                               \
+    {                                                                                               \
+      load_points<SRC>(base, fullEnd + kPts * tid, end, va, D);       /* the frame's last, partial tile */ \
+      body(va);                                                                                     \
     }                                                                                               \
   }
 
@@ -1099,20 +1146,33 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
     const int kEnd = (wave + 1) * nStrips / kWavesPerBlock;
     if(k < kEnd)
     {
+      /* loads by clamped addresses and the first look at them behind the strip before (first_use): the next strip's loads stay
+       * in flight while this one is worked on; only a frame's last strip can reach beyond `end` (block-uniform test) */
       F3 va[kPts], vb[kPts];
       int sa = SL.order[k], sb = 0;
-      load_points<SRC>(base, begin + (sa << 8) + kPts * lane, end, va, D);
+      const int lastStrip = SRC != kSrcDepth16 && ((end - begin) & 255) != 0 ? nStrips - 1 : -1;
+      auto issue = [&](const int strip, F3 (&v)[kPts])
+      {
+        if constexpr(SRC == kSrcDepth16)
+          load_points<SRC>(base, begin + (strip << 8) + kPts * lane, end, v, D);         /* deprojected where it is loaded */
+        else
+          load_points_clamped<SRC>(base, begin + (strip << 8) + kPts * lane, end, v);
+      };
+      issue(sa, va);
       while(true)
       {
         const bool more = k + 1 < kEnd;
         if(more)
         {
           sb = SL.order[k + 1];
-          load_points<SRC>(base, begin + (sb << 8) + kPts * lane, end, vb, D);
+          issue(sb, vb);
         }
+        if(sa == lastStrip)
+          zero_beyond(va, begin + (sa << 8) + kPts * lane, end);
         tileBody(va, sa * 4 + (lane >> 4));
         if(!more)
           break;
+        first_use(vb);
         k++;
         sa = sb;
 #pragma unroll
@@ -1175,8 +1235,33 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
     {
       /* one copy of the body: the next tile's loads go out before the current tile is processed, as in SSD_STREAM_LOOP, and
        * are moved into place after it (twelve moves per tile) */
-      F3 va[kPts], vb[kPts];
       const int fullEnd = begin + (end - begin) / kTile * kTile;      /* the tiles wholly inside the chunk: all of them unless the frame ends in a part of one */
+#ifdef SSD_K1_THREE_BODIES
+      /* experiment: two tiles of loads in flight per wave - three register buffers taken in turn by three copies of the body */
+      F3 va[kPts], vb[kPts], vc[kPts];
+      const int nFull = (fullEnd - begin) / kTile;
+      const int p0 = begin + kPts * tid;
+      if(nFull > 0)
+        load_points_full<SRC>(base, p0, va);
+      if(nFull > 1)
+        load_points_full<SRC>(base, p0 + kTile, vb);
+      for(int t = 0; t < nFull; )
+      {
+        if(t + 2 < nFull) load_points_full<SRC>(base, p0 + (t + 2) * kTile, vc);
+        tileInOrder(va);
+        if(++t >= nFull) break;
+        first_use(vb);
+        if(t + 2 < nFull) load_points_full<SRC>(base, p0 + (t + 2) * kTile, va);
+        tileInOrder(vb);
+        if(++t >= nFull) break;
+        first_use(vc);
+        if(t + 2 < nFull) load_points_full<SRC>(base, p0 + (t + 2) * kTile, vb);
+        tileInOrder(vc);
+        if(++t >= nFull) break;
+        first_use(va);
+      }
+#else
+      F3 va[kPts], vb[kPts];
       if(begin < fullEnd)
         load_points_full<SRC>(base, begin + kPts * tid, va);
       for(int i0 = begin; i0 < fullEnd; i0 += kTile)
@@ -1187,15 +1272,13 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
         tileInOrder(va);
         if(more)
         {
-          /* the loaded registers are first looked at HERE, behind the tile: without this the compiler builds the (x, y) register
-           * pairs of the next tile's points (v_pk_fma_f32 wants them aligned) right behind the loads - and waits for them there */
-          asm volatile("" : "+v"(vb[0].x), "+v"(vb[0].y), "+v"(vb[0].z), "+v"(vb[1].x), "+v"(vb[1].y), "+v"(vb[1].z),
-                            "+v"(vb[2].x), "+v"(vb[2].y), "+v"(vb[2].z), "+v"(vb[3].x), "+v"(vb[3].y), "+v"(vb[3].z));
+          first_use(vb);
 #pragma unroll
           for(int j = 0; j < kPts; j++)
             va[j] = vb[j];
         }
       }
+#endif
       if(fullEnd < end)
       {
         load_points<SRC>(base, fullEnd + kPts * tid, end, va, D);
