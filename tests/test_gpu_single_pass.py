@@ -72,10 +72,12 @@ def test_a_wrong_predictor_costs_time_not_results(ssd, gpu_device, sabotage):
     buf.free()
 
 
-@pytest.mark.parametrize("W,H", [(1024, 768), (512, 384), (256, 192), (640, 480), (848, 480), (1280, 720), (1920, 1080)])
+@pytest.mark.parametrize("W,H", [(1024, 768), (512, 384), (256, 192), (640, 480), (848, 480), (1280, 720), (1920, 1080), (600, 450), (427, 321), (128, 100)])
 def test_single_pass_forced_on_small_batches(ssd, oracle, gpu_device, W, H):
     """Geometries whose tile of 1024 points is one, two or four camera rows (K1 walks its chunk tile by tile) and geometries where
-    it is not (K1 walks the chunk's strips of 256 points sorted by column band; 848 is not even a whole number of cells), 12
+    it is not (K1 walks the chunk's strips of 256 points sorted by column band; 848 is not even a whole number of cells; 600 x 450
+    and 427 x 321 end in a part of a strip - the clamped loads of round 5 - and the latter is not even a multiple of four points:
+    12-byte loads; 128 x 100 ends in half a tile), 12
     frames with the single pass forced on (the product only takes it for batches of 64 XGA frames' worth of points and more), against two passes and the oracle."""
     n = 12
     sc, buf = _batch(ssd, gpu_device, W, H, n, 43000 + W, 43)
