@@ -1,0 +1,52 @@
+"""The next tile's loads of K1 must be IN FLIGHT while the current tile is processed — checked in the ISA of the built library.
+
+Round 5 found that every streaming kernel had waited for its "prefetch" right where it was issued since round 2 (the compiler copies
+parts of the loaded registers at once when the loads sit behind branches; profiles/r05_k1_variants.txt (m)), and that whether it does
+is the register allocator's decision at K1's budget of 96 registers: a harmless-looking change to the loop brought the copies back
+((o)).  So the property is pinned here: in the gfx950 code object inside lib/libssd_hip.so (disassembled by tools/isa_prefetch.py in
+under a second, no GPU), the aligned-vertex instantiations of K1 hold a group of 16-byte loads with hundreds of instructions between
+them and the next `s_waitcnt vmcnt`.  k_raster / k_inquad are not held to it (their loads are still waited for at once; K4 is bound
+by its instructions)."""
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+isa = importlib.import_module("isa_prefetch")
+
+pytestmark = pytest.mark.skipif(not (isa.tools_present() and os.path.exists(isa.DEFAULT_LIB)),
+                                reason="needs the built lib/libssd_hip.so and the ROCm llvm tools")
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    return isa.disassemble()
+
+
+def _one(kernels, fragment):
+    names = [n for n in kernels if fragment in n]
+    assert len(names) == 1, (fragment, names)
+    return kernels[names[0]]
+
+
+@pytest.mark.parametrize("fragment,least", [("13k_hist_planesILi1ELb0EE", 400),      # the single pass's K1, a tile a whole number of rows (XGA)
+                                            ("13k_hist_planesILi1ELb1EE", 400),      # the sorted strips (FHD, VGA)
+                                            ("6k_histILi1EE", 300)])                 # two passes
+def test_k1_keeps_the_next_tiles_loads_in_flight(kernels, fragment, least):
+    ins = _one(kernels, fragment)
+    d = isa.load_distances(ins)
+    assert len(d) >= 6, "expected the prologue's and the loop's three 16-byte loads"
+    far = [n for _, n in d if n >= least]
+    assert len(far) >= 3, ("the loop's loads are waited for %s instructions after they are issued: the prefetch is none "
+                           "(see profiles/r05_k1_variants.txt (m), (o))" % [n for _, n in d])
+
+
+def test_the_disassembly_is_the_shipped_kernels(kernels):
+    # every instantiation the launchers can pick is in the code object
+    for fragment in ("k_hist_planesILi%dELb%dEE" % (s, b) for s in (0, 1, 2) for b in (0, 1)):
+        _one(kernels, fragment)
+    for fragment in ("6k_histILi0EE", "6k_histILi1EE", "6k_histILi2EE", "9k_predictILi1EE", "7k_peaks", "7k_quads"):
+        assert any(fragment in n for n in kernels), fragment
