@@ -1072,7 +1072,9 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
         /* a point of a candidate bin: its pixel key, its share of the plane's z sum */
         const bool cand = plane != 0xff;
         const unsigned long long cm = __ballot(cand);
-        if(cm != 0ull)
+        /* the wave-uniform test skips the block with a scalar branch where most tiles hold no candidate (XGA: 1.91 against 1.97 ms
+         * without it); in the sorted strips' walk (FHD stress: nearly every strip holds some) it only costs (1.53 against 1.50 ms) */
+        if(STRIPS || cm != 0ull)
         {
           unsigned int key = kNoPixel;
           if(cand)
@@ -1100,7 +1102,7 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
             key = inside ? pixel_key(plane, iy, ix) : kNoPixel;
           }
           keys[j] = key;
-          anyKey = true;
+          anyKey = anyKey | (cm != 0ull);
         }
       }
     }
