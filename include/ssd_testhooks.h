@@ -72,6 +72,10 @@ int ssd_test_predict_table_host(const uint32_t *sample, int n_bins, int min_heig
  * the bound holds for, out[11] / out[12] = the boxes' two offsets, out[13] = 1 when K1 tests the input's magnitude per point, 0 when
  * make_pre_xy showed that a larger input cannot read "inside".  tests/test_prexy.py checks the bound against double precision. */
 int ssd_test_prexy_host(const double range[6], const double a[9], const double b[3], float out[14]);
+/* round 6 - the z row and the candidates' pixel in single precision first (make_pre_z / make_pre_pixel, csrc/ssd_prexy.h), on the
+ * host: out[0..3] = the z row's coefficients in bins, out[4] = -K, out[5] = 1/2 - E0 (sure iff |fract(t) - 1/2| < out[5] + out[4] * max|input|),
+ * out[6] = zTop, out[7] = zCheckTop; out[8..11] = W, W/2, -H, H/2, out[12] / out[13] = the pixel test's -K and 1/2 - E0; out[14] = recip */
+int ssd_test_prez_host(const double range[6], const double a[9], const double b[3], double height_interval, int width, int height, float out[16]);
 /* tools hook (tools/k1place.py): places the first workspace's cell records `offset_bytes` (a multiple of 8, within the extra bytes a
  * preceding ssd_test_record_realloc_sized asked for) into their allocation; the records' content is undefined afterwards until the
  * next full enqueue */

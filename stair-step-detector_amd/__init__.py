@@ -157,7 +157,7 @@ SOURCE_EXPORTS = [
 # libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
 HOOK_EXPORTS = [
     "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_ground_image", "ssd_test_line_host", "ssd_test_intersect_host", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_best_line_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
-    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_test_single_pass", "ssd_test_plane_pool", "ssd_test_single_pass_stats", "ssd_test_single_pass_frame", "ssd_test_single_pass_sample", "ssd_test_predict_table_host", "ssd_test_prexy_host", "ssd_test_record_offset", "ssd_test_record_realloc", "ssd_test_record_realloc_sized", "ssd_test_record_release", "ssd_testhooks_last_error",
+    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_test_single_pass", "ssd_test_plane_pool", "ssd_test_single_pass_stats", "ssd_test_single_pass_frame", "ssd_test_single_pass_sample", "ssd_test_predict_table_host", "ssd_test_prexy_host", "ssd_test_prez_host", "ssd_test_record_offset", "ssd_test_record_realloc", "ssd_test_record_realloc_sized", "ssd_test_record_release", "ssd_testhooks_last_error",
 ]
 SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
 HOOKS_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_testhooks.so")
@@ -283,6 +283,7 @@ def hooks_lib():
     L.ssd_test_single_pass_sample.argtypes = [vp, i32, vp]
     L.ssd_test_predict_table_host.argtypes = [vp, i32, i32, i32, vp]
     L.ssd_test_prexy_host.argtypes = [vp, vp, vp, vp]
+    L.ssd_test_prez_host.argtypes = [vp, vp, vp, C.c_double, i32, i32, vp]
     L.ssd_test_record_offset.argtypes = [vp, C.c_size_t]
     L.ssd_test_record_realloc.argtypes = [vp]
     L.ssd_test_record_realloc.restype = C.c_ulonglong
@@ -855,6 +856,18 @@ def calibration_points(scene, marks=CALIBRATION_MARKS, world_offset=(0.0, 0.0, 0
 def transformation_for_scene(scene):
     world, cam = calibration_points(scene)
     return GeometricTransformation(world, cam)
+
+
+def prez_host(x_min, x_max, y_min, y_max, z_min, z_max, a, b, height_interval=0.01, width=1024, height=768):
+    """test hook: the constants of K1's single-precision z row / bin and candidate pixel (csrc/ssd_prexy.h: make_pre_z, make_pre_pixel)"""
+    rng = (C.c_double * 6)(x_min, x_max, y_min, y_max, z_min, z_max)
+    aa = (C.c_double * 9)(*[float(v) for v in np.asarray(a, dtype=np.float64).reshape(9)])
+    bb = (C.c_double * 3)(*[float(v) for v in np.asarray(b, dtype=np.float64).reshape(3)])
+    out = (C.c_float * 16)()
+    _check(hooks_lib().ssd_test_prez_host(rng, aa, bb, float(height_interval), int(width), int(height), out), "hooks")
+    o = np.array(list(out), dtype=np.float32)
+    return dict(zc=o[:4], z_neg_k=o[4], z_h0=o[5], z_top=o[6], z_check_top=bool(o[7]), f_w=o[8], f_half_w=o[9], f_neg_h=o[10], f_half_h=o[11],
+                px_neg_k=o[12], px_h0=o[13], recip=float(o[14]))
 
 
 def prexy_host(x_min, x_max, y_min, y_max, z_min, z_max, a, b):

@@ -356,6 +356,7 @@ static int make_params(const ssd_config &c, const ssd_calibration &k, Params &P)
   P.px.W = P.W; P.px.H = P.H; P.px.W64 = P.W64;
   P.px.maxStepImages = P.maxStepImages;
   P.px.cellCols = (c.width + kCellHost / 2) / kCellHost > 0 ? (c.width + kCellHost / 2) / kCellHost : 1;
+  make_pre_pixel(P.pt, P.pre, P.px);          /* K1's candidates: the pixel in single precision first (ssd_prexy.h) */
   P.risers = 0; P.riserMinSupport = 1; P.riserTol = 0.0;
   P.heightInterval = c.height_interval;
   /* Shape of the waves' write-combining windows (ssd_kernels.hip, WaveWindow).  A wave walks down one cell column —

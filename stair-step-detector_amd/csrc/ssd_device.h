@@ -81,6 +81,16 @@ struct PreXY
   float maxInput;                             /* the bound behind lo / hi holds for inputs up to this magnitude ... */
   float boxLo, boxHi;                         /* the cell of a minimum is rn(d * 256 + boxLo), of a maximum rn(d * 256 + boxHi), saturated to 0 .. 255 */
   int checkInput;                             /* ... and K1 tests it per point (1) unless make_pre_xy() could show that a larger input cannot be called "inside" (0) */
+  /* Round 6: the z row in single precision first as well (make_pre_z(), ssd_prexy.h).  t = zc[0] x + zc[1] y + zc[2] z + zc[3] is the
+   * point's height above zMin in histogram bins; its distance from the exact value is bounded by e(M) = zK M + zE0 with
+   * M = max(|x|, |y|, |z|) - the bound follows the input's magnitude -, so a point whose t lies farther than e(M) from every
+   * integer has the reference's bin floor(t) and the reference's z-range decision (0 < t < zTop on the bits); the others, NaNs
+   * and overflows take the reference's doubles.  sure  <=>  |fract(t) - 1/2| < zH0 + zNegK * M. */
+  float zc[4];
+  float zNegK, zH0;                           /* -zK rounded away from zero, 1/2 - zE0 rounded down */
+  unsigned int zTopBits;                      /* bits of zTop: the sure point is in the z range iff bits(t) < zTopBits (t >= +0 and t < zTop) */
+  float zTop;                                 /* (zMax - zMin) / heightInterval: the integer next to it (zCheckTop == 0) or itself rounded (1) */
+  int zCheckTop;                              /* the z range does not end within 2^-20 of a bin edge: |t - zTop| <= e(M) is unsure too (two more instructions per point) */
 };
 
 struct PixelParams
@@ -94,6 +104,10 @@ struct PixelParams
                                                  vertical neighbours in the camera image (order of the kernels' cell lists) */
   int groundFull;                             /* k_inquad rasters every ground pixel (debug capture: the whole image is compared);
                                                  0 = only the pixels k_final's bottom scan can see (ground_strip_pixel) */
+  /* round 6, K1's candidates: the pixel from the single-precision d of the range test (make_pre_pixel(), ssd_prexy.h):
+   * px = d.x * fW + fHalfW, py = d.y * fNegH + fHalfH; certain iff max(|fract(px) - 1/2|, |fract(py) - 1/2|) < pxH0 + pxNegK * max(|x|, |y|, |z|) */
+  float fW, fHalfW, fNegH, fHalfH;
+  float pxNegK, pxH0;
 };
 
 /* what the 16-bit depth source needs beside the depth image: rs2::pointcloud's pre-computed maps

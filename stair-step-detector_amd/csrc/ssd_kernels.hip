@@ -842,9 +842,9 @@ __device__ __forceinline__ void specwin_emit(unsigned long long *ww, SpecMiss &m
 /* ---- round 5: K1's x / y range test in single precision first (PreXY, ssd_device.h; the bound: ssd_prexy.h) ---- */
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 /* (d.x, d.y): the point's world x / y, centred on the measuring range and divided by its extent - three packed FMAs */
-__device__ __forceinline__ f32x2 pre_xy(const PreXY &Q, float x, float y, float z)
+__device__ __forceinline__ f32x2 pre_xy(const PreXY &Q, const f32x2 c3, float x, float y, float z)
 {
-  f32x2 d = __builtin_elementwise_fma(f32x2{ Q.c[2][0], Q.c[2][1] }, f32x2{ z, z }, f32x2{ Q.c[3][0], Q.c[3][1] });
+  f32x2 d = __builtin_elementwise_fma(f32x2{ Q.c[2][0], Q.c[2][1] }, f32x2{ z, z }, c3);
   d = __builtin_elementwise_fma(f32x2{ Q.c[1][0], Q.c[1][1] }, f32x2{ y, y }, d);
   d = __builtin_elementwise_fma(f32x2{ Q.c[0][0], Q.c[0][1] }, f32x2{ x, x }, d);
   return d;
@@ -860,6 +860,13 @@ __device__ __forceinline__ float absmax3(float a, float b, float c)
 {
   float r;
   asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+/* truncating conversion that saturates (negative and NaN: 0) instead of being undefined */
+__device__ __forceinline__ unsigned int cvt_u32_f32(float a)
+{
+  unsigned int r;
+  asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(a));
   return r;
 }
 __device__ __forceinline__ float min_f32(float a, float b)
@@ -929,9 +936,11 @@ struct NoSpecLds {};
  * v_readlane per point). */
 struct K1Consts
 {
-  double a[6], b[2];                              /* the x and y rows of CameraToWorld */
-  double xMin, xMax, yMin, yMax;
+  double a[9], b[3];                              /* CameraToWorld, all three rows */
+  double xMin, xMax, yMin, yMax, zMin, zMax;
   double boxX, boxY;
+  double recip;
+  double xToImage, yToImage;                      /* SPEC: Projection2D, for the candidate whose pixel single precision cannot call */
 };
 /* the address of the block's copy, opaque to the compiler at every use: loads from it stay where they are written (hoisted
  * out of the point loop they would occupy thirty-two vector registers for its whole length) */
@@ -955,7 +964,7 @@ struct HistLds
 
 /* SPEC (single pass): the block also rasters the points of the bins that have a plane (FrameState::specPlane, k_predict) into
  * the frame's planes, as k_raster does for the plateaus' bins: pixel (image_pixel), the plane's z sum and out-of-image count. */
-template<int SRC, bool SPEC, bool STRIPS, typename SPECLDS>
+template<int SRC, bool SPEC, bool STRIPS, bool CHECKS, typename SPECLDS>
 __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float *__restrict__ xyz, size_t strideFloats, const PointParams &P,
                                            const PreXY &Q, const PixelParams &X, FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
                                            unsigned long long *__restrict__ planeImg,
@@ -1002,11 +1011,16 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
     lNonZero = 0;
     K1Consts &c = L.kc;
 #pragma unroll
-    for(int i = 0; i < 6; i++)
+    for(int i = 0; i < 9; i++)
       c.a[i] = P.a[i];
-    c.b[0] = P.b[0]; c.b[1] = P.b[1];
-    c.xMin = P.xMin; c.xMax = P.xMax; c.yMin = P.yMin; c.yMax = P.yMax;
+    c.b[0] = P.b[0]; c.b[1] = P.b[1]; c.b[2] = P.b[2];
+    c.xMin = P.xMin; c.xMax = P.xMax; c.yMin = P.yMin; c.yMax = P.yMax; c.zMin = P.zMin; c.zMax = P.zMax;
     c.boxX = P.boxX; c.boxY = P.boxY;
+    c.recip = P.recip;
+    if constexpr(SPEC)
+    {
+      c.xToImage = X.xToImage; c.yToImage = X.yToImage;
+    }
   }
   __syncthreads();
 
@@ -1015,103 +1029,169 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
   int it = 0;
   int nStore = -1;                                                    /* cell records to store (STRIPS), else it * kCellsPerTile */
 
+  /* the lane's copies of constants that are the SECOND scalar operand of an instruction (one is allowed): the z row's fourth
+   * coefficient, the threshold's offset, the x / y rows' fourth pair - without them a v_mov per use and point */
+  float zc3 = Q.zc[3], zh0 = Q.zH0;
+  f32x2 c3xy = f32x2{ Q.c[3][0], Q.c[3][1] };
+  asm volatile("" : "+v"(zc3), "+v"(zh0), "+v"(c3xy));
+
+  /* SPEC: a point of a candidate bin (in range, its bin has plane `plane`): its share of the plane's z sum, its pixel key.
+   * projectToBinaryImage (pointcloud.cpp:458-471) for a bin that may turn out a plateau's.  The z sum takes the reference's doubles
+   * (world_point_flat's z row).  The pixel (Projection2D::worldToImage, pointcloud.cpp:79-83) comes from the single-precision d of
+   * the range test where that is certain (round 6, make_pre_pixel()): px = (d.x + 1/2) W and py = (1/2 - d.y) H farther from every
+   * integer than the bound for this point's magnitude truncate to the reference's pixel - and lie inside the image, 0 and W / H
+   * being integers; the others take the reference's rows and pixel in doubles. */
+  auto candidatePoint = [&](const F3 &q, const f32x2 dj, const int plane) -> unsigned int
+  {
+    if constexpr(!SPEC)
+      return kNoPixel;
+    else
+    {
+    const double x = q.x, y = q.y, z = q.z;
+    double wz = (P.a[6] * x + P.a[7] * y) + P.a[8] * z;
+    wz = wz + P.b[2];
+    const float px = __builtin_fmaf(dj.x, X.fW, X.fHalfW), py = __builtin_fmaf(dj.y, X.fNegH, X.fHalfH);
+    const float gx = __builtin_amdgcn_fractf(px) - 0.5f, gy = __builtin_amdgcn_fractf(py) - 0.5f;
+    const float hp = __builtin_fmaf(absmax3(q.x, q.y, q.z), X.pxNegK, X.pxH0);
+    unsigned int ix = cvt_u32_f32(px), iy = cvt_u32_f32(py);
+    bool inside = true;
+    if(!(absmax2(gx, gy) < hp))
+    {
+      /* rare: the doubles, and the image's bounds (quirk Q5) */
+      const K1ConstsLds c = k1_consts(L.kc);
+      double wx = (c->a[0] * x + c->a[1] * y) + c->a[2] * z;
+      double wy = (c->a[3] * x + c->a[4] * y) + c->a[5] * z;
+      wx = wx + c->b[0];
+      wy = wy + c->b[1];
+      ix = static_cast<unsigned int>(static_cast<int>((wx - c->xMin) * c->xToImage));
+      iy = static_cast<unsigned int>(static_cast<int>((c->yMax - wy) * c->yToImage));
+      inside = (ix < static_cast<unsigned int>(X.W)) & (iy < static_cast<unsigned int>(X.H));
+      if(!inside && SSD_CHK(14, plane, kMaxPlanes))
+        atomicAdd(&SL.oob[plane], 1u);                   /* quirk Q5 */
+    }
+    if(plane != curT)
+    {
+      if(curT >= 0 && SSD_CHK(13, curT, kMaxPlanes))
+        atomicAdd(&SL.ltot[curT][lane & 7], accT);
+      curT = plane;
+      accT = 0;
+    }
+    accT += static_cast<unsigned long long>(z_plus_magic_bits(wz));      /* the bits of z + 6144; k_peaks takes the constant's share off (count x kMagicBits) */
+    return inside ? pixel_key(plane, static_cast<int>(iy), static_cast<int>(ix)) : kNoPixel;
+    }
+  };
+
   auto tileBody = [&](const F3 (&v)[kPts], const int cellAt)
   {
     unsigned int groups = 0u;
     /* extremes of d (pre_xy) over the lane's in-range points: the cell's box */
     float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+    unsigned int planes[kPts] = { 0xffu, 0xffu, 0xffu, 0xffu };     /* SPEC: the plane of the point's bin (0xff: none, or the point is out of range) */
+    /* SPEC: the points' d, for their pixels - kept where the registers are there (the tile loop on vertex input), made again otherwise */
+    constexpr bool kKeepD = SPEC && !STRIPS && SRC != kSrcDepth16;
+    f32x2 dk[kPts];
     unsigned int keys[kPts] = { kNoPixel, kNoPixel, kNoPixel, kNoPixel };
-    bool anyKey = false;                                          /* wave-uniform */
 #pragma unroll
     for(int j = 0; j < kPts; j++)
     {
       const F3 p{ v[j].x, v[j].y, v[j].z };
-      /* z: the reference's doubles (the bin hangs on them); pointcloud.cpp:143-146 counted per wave on the scalar unit */
-      double wz;
-      const bool inz = world_z_flat(P, p, wz);
-      nz += static_cast<unsigned int>(__popcll(__ballot(p.z > 0.0f)));
-      /* x / y: single precision first */
-      f32x2 d = pre_xy(Q, p.x, p.y, p.z);
+      /* pointcloud.cpp:143-146, counted per wave on the scalar unit */
+      const bool valid = p.z > 0.0f;
+      nz += static_cast<unsigned int>(__popcll(__ballot(valid)));
+      /* x / y in single precision (round 5): inside for sure, outside for sure (M > hi), or the band between them (and NaNs) */
+      f32x2 d = pre_xy(Q, c3xy, p.x, p.y, p.z);
       const float M = absmax2(d.x, d.y);
       bool inxy = M < Q.lo;
-      /* the band between lo and hi (a NaN reads "outside", and its point has failed the z test in doubles) and, unless
-       * make_pre_xy() showed that larger inputs cannot read "inside" (block-uniform: a scalar branch), inputs beyond maxInput */
-      bool unsure = (__float_as_uint(M) - __float_as_uint(Q.lo)) <= (__float_as_uint(Q.hi) - __float_as_uint(Q.lo));     /* lo <= M <= hi on the bits of non-negative floats: a cheap subtraction and one compare */
-      if(Q.checkInput)
+      bool maybexy = !(M > Q.hi);
+      const float M3 = absmax3(p.x, p.y, p.z);
+      if constexpr(CHECKS)
       {
-        asm volatile("" ::: "memory");         /* a branch on the scalar, not a select: the test is two vector instructions per point */
-        unsure = unsure | !(absmax3(p.x, p.y, p.z) <= Q.maxInput);
+        /* unless make_pre_xy() showed that larger inputs cannot read "inside" */
+        const bool far = Q.checkInput && !(M3 <= Q.maxInput);
+        inxy = inxy & !far;
+        maybexy = maybexy | far;
       }
-      if(inz & unsure)
+      /* z in single precision (round 6, make_pre_z()): t = the height above zMin in bins.  Farther from every integer than the
+       * bound for this point's magnitude: the bin is floor(t) and the z range is 0 < t < zTop, as the doubles would say */
+      const float t = __builtin_fmaf(Q.zc[0], p.x, __builtin_fmaf(Q.zc[1], p.y, __builtin_fmaf(Q.zc[2], p.z, zc3)));
+      const float g = __builtin_amdgcn_fractf(t) - 0.5f;
+      const float h = __builtin_fmaf(M3, Q.zNegK, zh0);
+      bool unsurez = !(__builtin_fabsf(g) < h);                          /* true for a NaN, and for a magnitude whose bound exceeds half a bin */
+      const bool inzf = __float_as_uint(t) < Q.zTopBits;                 /* +0 <= t < zTop on the bits (a negative t has the sign bit) */
+      if constexpr(CHECKS)
+        unsurez = unsurez | (Q.zCheckTop && !(__builtin_fabsf(t - Q.zTop) > 0.5f - h));     /* the range's upper end is no bin edge: its own band */
+      unsigned int b = cvt_u32_f32(t);
+      /* in range for sure; or possibly in range - neither test says "outside for sure" - with a test unsure: those take the doubles */
+      bool in = valid & inzf & inxy & !unsurez;
+      if(valid & maybexy & (unsurez | (inzf & !inxy)))
       {
-        /* the band around the range's edges, inputs beyond maxInput, NaNs: the doubles decide (rare: one lane in thousands) */
+        /* rare (one lane in thousands): the reference's arithmetic, all of it - world_point_flat's rows and compares, height_bin */
         const K1ConstsLds c = k1_consts(L.kc);
         const double x = p.x, y = p.y, z = p.z;
-        double wx = (c->a[0] * x + c->a[1] * y) + c->a[2] * z;         /* world_point_flat's rows */
+        double wx = (c->a[0] * x + c->a[1] * y) + c->a[2] * z;
         double wy = (c->a[3] * x + c->a[4] * y) + c->a[5] * z;
+        double wz = (c->a[6] * x + c->a[7] * y) + c->a[8] * z;
         wx = wx + c->b[0];
         wy = wy + c->b[1];
-        inxy = (wx > c->xMin) & (wx < c->xMax) & (wy > c->yMin) & (wy < c->yMax);
+        wz = wz + c->b[2];
+        in = (wx > c->xMin) & (wx < c->xMax) & (wy > c->yMin) & (wy < c->yMax) & (wz > c->zMin) & (wz < c->zMax);
+        b = static_cast<unsigned int>(static_cast<int>((wz - c->zMin) * c->recip));      /* height_bin; meaningless for a point out of range, as is d */
         d.x = static_cast<float>((wx - c->xMin) * c->boxX * 0.00390625 - 0.5);
         d.y = static_cast<float>((wy - c->yMin) * c->boxY * 0.00390625 - 0.5);
       }
-      int plane = 0xff;
-      if(inz & inxy)
+      if(in)
       {
-        const unsigned int b = static_cast<unsigned int>(height_bin(P, wz));     /* in [0, nBins) for a point in range */
         if(SSD_CHK(11, b, P.nBins))
           atomicAdd(mine + b * kHistCopies, 1u);                          /* ++hist[bin], pointcloud.cpp:199-202 */
         groups |= 1u << (b / static_cast<unsigned int>(kBinsPerGroup));
         x0 = min_f32(x0, d.x); x1 = max_f32(x1, d.x);
         y0 = min_f32(y0, d.y); y1 = max_f32(y1, d.y);
         if constexpr(SPEC)
-          plane = SSD_CHK(12, b, kMaxBins) ? SL.plane[b] : 0xff;
-      }
-      if constexpr(SPEC)
-      {
-        /* a point of a candidate bin: its pixel key, its share of the plane's z sum */
-        const bool cand = plane != 0xff;
-        const unsigned long long cm = __ballot(cand);
-        /* the wave-uniform test skips the block with a scalar branch where most tiles hold no candidate (XGA: 1.91 against 1.97 ms
-         * without it); in the sorted strips' walk (FHD stress: nearly every strip holds some) it only costs (1.53 against 1.50 ms) */
-        if(STRIPS || cm != 0ull)
         {
-          unsigned int key = kNoPixel;
-          if(cand)
+          const unsigned int plane = SSD_CHK(12, b, kMaxBins) ? SL.plane[b] : 0xffu;
+          if constexpr(STRIPS)
           {
-            /* as k_raster's body: projectToBinaryImage (pointcloud.cpp:458-471) for a bin that may turn out a plateau's; the
-             * point is in range, its x / y rows are world_point_flat's */
-            const double x = p.x, y = p.y, z = p.z;
-            double wx = (P.a[0] * x + P.a[1] * y) + P.a[2] * z;
-            double wy = (P.a[3] * x + P.a[4] * y) + P.a[5] * z;
-            wx = wx + P.b[0];
-            wy = wy + P.b[1];
-            const int ix = static_cast<int>((wx - P.xMin) * X.xToImage);         /* Projection2D::worldToImage (pointcloud.cpp:79-83) as image_pixel */
-            const int iy = static_cast<int>((P.yMax - wy) * X.yToImage);
-            const bool inside = (static_cast<unsigned int>(ix) < static_cast<unsigned int>(X.W)) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(X.H));
-            if(plane != curT)
-            {
-              if(curT >= 0 && SSD_CHK(13, curT, kMaxPlanes))
-                atomicAdd(&SL.ltot[curT][lane & 7], accT);
-              curT = plane;
-              accT = 0;
-            }
-            accT += static_cast<unsigned long long>(z_plus_magic_bits(wz));      /* the bits of z + 6144; k_peaks takes the constant's share off (count x kMagicBits) */
-            if(!inside && SSD_CHK(14, plane, kMaxPlanes))
-              atomicAdd(&SL.oob[plane], 1u);                   /* quirk Q5, rare */
-            key = inside ? pixel_key(plane, iy, ix) : kNoPixel;
+            if(plane != 0xffu)
+              keys[j] = candidatePoint(p, d, static_cast<int>(plane));
           }
-          keys[j] = key;
-          anyKey = anyKey | (cm != 0ull);
+          else
+            planes[j] = plane;
         }
       }
+      if constexpr(kKeepD)
+        dk[j] = d;
     }
-    if constexpr(SPEC)
+    if constexpr(SPEC && !STRIPS)
     {
-      /* most tiles hold no point of a candidate bin (ground, risers, background) */
-      if(anyKey)
+      /* The points of the candidate bins, behind the tile's other work: one wave-uniform test per TILE skips all of it where no lane
+       * holds one - most tiles (ground, risers, background).  A plane number is below 0xff, so the AND of the four is 0xff only
+       * if all are.  (The sorted strips' walk - FHD stress: nearly every strip holds some - takes them point by point above: it
+       * has no registers for a second loop.) */
+      const unsigned int all4 = planes[0] & planes[1] & planes[2] & planes[3];
+#if defined(SSD_ABL) && SSD_ABL == 2                  /* tools: timing without the candidates' work (results are wrong) */
+      if(false)
+#else
+      if(__ballot(all4 != 0xffu) != 0ull)
+#endif
+      {
+#pragma unroll
+        for(int j = 0; j < kPts; j++)
+        {
+          const int plane = static_cast<int>(planes[j]);
+          unsigned int key = kNoPixel;
+          if(plane != 0xff)
+            key = candidatePoint(v[j], kKeepD ? dk[j] : pre_xy(Q, c3xy, v[j].x, v[j].y, v[j].z), plane);
+          keys[j] = key;
+        }
+#if defined(SSD_ABL) && SSD_ABL == 1                  /* tools: timing without the window (results are wrong) */
+        asm volatile("" :: "v"(keys[0]), "v"(keys[1]), "v"(keys[2]), "v"(keys[3]));
+#else
         specwin_emit(SL.wins[tid >> 6], missed, win, frameImg, imgWords, X.W64, SL.boxes, keys, lane);
+#endif
+      }
     }
+    if constexpr(SPEC && STRIPS)
+      specwin_emit(SL.wins[tid >> 6], missed, win, frameImg, imgWords, X.W64, SL.boxes, keys, lane);
     row_reduce_cell(groups, x0, x1, y0, y1);
     if((lane & 15) == 0 && SSD_CHK(15, cellAt, kMaxCellsPerBlock))    /* cell = 64 consecutive points = lanes 16q .. 16q+15 */
       lInfo[cellAt] = make_uint2(groups, cell_box_from_d(Q, x0, x1, y0, y1));
@@ -1321,14 +1401,14 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
   }
 }
 
-template<int SRC>
+template<int SRC, bool CHECKS>
 __global__ __launch_bounds__(kThreads, 6) void k_hist(const float *__restrict__ xyz, size_t strideFloats, PointParams P, PreXY Q,
                                                    FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
                                                    size_t tileMaskStride, int chunkPoints, DepthSrc D)
 {
   __shared__ HistLds L;
   NoSpecLds none;
-  hist_block<SRC, false, false>(L, none, xyz, strideFloats, P, Q, PixelParams{}, st, tileMasks, nullptr, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);   /* frame on the fast grid axis: see launch note on XCD balance */
+  hist_block<SRC, false, false, CHECKS>(L, none, xyz, strideFloats, P, Q, PixelParams{}, st, tileMasks, nullptr, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);   /* frame on the fast grid axis: see launch note on XCD balance */
 }
 
 /* K1 of a single-pass batch: histogram, cell records AND the planes of the candidate bins.  31 KiB of LDS: five blocks per CU
@@ -1336,7 +1416,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_hist(const float *__restrict__ 
 #ifndef SSD_K1S_WAVES
 #define SSD_K1S_WAVES 5
 #endif
-template<int SRC, bool STRIPS>
+template<int SRC, bool STRIPS, bool CHECKS>
 __global__ __launch_bounds__(kThreads, SSD_K1S_WAVES) void k_hist_planes(const float *__restrict__ xyz, size_t strideFloats, PointParams P, PreXY Q, PixelParams X,
                                                    FrameState *__restrict__ st, uint2 *__restrict__ tileMasks,
                                                    unsigned long long *__restrict__ planeImg,
@@ -1344,7 +1424,7 @@ __global__ __launch_bounds__(kThreads, SSD_K1S_WAVES) void k_hist_planes(const f
 {
   __shared__ HistLds L;
   __shared__ SpecLds SL;
-  hist_block<SRC, true, STRIPS>(L, SL, xyz, strideFloats, P, Q, X, st, tileMasks, planeImg, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
+  hist_block<SRC, true, STRIPS, CHECKS>(L, SL, xyz, strideFloats, P, Q, X, st, tileMasks, planeImg, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
 }
 
 /* K0 of a single-pass batch: which height bins may belong to a step plateau?  A histogram of one cell in every kSpecSample (a
@@ -3911,15 +3991,27 @@ void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameSt
                  int nframes, int chunkPoints, const DepthSrc *depth, unsigned long long *planeImg, hipStream_t s)
 {
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
+  /* the rare configurations' per-point tests (inputs beyond PreXY::maxInput that could read "inside", a z range that does not end on
+   * a bin edge) live in instantiations of their own: as run-time flags they cost the common one two instructions per point */
+  const bool checks = P.pre.checkInput != 0 || P.pre.zCheckTop != 0;
   if(planeImg)
   {
     /* a tile a whole number of camera rows: the tile loop keeps every wave in its band of columns; else the sorted strips */
     const bool strips = kTile % P.W != 0;
+#define SSD_LAUNCH_PLANES2(SRC, STRIPS, DEPTH)                                                                                          \
+    if(checks)                                                                                                                             \
+      hipLaunchKernelGGL((k_hist_planes<SRC, STRIPS, true>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, DEPTH); \
+    else                                                                                                                                   \
+      hipLaunchKernelGGL((k_hist_planes<SRC, STRIPS, false>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, DEPTH);
 #define SSD_LAUNCH_PLANES(SRC, DEPTH)                                                                                                    \
     if(strips)                                                                                                                             \
-      hipLaunchKernelGGL((k_hist_planes<SRC, true>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, DEPTH); \
+    {                                                                                                                                      \
+      SSD_LAUNCH_PLANES2(SRC, true, DEPTH)                                                                                                 \
+    }                                                                                                                                      \
     else                                                                                                                                   \
-      hipLaunchKernelGGL((k_hist_planes<SRC, false>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, P.px, st, tileMasks, planeImg, tileMaskStride, chunkPoints, DEPTH);
+    {                                                                                                                                      \
+      SSD_LAUNCH_PLANES2(SRC, false, DEPTH)                                                                                                \
+    }
     if(depth)
     {
       SSD_LAUNCH_PLANES(kSrcDepth16, *depth)
@@ -3932,15 +4024,28 @@ void launch_hist(const float *xyz, size_t strideFloats, const Params &P, FrameSt
     {
       SSD_LAUNCH_PLANES(kSrcF3, DepthSrc{})
     }
+#undef SSD_LAUNCH_PLANES2
 #undef SSD_LAUNCH_PLANES
     return;
   }
+#define SSD_LAUNCH_HIST(SRC, DEPTH)                                                                                                      \
+  if(checks)                                                                                                                               \
+    hipLaunchKernelGGL((k_hist<SRC, true>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, st, tileMasks, tileMaskStride, chunkPoints, DEPTH); \
+  else                                                                                                                                     \
+    hipLaunchKernelGGL((k_hist<SRC, false>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, st, tileMasks, tileMaskStride, chunkPoints, DEPTH);
   if(depth)
-    hipLaunchKernelGGL(k_hist<kSrcDepth16>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, st, tileMasks, tileMaskStride, chunkPoints, *depth);
+  {
+    SSD_LAUNCH_HIST(kSrcDepth16, *depth)
+  }
   else if(aligned16(xyz, strideFloats, P.nPoints))
-    hipLaunchKernelGGL(k_hist<kSrcF3Aligned>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, st, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
+  {
+    SSD_LAUNCH_HIST(kSrcF3Aligned, DepthSrc{})
+  }
   else
-    hipLaunchKernelGGL(k_hist<kSrcF3>, grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, st, tileMasks, tileMaskStride, chunkPoints, DepthSrc{});
+  {
+    SSD_LAUNCH_HIST(kSrcF3, DepthSrc{})
+  }
+#undef SSD_LAUNCH_HIST
 }
 void launch_peaks(const Params &P, FrameState *st, int nframes, DebugFrame *dbg, int *fallback, hipStream_t s)
 {

@@ -39,11 +39,14 @@
 
 #include "ssd_device.h"
 #include <cmath>
+#include <cstring>
 
 namespace ssd
 {
 
 constexpr double kPreXYMaxInput = 64.0;       /* metres: an L515 ranges to 9 m; points beyond go through the doubles */
+
+inline void make_pre_z(const PointParams &P, PreXY &Q);
 
 inline PreXY make_pre_xy(const PointParams &P)
 {
@@ -72,6 +75,7 @@ inline PreXY make_pre_xy(const PointParams &P)
     /* d then always comes from the doubles (K1's fallback rounds the exact value to single: 2^-24) */
     Q.boxLo = static_cast<float>(128.0 - 256.0 * 0x1p-20 - 0.5);
     Q.boxHi = static_cast<float>(128.0 + 256.0 * 0x1p-20 - 0.5);
+    make_pre_z(P, Q);
     return Q;
   }
   Q.lo = std::nextafterf(static_cast<float>(0.5 - e), 0.0f);
@@ -113,7 +117,114 @@ inline PreXY make_pre_xy(const PointParams &P)
    * less for an integer); the single-precision FMA's own rounding (2^-17 of a grid cell) is inside e's slack */
   Q.boxLo = static_cast<float>(128.0 - 256.0 * e - 0.5);
   Q.boxHi = static_cast<float>(128.0 + 256.0 * e - 0.5);
+  make_pre_z(P, Q);
   return Q;
+}
+
+/*
+ * Round 6: the z row, the z-range test and the height bin in single precision first (PreXY::zc .. zCheckTop).
+ *
+ * The reference (pointcloud.cpp:150-178, transformation.h:59-64), all in doubles, every operation rounded:
+ *     wz = ((a6 x + a7 y) + a8 z) + b2;    in range  <=>  wz > zMin && wz < zMax;    bin = (int)((wz - zMin) * recip)
+ * Write T for the exact real value of ((a6 x + a7 y + a8 z + b2) - zMin) * recip (the doubles a, b, zMin, recip taken as they are)
+ * and A = |a6 x| + |a7 y| + |a8 z| + |b2|.
+ *   (i)  the reference's wz is within 4 * 2^-53 A of the real a.p + b2 (three products, three sums), so
+ *          wz > zMin  <=  T >  dRef,     wz < zMin  <=  T < -dRef,     likewise around Tmax = (zMax - zMin) * recip,
+ *        and its u = fl(fl(wz - zMin) * recip) is within 2^-53 recip (6 A + 2 |zMin|) of T:   dRef := 2^-50 recip (A + |zMin|);
+ *   (ii) K1 evaluates t = fma(c0, x, fma(c1, y, fma(c2, z, c3))) in single precision, c_i = fl32(a_(6+i) * recip),
+ *        c3 = fl32((b2 - zMin) * recip): as for x / y above, |t - T| <= 4.01 * 2^-24 S with S = (|c0| + |c1| + |c2|) M + |c3| for
+ *        M = max(|x|, |y|, |z|) - and this bound is taken PER POINT (one v_max3_f32 and one FMA), not for a fixed input range:
+ *        at 100 bins per metre a bound for 64 m would put one point in a hundred into the band, at the 1 - 3 m of a real frame it
+ *        is one in five thousand.
+ * With e(M) = zK M + zE0 >= 4.01 * 2^-24 S + dRef + (what the test itself rounds: fract, the subtraction, the FMA: below 2^-24) + eta:
+ * a t farther than e(M) from every integer lies on the same side of every integer as T and as u - the bin is floor(t), and 0 is an
+ * integer: the lower limit is decided -, and the upper limit is decided when Tmax is within eta <= 2^-20 of an integer N (any range
+ * that is a whole number of height intervals; zTop = N): t < N then means T < Tmax - dRef.  Otherwise (zCheckTop) zTop = fl32(Tmax),
+ * its rounding goes into zE0, and K1 calls points with |t - zTop| <= e(M) unsure as well.
+ * The constants here take 4.5 for the 4.01 and add a floor of 2^-18 of a bin (0.04 um).  NaNs fail the ordered compare, an input
+ * that overflows single precision has M > 10^30 and a negative threshold: both "unsure".  K1 sends every unsure point that the
+ * other test has not called "outside" through the reference's doubles - all three rows, every compare, the bin.
+ */
+inline void make_pre_z(const PointParams &P, PreXY &Q)
+{
+  const double R = P.recip;
+  double sumC = 0.0, amax = 0.0;
+  for(int i = 0; i < 3; i++)
+  {
+    Q.zc[i] = static_cast<float>(P.a[6 + i] * R);
+    sumC += std::fabs(static_cast<double>(Q.zc[i]));
+    amax = std::fmax(amax, std::fabs(P.a[6 + i]));
+  }
+  Q.zc[3] = static_cast<float>((P.b[2] - P.zMin) * R);
+  const long double tmaxL = (static_cast<long double>(P.zMax) - static_cast<long double>(P.zMin)) * static_cast<long double>(R);
+  const double tmax = static_cast<double>(tmaxL);
+  const double N = std::nearbyint(tmax);
+  const double eta = static_cast<double>(tmaxL > static_cast<long double>(N) ? tmaxL - static_cast<long double>(N) : static_cast<long double>(N) - tmaxL);
+  Q.zCheckTop = eta <= 0x1p-20 ? 0 : 1;
+  const double top = Q.zCheckTop ? tmax : N;
+  Q.zTop = static_cast<float>(top);
+  const double K = 4.5 * 0x1p-24 * sumC + 0x1p-50 * 3.0 * amax * R;
+  const double E0 = 4.5 * 0x1p-24 * std::fabs(static_cast<double>(Q.zc[3])) + 0x1p-50 * (std::fabs(P.b[2]) + std::fabs(P.zMin)) * R
+                    + (Q.zCheckTop ? 0x1p-23 * std::fabs(top) : eta) + 0x1p-18;
+  const bool usable = std::isfinite(K) && std::isfinite(E0) && E0 < 0.25 && K > 0.0 && top >= 1.0 && top < 8388608.0
+                      && std::isfinite(static_cast<double>(Q.zc[3])) && std::isfinite(sumC);
+  if(!usable)
+  {
+    /* a calibration or a range single precision says nothing about: the threshold is negative, every point takes the doubles */
+    Q.zNegK = -1.0f; Q.zH0 = -1.0f;
+    Q.zTop = 1.0f; Q.zCheckTop = 0;
+    Q.zc[0] = Q.zc[1] = Q.zc[2] = Q.zc[3] = 0.0f;
+  }
+  else
+  {
+    Q.zNegK = -std::nextafterf(static_cast<float>(K), INFINITY);
+    Q.zH0 = std::nextafterf(static_cast<float>(0.5 - E0), 0.0f);
+  }
+  unsigned int bits;
+  static_assert(sizeof(bits) == sizeof(Q.zTop), "float is 32 bits");
+  std::memcpy(&bits, &Q.zTop, sizeof(bits));
+  Q.zTopBits = bits;
+}
+
+/*
+ * Round 6: the pixel of a candidate point (K1, single pass) from the single-precision d of the range test.
+ *
+ * The reference (pointcloud.cpp:79-83), in doubles: ix = (int)((wx - xMin) * xToImage), iy = (int)((yMax - wy) * yToImage) with
+ * xToImage = fl(W / fl(xMax - xMin)).  With D the exact centred coordinate of the range test (above), the exact real pixel coordinate
+ * is PX = (D_x + 1/2) W (1 + rho), |rho| <= 2^-51 (the two roundings in xToImage), PY = (1/2 - D_y) H (1 + rho'), and the
+ * reference's own value lies within 2^-50 xToImage (A + |xMin|) of PX (as dRef above).  K1 has d with |d - D| <= 4.01 * 2^-24 S(M)
+ * (a lane that went through the doubles has d = fl32(D): 2^-26) and evaluates px = fma(d.x, W, W / 2): one more rounding, at most
+ * 2^-24 W.  So |px - PX| <= W (4.01 * 2^-24 S_x(M) + 2^-23) =: and a px farther than that (plus the reference's own 2^-50 ..) from
+ * every integer truncates to the reference's ix; 0 and W are integers, so such a pixel also lies inside the image (quirk Q5 - a
+ * point within an ulp of the range's edge that lands on column W - is a matter for the doubles).  One threshold for both
+ * coordinates: the larger bound.  Constants as in make_pre_z(): 4.5 for 4.01, a floor of 2^-18 of a pixel.
+ */
+inline void make_pre_pixel(const PointParams &P, const PreXY &Q, PixelParams &X)
+{
+  const double W = X.W, H = X.H;
+  X.fW = static_cast<float>(W); X.fHalfW = static_cast<float>(0.5 * W);
+  X.fNegH = static_cast<float>(-H); X.fHalfH = static_cast<float>(0.5 * H);
+  const double sumX = std::fabs(static_cast<double>(Q.c[0][0])) + std::fabs(static_cast<double>(Q.c[1][0])) + std::fabs(static_cast<double>(Q.c[2][0]));
+  const double sumY = std::fabs(static_cast<double>(Q.c[0][1])) + std::fabs(static_cast<double>(Q.c[1][1])) + std::fabs(static_cast<double>(Q.c[2][1]));
+  double amax = 0.0;
+  for(int i = 0; i < 6; i++)
+    amax = std::fmax(amax, std::fabs(P.a[i]));
+  const double toImg = std::fmax(X.xToImage, X.yToImage);
+  const double K = 4.5 * 0x1p-24 * std::fmax(W * sumX, H * sumY) + 0x1p-50 * 3.0 * amax * toImg;
+  const double E0 = std::fmax(W * (4.5 * 0x1p-24 * std::fabs(static_cast<double>(Q.c[3][0])) + 0x1p-22), H * (4.5 * 0x1p-24 * std::fabs(static_cast<double>(Q.c[3][1])) + 0x1p-22))
+                    + 0x1p-50 * (std::fmax(std::fabs(P.b[0]), std::fabs(P.b[1])) + std::fmax(std::fabs(P.xMin), std::fabs(P.yMax))) * toImg + 0x1p-18;
+  /* width and height are exact in single precision up to 2^24; d must be the pre-filter's (a handle whose range test always takes
+   * the doubles has d = fl32(D), which the bound covers as well) */
+  const bool usable = std::isfinite(K) && std::isfinite(E0) && E0 < 0.25 && K > 0.0 && W <= 8192.0 && H <= 8192.0;
+  if(usable)
+  {
+    X.pxNegK = -std::nextafterf(static_cast<float>(K), INFINITY);
+    X.pxH0 = std::nextafterf(static_cast<float>(0.5 - E0), 0.0f);
+  }
+  else
+  {
+    X.pxNegK = -1.0f; X.pxH0 = -1.0f;        /* negative threshold: every candidate's pixel takes the doubles */
+  }
 }
 
 } // namespace ssd

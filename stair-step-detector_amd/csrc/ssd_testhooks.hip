@@ -381,6 +381,28 @@ int ssd_test_prexy_host(const double range[6], const double a[9], const double b
   return SSD_OK;
 }
 
+int ssd_test_prez_host(const double range[6], const double a[9], const double b[3], double height_interval, int width, int height, float out[16])
+{
+  if(!range || !a || !b || !out || !(height_interval > 0.0) || width <= 0 || height <= 0)
+    return fail(SSD_E_ARG, "ssd_test_prez_host: bad argument");
+  PointParams P{};
+  for(int i = 0; i < 9; i++) P.a[i] = a[i];
+  for(int i = 0; i < 3; i++) P.b[i] = b[i];
+  P.xMin = range[0]; P.xMax = range[1]; P.yMin = range[2]; P.yMax = range[3]; P.zMin = range[4]; P.zMax = range[5];
+  P.recip = 1.0 / height_interval;                       /* as make_params (ssd_capi.hip) */
+  const PreXY Q = make_pre_xy(P);
+  PixelParams X{};
+  X.W = width; X.H = height;
+  X.xToImage = width / (P.xMax - P.xMin);
+  X.yToImage = height / (P.yMax - P.yMin);
+  make_pre_pixel(P, Q, X);
+  for(int i = 0; i < 4; i++) out[i] = Q.zc[i];
+  out[4] = Q.zNegK; out[5] = Q.zH0; out[6] = Q.zTop; out[7] = static_cast<float>(Q.zCheckTop);
+  out[8] = X.fW; out[9] = X.fHalfW; out[10] = X.fNegH; out[11] = X.fHalfH; out[12] = X.pxNegK; out[13] = X.pxH0;
+  out[14] = static_cast<float>(P.recip); out[15] = 0.0f;
+  return SSD_OK;
+}
+
 /* the kernels' line helpers (csrc/ssd_math.h: line_through_i / line_through_d = LineCoordinates(p, q), types.h:140-158; intersect60 =
  * Line<double>::intersection, segmentation.cpp:344-362, whose numerators are LineCoordinates::det / detx / dety) compiled for the host */
 int ssd_test_line_host(const double pq[4], double abc_d[3], int32_t abc_i[3])

@@ -32,9 +32,13 @@ def _one(kernels, fragment):
     return kernels[names[0]]
 
 
-@pytest.mark.parametrize("fragment,least", [("13k_hist_planesILi1ELb0EE", 400),      # the single pass's K1, a tile a whole number of rows (XGA)
-                                            ("13k_hist_planesILi1ELb1EE", 400),      # the sorted strips (FHD, VGA)
-                                            ("6k_histILi1EE", 300)])                 # two passes
+# (the last template flag, round 6: the instantiation with the rare configurations' per-point tests - launch_hist picks by configuration)
+@pytest.mark.parametrize("fragment,least", [("13k_hist_planesILi1ELb0ELb0EE", 400),  # the single pass's K1, a tile a whole number of rows (XGA)
+                                            ("13k_hist_planesILi1ELb0ELb1EE", 400),
+                                            ("13k_hist_planesILi1ELb1ELb0EE", 400),  # the sorted strips (FHD, VGA)
+                                            ("13k_hist_planesILi1ELb1ELb1EE", 400),
+                                            ("6k_histILi1ELb0EE", 300),              # two passes
+                                            ("6k_histILi1ELb1EE", 300)])
 def test_k1_keeps_the_next_tiles_loads_in_flight(kernels, fragment, least):
     ins = _one(kernels, fragment)
     d = isa.load_distances(ins)
@@ -46,7 +50,7 @@ def test_k1_keeps_the_next_tiles_loads_in_flight(kernels, fragment, least):
 
 def test_the_disassembly_is_the_shipped_kernels(kernels):
     # every instantiation the launchers can pick is in the code object
-    for fragment in ("k_hist_planesILi%dELb%dEE" % (s, b) for s in (0, 1, 2) for b in (0, 1)):
+    for fragment in ("k_hist_planesILi%dELb%dELb%dEE" % (s, b, c) for s in (0, 1, 2) for b in (0, 1) for c in (0, 1)):
         _one(kernels, fragment)
-    for fragment in ("6k_histILi0EE", "6k_histILi1EE", "6k_histILi2EE", "9k_predictILi1EE", "7k_peaks", "7k_quads"):
+    for fragment in ("6k_histILi0ELb0EE", "6k_histILi1ELb1EE", "6k_histILi2ELb0EE", "9k_predictILi1EE", "7k_peaks", "7k_quads"):
         assert any(fragment in n for n in kernels), fragment
