@@ -156,6 +156,21 @@ class Ranks:
             dist.destroy_process_group()
 
 
+def numa_node_of(address):
+    """the NUMA node that holds the page at `address` (get_mempolicy(MPOL_F_NODE | MPOL_F_ADDR)), or None where the call is not allowed"""
+    import ctypes
+    try:
+        libc = ctypes.CDLL(None, use_errno=True)
+        node = ctypes.c_int(-1)
+        SYS_get_mempolicy = {"x86_64": 239, "aarch64": 236}.get(os.uname().machine)
+        if SYS_get_mempolicy is None:
+            return None
+        rc = libc.syscall(ctypes.c_long(SYS_get_mempolicy), ctypes.byref(node), None, ctypes.c_ulong(0), ctypes.c_void_p(address), ctypes.c_ulong(1 | 2))
+        return int(node.value) if rc == 0 else None
+    except Exception:
+        return None
+
+
 def host_fed_leg(ssd, scenes, n_frames=256, reps=3, device=0):
     """PCIe-inclusive rates of ssd_process_host / ssd_process_depth_host (frames in HOST memory; double-buffered ingest:
     the copy of a slice overlaps the kernels of the one before) — the deployment a camera implies.  Reported beside the
@@ -177,14 +192,24 @@ def host_fed_leg(ssd, scenes, n_frames=256, reps=3, device=0):
         pinned.array[...] = dev.download(W * H * item * n_frames, dtype=dtype).reshape(shape)
         pageable = np.array(pinned.array)
         run = det.process_host if kind == "float3" else det.process_depth_host
-        for name, arr in (("pinned", pinned.array), ("pageable", pageable)):
+        # both sources in both orders (pinned, pageable, pageable, pinned), two warm-up calls in front of every timed leg: round 5's
+        # line had the pinned source 23 % BEHIND the pageable one on the driver's box - measured first, behind a single warm-up call
+        # (VERDICT round 5, item 7); with the order taken out, the two legs of a source say whether a difference is the source's
+        legs = {"pinned": [], "pageable": []}
+        found = 0
+        for name, arr in (("pinned", pinned.array), ("pageable", pageable), ("pageable", pageable), ("pinned", pinned.array)):
+            run(arr)
             run(arr)
             t0 = time.perf_counter()
             for _ in range(reps):
                 res = run(arr)
-            dt = (time.perf_counter() - t0) / reps
+            legs[name].append((time.perf_counter() - t0) / reps)
+            found = int(sum(1 for r in res if r.n_steps >= 3))
+        for name, arr in (("pinned", pinned.array), ("pageable", pageable)):
+            dt = min(legs[name])
             out["%s_%s" % (kind, name)] = {"frames_per_s": n_frames / dt, "host_to_device_GBps": n_frames * W * H * item / dt / 1e9,
-                                          "stairs_found": int(sum(1 for r in res if r.n_steps >= 3))}
+                                          "legs_GBps": [n_frames * W * H * item / d / 1e9 for d in legs[name]],
+                                          "numa_node_of_source": numa_node_of(arr.ctypes.data), "stairs_found": found}
         pinned.free()
     dev.free()
     det.close()
@@ -575,6 +600,24 @@ def main():
             out["roofline"]["valu_floor_ms"] = floors["valu_floor_ms"]
             out["roofline"]["hbm_floor_ms"] = floors["hbm_floor_ms"]
             out["roofline"]["pass_ms"] = floors["measured_ms"]
+        # Which K1 number is which: `frac` is THIS run's - HIP events on the stream, this GPU -; frac_profiles is
+        # the committed rocprofv3 --kernel-trace --stats average of the same command on the GPU named beside it.  GPUs of this pool
+        # differ by several per cent on this kernel (profiles/r06_box_spread.txt): when the two differ by more than 3 %, the line says so.
+        out["roofline"]["frac_source"] = "this run: HIP events around the kernel on its stream, %d timed launches, GPU %s" % (
+            args.steps, where.get("uuid") or where.get("pci_bus_id") or str(device))
+        kp = os.path.join(ROOT, "profiles", "k1_rocprof.json")
+        if os.path.exists(kp) and not fhd and not depth_in and F == 1024:
+            try:
+                j = json.load(open(kp))
+                out["roofline"]["frac_profiles"] = j["frac"]
+                out["roofline"]["frac_profiles_source"] = {"file": "profiles/k1_rocprof.json", "avg_launch_ms": j["avg_launch_ms"], "gpu": j.get("gpu"),
+                                                           "summary": j.get("summary"), "stale": counters_stamp("k1_rocprof.json", lib_sha)[1]}
+                if j["frac"] > 0 and abs(out["roofline"]["frac"] - j["frac"]) / j["frac"] > 0.03:
+                    out["roofline"]["frac_warning"] = ("this run's K1 fraction %.3f and the committed rocprofv3 average %.3f differ by more than 3 %%: another GPU of the "
+                                                       "pool, or another clock state of the same one (profiles/r06_box_spread.txt); the claim against the north star's 0.60 "
+                                                       "rests on `frac`, measured here" % (out["roofline"]["frac"], j["frac"]))
+            except Exception:
+                pass
         out["library"] = {"path": os.path.relpath(ssd.LIB_PATH, ROOT), "sha256": lib_sha}
         out["devices"] = [sh["where"] for sh in shards]
         out["distinct_devices"] = distinct_devices(out["devices"])
@@ -618,21 +661,31 @@ def main():
             # the same port on all host cores, one frame per thread (ctypes drops the GIL)
             if world == 1 and _AFFINITY_AT_START:
                 os.sched_setaffinity(0, _AFFINITY_AT_START)      # "all host cores": not only the GPU's socket (pool threads inherit this)
-            cores = len(os.sched_getaffinity(0))
+            cpus = sorted(os.sched_getaffinity(0))
+            cores = len(cpus)
             if world == 1 and cores > 1 and len(keep) > 1:
-                from concurrent.futures import ThreadPoolExecutor
-                reps = max(1, (4 * cores + len(keep) - 1) // len(keep))
-                work = keep * reps
-                with ThreadPoolExecutor(cores) as pool:
-                    c0 = time.perf_counter()
-                    list(pool.map(lambda a: oracle.process_lean(ocfg, ocal, a), work))
-                    adt = time.perf_counter() - c0
-                out["cpu_baseline_all_cores"] = {"value": len(work) / adt, "unit": "frames/s", "cores": cores, "kind": "port",
-                                                 "sample": "%d frames (%d distinct), one frame per thread, %.1f s wall" % (len(work), len(keep), adt),
-                                                 "limited_by": "not by the cores: a pool of Python threads calling the oracle through ctypes, every frame's 9.4 MB cloud and the "
-                                                               "oracle's per-frame allocations (point lists, byte images) through one allocator and the sockets' memory - %.1f frames/s "
-                                                               "per core here against the single thread's rate above; it understates what the host could do and is a stated baseline, "
-                                                               "never the target" % (len(work) / adt / cores)}
+                # The native runner (oracle/ssd_oracle_mt.cpp): one pinned std::thread per host CPU, each on a
+                # private copy of a frame it touched first (its own NUMA node), all from one start line, frames pre-loaded - what the
+                # host could do if frames were sharded across its cores as they are across GPUs.  (Round 5 drove the same oracle from a
+                # pool of Python threads through ctypes: 4 frames/s per core against 90 on one.)
+                single = n_cpu / cdt
+                reps = 3 if fhd else 8                                         # frames per thread: seconds of wall time even at a memory-bound rate
+                many = oracle.process_many(ocfg, ocal, keep[:min(len(keep), 32)], cpus, reps=reps)
+                per_core = many["frames_per_s"] / cores
+                bytes_per_frame = 12.0 * W * H
+                out["cpu_baseline_all_cores"] = {
+                    "value": many["frames_per_s"], "unit": "frames/s", "cores": cores, "kind": "port",
+                    "sample": "%d frames: %d pinned threads (one per host CPU) x %d frames each, every thread on a private copy of one of %d distinct "
+                              "frames of the batch, %.1f s wall from the first thread's start to the last one's end (oracle/ssd_oracle_mt.cpp)"
+                              % (many["frames"], cores, reps, min(len(keep), 32), many["wall_s"]),
+                    "frames_per_s_per_core": per_core, "single_thread_frames_per_s": single, "scaling_vs_cores_x_single_thread": per_core / single,
+                    "host_read_GBps_same_threads": many["read_gb_per_s"],
+                    "limited_by": ("the cores: within 2 x of cores x the single thread's rate" if per_core * 2.0 >= single else
+                                   "the host's memory, not the cores: %.0f frames/s x (12 B x %d points read + the oracle's own per-frame lists, images and "
+                                   "their write-allocate traffic, several times that) against %.0f GB/s that the same %d threads read from their private "
+                                   "frames in a plain loop; %.1f frames/s per core against %.1f on one thread alone"
+                                   % (many["frames_per_s"], W * H, many["read_gb_per_s"], cores, per_core, single)),
+                    "input_GBps": many["frames_per_s"] * bytes_per_frame / 1e9}
             out["parity"] = {"frames_checked_against_oracle": checked, "max_abs_height_err_m": rep.get("max_height_err", 0.0),
                              "max_abs_corner_err_m": rep.get("max_corner_err", 0.0), "bar_m": 1e-4}
         if world == 1 and not depth_in and not args.no_latency:
@@ -694,8 +747,12 @@ def main():
             del frames
             torch.cuda.empty_cache()
             out["host_fed"] = host_fed_leg(ssd, scenes, device=device)
+            out["host_fed"]["gpu_numa_node"] = where.get("numa_node")
             out["host_fed"]["note"] = ("frames in host memory through ssd_process_host / ssd_process_depth_host (PCIe-inclusive, "
-                                       "double-buffered ingest); NOT the metric `value`, which is measured on frames resident in HBM")
+                                       "double-buffered ingest); NOT the metric `value`, which is measured on frames resident in HBM.  Every source "
+                                       "is timed twice, in the order pinned, pageable, pageable, pinned, behind two warm-up calls each; the figure is "
+                                       "the better leg, legs_GBps holds both, numa_node_of_source the node of the source's first page (ssd_host_alloc "
+                                       "= hipHostMalloc: wherever the calling thread's policy puts it) beside gpu_numa_node")
         print(json.dumps(out), flush=True)
 
     det.close()

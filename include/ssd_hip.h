@@ -150,7 +150,11 @@ size_t ssd_workspace_bytes(const ssd_handle *h);
  * the input ("The single pass"): about 10 % more frames/s for 2.4 MB more per XGA frame and workspace
  * (SSD_MAX_PLANES bit images per frame), the results the same bit for bit.  enable = 0 gives that memory back and keeps the
  * handle on two passes; enable != 0 (the default of a handle whose max_frames_per_batch qualifies) takes it again.  Waits for the
- * handle's batches in flight.  No reference counterpart (a deployment knob). */
+ * handle's batches in flight.  No reference counterpart (a deployment knob).
+ * The planes are the last thing ssd_create allocates and the one thing it can do without: when they do not fit - or would cross
+ * SSD_MAX_PLANE_BYTES, an environment variable that bounds what a handle may take for the planes of all its workspaces together
+ * (a GPU shared with other tenants) - the handle is created on two passes, ssd_create returns SSD_OK and ssd_last_error() says why;
+ * ssd_set_single_pass(h, 1) under the same shortage fails with SSD_E_NOMEM and leaves the handle whole, on two passes. */
 int ssd_set_single_pass(ssd_handle *h, int enable);
 
 /* ---- processing ------------------------------------------------------------

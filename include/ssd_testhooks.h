@@ -76,11 +76,11 @@ int ssd_test_prexy_host(const double range[6], const double a[9], const double b
  * host: out[0..3] = the z row's coefficients in bins, out[4] = -K, out[5] = 1/2 - E0 (sure iff |fract(t) - 1/2| < out[5] + out[4] * max|input|),
  * out[6] = zTop, out[7] = zCheckTop; out[8..11] = W, W/2, -H, H/2, out[12] / out[13] = the pixel test's -K and 1/2 - E0; out[14] = recip */
 int ssd_test_prez_host(const double range[6], const double a[9], const double b[3], double height_interval, int width, int height, float out[16]);
-/* tools hook (tools/k1place.py): places the first workspace's cell records `offset_bytes` (a multiple of 8, within the extra bytes a
+/* tools hook (tools/k1place2.py): places the first workspace's cell records `offset_bytes` (a multiple of 8, within the extra bytes a
  * preceding ssd_test_record_realloc_sized asked for) into their allocation; the records' content is undefined afterwards until the
  * next full enqueue */
 int ssd_test_record_offset(ssd_handle *h, size_t offset_bytes);
-/* tools hook (tools/k1place.py): gives the first workspace a NEWLY allocated array for its cell records (the previous ones stay
+/* tools hook (tools/k1place2.py): gives the first workspace a NEWLY allocated array for its cell records (the previous ones stay
  * allocated until ssd_test_record_release, so that every call lands somewhere else); returns the device address */
 unsigned long long ssd_test_record_realloc(ssd_handle *h);
 unsigned long long ssd_test_record_realloc_sized(ssd_handle *h, size_t extra_bytes, size_t offset_bytes);   /* a larger allocation, the records `offset_bytes` into it */

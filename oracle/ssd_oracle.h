@@ -138,6 +138,13 @@ int ssdo_process(const ssdo_config *cfg, const ssdo_calibration *cal, const floa
 int ssdo_process_lean(const ssdo_config *cfg, const ssdo_calibration *cal, const float *xyz,
                       double *steps_ext /* [SSDO_MAX_STEPS][9] */, int *status);
 
+/* The same on many host threads at once (ssd_oracle_mt.cpp; bench.py's cpu_baseline_all_cores): thread t, pinned to cpus[t] (NULL:
+ * unpinned), copies frames[t % n_distinct] into memory of its own and runs ssdo_process_lean on it `reps` times behind a common
+ * start line.  wall_seconds: first start to last end; read_gb_per_s: what the same threads read from their private frames in a
+ * plain loop afterwards (the host memory's rate for them); steps_total: steps found, summed.  Returns 0, or <0. */
+int ssdo_process_many(const ssdo_config *cfg, const ssdo_calibration *cal, const float *const *frames, int n_distinct,
+                      const int *cpus, int n_threads, int reps, double *wall_seconds, double *read_gb_per_s, long long *steps_total);
+
 /* rs2::pointcloud::calculate (pointcloud.cpp:138) for an undistorted depth stream, as librealsense2 2.42.0 computes it
  * in float (third party, absent from the reference tree: restated from src/proc/pointcloud.cpp + rsutil.h; parity unpinned):
  * d = raw * depth_units; x = d * ((u - ppx) / fx); y = d * ((v - ppy) / fy); z = d; raw 0 -> (0,0,0) */

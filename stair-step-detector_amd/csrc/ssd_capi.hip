@@ -453,24 +453,55 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
     HIP_TRY_H(hipMemset(L.dStepImg, 0, stepBytes));
     HIP_TRY_H(hipMemset(L.dGroundImg, 0, groundBytes));
   }
+  const size_t resBytes = sizeof(ssd_frame_result) * h->F * h->nSlots;
+  HIP_TRY_H(hipMalloc(&h->dResults, resBytes));
+  HIP_TRY_H(hipHostMalloc(&h->hResults, resBytes, hipHostMallocDefault));
+  std::memset(h->hResults, 0, resBytes);
+  HIP_TRY_H(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->hResultsDev), h->hResults, 0));
+  for(int k = 0; k < h->nSlots; k++)
+    HIP_TRY_H(hipEventCreateWithFlags(&h->resultsReady[k], hipEventDisableTiming));
+  HIP_TRY_H(hipMemset(h->dResults, 0, resBytes));
   /* The planes of the single pass are an optimisation (results are the same without them): when they do not fit beside the
    * rest - a larger batch, more workspaces, memory shared with the caller's frames - the handle gives up the planes of ALL its
-   * workspaces and runs two passes, as ssd_set_single_pass(h, 0) would; it does not fail. */
+   * workspaces and runs two passes, as ssd_set_single_pass(h, 0) would; it does not fail.  They are taken LAST,
+   * behind everything the handle cannot do without: a device with room for the planes but not for what
+   * followed them used to fail the whole handle.  SSD_MAX_PLANE_BYTES (environment) bounds what a handle may take for the planes
+   * of all its workspaces together - for a GPU shared with other tenants; a workspace whose planes would cross it counts as one
+   * whose allocation failed.  Why a handle has no planes is kept for ssd_last_error() (ssd_create still returns SSD_OK). */
   size_t planeBytesHeld = 0;
   if(planeBytes)
   {
     bool ok = true;
+    std::string why;
+    unsigned long long cap = ~0ull;
+    if(const char *e = std::getenv("SSD_MAX_PLANE_BYTES"))
+      cap = std::strtoull(e, nullptr, 10);
     for(int k = 0; k < depth && ok; k++)
     {
       ssd_lane &L = h->lane[k];
-      ok = hipMalloc(&L.dPlaneImg, planeBytes) == hipSuccess
-           && hipMalloc(&L.dFallback, sizeof(int) * (kFallbackList + static_cast<size_t>(h->F))) == hipSuccess;
+      if(static_cast<unsigned long long>(k + 1) * planeBytes > cap)
+      {
+        ok = false;
+        why = "SSD_MAX_PLANE_BYTES = " + std::to_string(cap) + " < " + std::to_string(static_cast<unsigned long long>(depth) * planeBytes);
+        break;
+      }
+      const hipError_t e1 = hipMalloc(&L.dPlaneImg, planeBytes);
+      const hipError_t e2 = e1 == hipSuccess ? hipMalloc(&L.dFallback, sizeof(int) * (kFallbackList + static_cast<size_t>(h->F))) : e1;
+      if(e2 != hipSuccess)
+      {
+        ok = false;
+        why = std::string("hipMalloc of ") + std::to_string(planeBytes) + " bytes for workspace " + std::to_string(k) + ": " + hipGetErrorString(e2);
+      }
     }
     if(ok && hipHostMalloc(&h->hFallback, sizeof(int) * 2 * kMaxLanes, hipHostMallocDefault) != hipSuccess)
+    {
       ok = false;
+      why = "hipHostMalloc of the work lists' counters failed";
+    }
     if(!ok)
     {
       (void)hipGetLastError();                   /* the failed allocation's error is not the handle's */
+      g_err = "ssd_create: no planes for the single pass (" + why + "): the handle runs two passes";
       for(int k = 0; k < depth; k++)
       {
         ssd_lane &L = h->lane[k];
@@ -491,14 +522,6 @@ int ssd_create(const ssd_config *cfg, const ssd_calibration *cal, int device, ss
       planeBytesHeld = planeBytes;
     }
   }
-  const size_t resBytes = sizeof(ssd_frame_result) * h->F * h->nSlots;
-  HIP_TRY_H(hipMalloc(&h->dResults, resBytes));
-  HIP_TRY_H(hipHostMalloc(&h->hResults, resBytes, hipHostMallocDefault));
-  std::memset(h->hResults, 0, resBytes);
-  HIP_TRY_H(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->hResultsDev), h->hResults, 0));
-  for(int k = 0; k < h->nSlots; k++)
-    HIP_TRY_H(hipEventCreateWithFlags(&h->resultsReady[k], hipEventDisableTiming));
-  HIP_TRY_H(hipMemset(h->dResults, 0, resBytes));
   HIP_TRY_H(hipDeviceSynchronize());
 #undef HIP_TRY_H
   h->bytes = static_cast<size_t>(depth) * (sizeof(FrameState) * h->F + stepBytes + groundBytes + planeBytesHeld + maskBytes) + resBytes;
@@ -591,7 +614,10 @@ int ssd_set_single_pass(ssd_handle *h, int enable)
       ssd_lane &L = h->lane[k];
       if(!L.dPlaneImg)
       {
-        const hipError_t e = hipMalloc(&L.dPlaneImg, planeBytes);
+        unsigned long long cap = ~0ull;
+        if(const char *ev = std::getenv("SSD_MAX_PLANE_BYTES"))
+          cap = std::strtoull(ev, nullptr, 10);
+        const hipError_t e = static_cast<unsigned long long>(k + 1) * planeBytes > cap ? hipErrorOutOfMemory : hipMalloc(&L.dPlaneImg, planeBytes);
         if(e != hipSuccess)
         {
           /* asked for explicitly, so said loudly - but the handle stays whole: on two passes, with no plane of any workspace */

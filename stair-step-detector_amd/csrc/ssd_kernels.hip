@@ -56,6 +56,17 @@ __device__ __forceinline__ bool ssd_chk(int site, unsigned long long idx, unsign
 #define SSD_CHK(site, idx, limit) (true)
 #endif
 
+/* Tools build (-DSSD_COUNT, tools/k1count.py): what K1's windows do - tiles with candidate points, window moves, words flushed,
+ * pixels that missed the window.  In the product build the macros are empty. */
+#ifdef SSD_COUNT
+__device__ unsigned long long ssd_k1_counters[8];
+#define SSD_CNT(i, n) do { if(threadIdx.x % 64 == 0) atomicAdd(&ssd_k1_counters[i], static_cast<unsigned long long>(n)); } while(0)
+#define SSD_CNT_LANES(i, pred) do { const unsigned long long cnt_m = __ballot(pred); if(threadIdx.x % 64 == 0 && cnt_m) atomicAdd(&ssd_k1_counters[i], static_cast<unsigned long long>(__popcll(cnt_m))); } while(0)
+#else
+#define SSD_CNT(i, n) do { } while(0)
+#define SSD_CNT_LANES(i, pred) do { } while(0)
+#endif
+
 /* ========================================================================= */
 /* shared per-point arithmetic                                                */
 
@@ -731,56 +742,107 @@ __device__ __forceinline__ unsigned int wave_or_u32(unsigned int v)
   return static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(v), 0) | __builtin_amdgcn_readlane(static_cast<int>(v), 16)
                                    | __builtin_amdgcn_readlane(static_cast<int>(v), 32) | __builtin_amdgcn_readlane(static_cast<int>(v), 48));
 }
-/* the window out (non-zero words only) and cleared; per plane the rows and word columns that held bits, as two bit masks
- * OR-ed over the wave (one reduction per plane with bits, not four min / max), extend the plane's box; all 64 lanes */
-__device__ __forceinline__ void specwin_flush(unsigned long long *ww, const SpecWindow &w, unsigned long long *__restrict__ planes,
-                                              unsigned int imgWords, int W64, ImageBox *boxes, int lane)
+/* Round 6: the window's rows are a RING - image row r of the window's range [row0, row0 + kSpecWinRows) lives in slot
+ * r & (kSpecWinRows - 1) - so that the window can SLIDE down the image by half its height, writing out only the rows it leaves,
+ * instead of standing still until more than half of a tile's pixels miss it and then being written out whole: measured on the
+ * bench's frames, 98 % of the wave-tiles' pixels span fewer than 16 rows, yet 5 % of all pixels missed the standing window
+ * "below" - in the tiles before each move - and went to memory one by one (tools/k1count.py, profiles/r06_k1_windows.txt).
+ *
+ * NROWS rows from image row rBegin (within the window's range) out - non-zero words only - and cleared.  One pass per plane
+ * and 8 rows: lane = (row, word column).  The rows and columns that held bits come from the ballot of the non-zero words on the
+ * scalar unit (no reductions over the wave), and extend the plane's box.  All 64 lanes. */
+template<int NROWS>
+__device__ __forceinline__ void specwin_flush_rows(unsigned long long *ww, const SpecWindow &w, const int rBegin, unsigned long long *__restrict__ planes,
+                                                   unsigned int imgWords, int W64, ImageBox *boxes, int lane)
 {
+  static_assert(NROWS % 8 == 0 && NROWS <= kSpecWinRows, "whole passes of 8 rows");
   if(w.plane0 < 0)
     return;
 #pragma unroll
   for(int pl = 0; pl < kSpecWinPlanes; pl++)
   {
     unsigned long long *img = planes + static_cast<size_t>(w.plane0 + pl) * imgWords;
-    unsigned long long seen = 0ull;             /* bits 0..31: rows, 32..39: word columns */
 #pragma unroll
-    for(int k = 0; k < kSpecWinRows * kSpecWinCols / 64; k++)
+    for(int k = 0; k < NROWS / 8; k++)
     {
-      const int i = k * 64 + lane;              /* within the plane: row = i >> 3, column = i & 7 */
-      const unsigned long long v = ww[pl * (kSpecWinRows * kSpecWinCols) + i];
+      const int y = rBegin + 8 * k + (lane >> 3), x = w.col0 + (lane & 7);
+      const int at = pl * (kSpecWinRows * kSpecWinCols) + ((y & (kSpecWinRows - 1)) << 3) + (lane & 7);
+      const unsigned long long v = ww[at];
+      const unsigned long long nz = __ballot(v != 0ull);         /* bit 8 r + c: row rBegin + 8 k + r, word column col0 + c */
+      SSD_CNT(3, __popcll(nz));
       if(v)
       {
-        const int y = w.row0 + (i >> 3), x = w.col0 + (i & 7);
+#if !(defined(SSD_ABL) && SSD_ABL == 3)
         if(SSD_CHK(6, static_cast<size_t>(w.plane0 + pl) * imgWords + static_cast<size_t>(y) * W64 + x, static_cast<size_t>(kMaxPlanes) * imgWords) && SSD_CHK(7, x, W64))
           atomicOr(img + static_cast<size_t>(y) * W64 + x, v);
-        ww[pl * (kSpecWinRows * kSpecWinCols) + i] = 0ull;
-        seen |= (1ull << (i >> 3)) | (0x100000000ull << (i & 7));
+#endif
+        ww[at] = 0ull;
       }
-    }
-    if(__ballot(seen != 0ull) == 0ull)
-      continue;
-    const unsigned int rows = wave_or_u32(static_cast<unsigned int>(seen)), cols = wave_or_u32(static_cast<unsigned int>(seen >> 32));
-    if(lane == 0)
-    {
-      ImageBox &b = boxes[w.plane0 + pl];
-      atomicMin(&b.yMin, w.row0 + __ffs(static_cast<int>(rows)) - 1); atomicMax(&b.yMax, w.row0 + 31 - __clz(static_cast<int>(rows)));
-      atomicMin(&b.xMin, w.col0 + __ffs(static_cast<int>(cols)) - 1); atomicMax(&b.xMax, w.col0 + 31 - __clz(static_cast<int>(cols)));
+      if(nz != 0ull)
+      {
+        unsigned long long r = nz | (nz >> 4);
+        r |= r >> 2;
+        r |= r >> 1;
+        r &= 0x0101010101010101ull;                               /* bit 8 r: row r held bits */
+        unsigned long long c = nz | (nz >> 32);
+        c |= c >> 16;
+        c |= c >> 8;
+        c &= 0xffull;                                             /* bit c: column c held bits */
+        const int rLo = (__ffsll(static_cast<long long>(r)) - 1) >> 3, rHi = (63 - __clzll(static_cast<long long>(r))) >> 3;
+        const int cLo = __ffsll(static_cast<long long>(c)) - 1, cHi = 63 - __clzll(static_cast<long long>(c));
+        if(lane == 0)
+        {
+          ImageBox &bx = boxes[w.plane0 + pl];
+          atomicMin(&bx.yMin, rBegin + 8 * k + rLo); atomicMax(&bx.yMax, rBegin + 8 * k + rHi);
+          atomicMin(&bx.xMin, w.col0 + cLo); atomicMax(&bx.xMax, w.col0 + cHi);
+        }
+      }
     }
   }
 }
-/* as wavewin_prepare; the new origin: one plane below the lowest missing one (a tread's minority bin may lie on either side
- * of the bin seen first), the lowest missing row, one word left of the lowest missing column */
-__device__ __forceinline__ void specwin_prepare(unsigned long long *ww, SpecWindow &w, unsigned long long *__restrict__ planes,
-                                                unsigned int imgWords, int W64, ImageBox *boxes, unsigned int first, int lane)
+/* the whole window out (before it is re-anchored, and at the end of the block's loop) */
+__device__ __forceinline__ void specwin_flush(unsigned long long *ww, const SpecWindow &w, unsigned long long *__restrict__ planes,
+                                              unsigned int imgWords, int W64, ImageBox *boxes, int lane)
 {
+  specwin_flush_rows<kSpecWinRows>(ww, w, w.row0, planes, imgWords, W64, boxes, lane);
+}
+/* Before a tile's pixels go out, all 64 lanes; first / last: the lane's lowest and highest pixel_key of this tile (kNoPixel: none;
+ * last as a signed number: kNoPixel is -1 and sorts below every key).
+ *   - enough lanes (kSpecSlideLanes) whose last pixel lies in the half window BELOW the window - same planes, same columns -
+ *     while no more than half of the lanes miss it altogether: the window slides down by half its height (the rows it leaves
+ *     are written out);
+ *   - more than half of the lanes that have pixels miss it: written out whole and re-anchored - one plane below the lowest
+ *     plane of the tile's pixels (a tread's minority bin may lie on either side of the bin seen first), the lowest missing row,
+ *     one word left of the lowest missing column. */
+constexpr int kSpecSlideLanes = 6;
+constexpr int kSpecSlideRows = kSpecWinRows / 2;
+static_assert(kSpecSlideRows % 8 == 0, "a slide writes whole passes of 8 rows");
+__device__ __forceinline__ void specwin_prepare(unsigned long long *ww, SpecWindow &w, unsigned long long *__restrict__ planes,
+                                                unsigned int imgWords, int W64, ImageBox *boxes, unsigned int first, int last, int lane)
+{
+  const unsigned int base = specwin_base(w);
   const bool has = first != kNoPixel;
-  const bool miss = has && !specwin_hit(first - specwin_base(w));
+  const bool miss = has && !specwin_hit(first - base);
+  /* "below": the difference to the origin has the row offset's next bit set and nothing else outside the window's fields, with
+   * the offset below 1.5 windows: rows [kSpecWinRows, kSpecWinRows + kSpecSlideRows) */
+  const unsigned int dl = static_cast<unsigned int>(last) - base;
+  const bool below = last >= 0 && (dl & ~(kSpecInside & ~(static_cast<unsigned int>(kSpecSlideRows) << 13))) == (static_cast<unsigned int>(kSpecWinRows) << 13);
   const unsigned long long missing = __ballot(miss);
-  if(missing == 0ull || 2 * __popcll(missing) <= __popcll(__ballot(has)))
+  const int nMissing = __popcll(missing), nHas = __popcll(__ballot(has));
+  if(2 * nMissing <= nHas)
+  {
+    if(__popcll(__ballot(below)) >= kSpecSlideLanes)
+    {
+      SSD_CNT(2, 1);
+      specwin_flush_rows<kSpecSlideRows>(ww, w, w.row0, planes, imgWords, W64, boxes, lane);
+      w.row0 += kSpecSlideRows;
+    }
     return;
+  }
   const unsigned int loPlane = __builtin_amdgcn_readfirstlane(wave_min_u32(has ? first >> 26 : 31u));     /* of ALL the tile's pixels: the planes of a tread alternate */
   const unsigned int loRow = __builtin_amdgcn_readfirstlane(wave_min_u32(miss ? (first >> 13) & 0x1fffu : 0x1fffu));
   const unsigned int loCol = __builtin_amdgcn_readfirstlane(wave_min_u32(miss ? first & 0x1fffu : 0x1fffu));
+  SSD_CNT(2, 1);
   specwin_flush(ww, w, planes, imgWords, W64, boxes, lane);
   w.plane0 = max(0, min(static_cast<int>(loPlane) - (kSpecWinPlanes > 2 ? 1 : 0), kMaxPlanes - kSpecWinPlanes));
   w.row0 = static_cast<int>(loRow);
@@ -807,11 +869,12 @@ __device__ __forceinline__ void specmiss_flush(const SpecMiss &m, ImageBox *boxe
     atomicMin(&boxes[lane].xMin, x0); atomicMax(&boxes[lane].xMax, x1);
   }
 }
-/* as wavewin_emit */
+/* as wavewin_emit; the window's word of a pixel: (plane offset, row slot = row & (rows - 1), half word) */
 __device__ __forceinline__ void specwin_emit(unsigned long long *ww, SpecMiss &miss, SpecWindow &w, unsigned long long *__restrict__ planes,
                                              unsigned int imgWords, int W64, ImageBox *boxes, const unsigned int (&key)[4], int lane)
 {
-  specwin_prepare(ww, w, planes, imgWords, W64, boxes, min(min(key[0], key[1]), min(key[2], key[3])), lane);
+  specwin_prepare(ww, w, planes, imgWords, W64, boxes, min(min(key[0], key[1]), min(key[2], key[3])),
+                  max(max(static_cast<int>(key[0]), static_cast<int>(key[1])), max(static_cast<int>(key[2]), static_cast<int>(key[3]))), lane);
   const unsigned int base = specwin_base(w);
   unsigned int *ww32 = reinterpret_cast<unsigned int *>(ww);
 #pragma unroll
@@ -819,10 +882,13 @@ __device__ __forceinline__ void specwin_emit(unsigned long long *ww, SpecMiss &m
   {
     const unsigned int k = key[j], d = k - base;
     const unsigned int bit = 1u << (k & 31u);
+    SSD_CNT_LANES(4, k != kNoPixel);
+    SSD_CNT_LANES(5, k != kNoPixel && !specwin_hit(d));
     if(specwin_hit(d))
     {
-      if(SSD_CHK(8, ((d >> 26) << (kSpecRowBits + 4)) | (((d >> 13) & (kSpecWinRows - 1u)) << 4) | ((d & 0x1fffu) >> 5), 2 * kSpecWinWords))
-        atomicOr(&ww32[((d >> 26) << (kSpecRowBits + 4)) | (((d >> 13) & (kSpecWinRows - 1u)) << 4) | ((d & 0x1fffu) >> 5)], bit);     /* (plane, row, half word) */
+      const unsigned int at = ((d >> 26) << (kSpecRowBits + 4)) | (((k >> 13) & (kSpecWinRows - 1u)) << 4) | ((d & 0x1fffu) >> 5);
+      if(SSD_CHK(8, at, 2 * kSpecWinWords))
+        atomicOr(&ww32[at], bit);
     }
     else if(k != kNoPixel)
     {
@@ -882,11 +948,14 @@ __device__ __forceinline__ float max_f32(float a, float b)
   return r;
 }
 /* the cell's five reductions over the 16 lanes of a DPP row (groups: OR; the box: two minima, two maxima of the lanes' d), in one
- * block of twenty instructions, the five chains interleaved so that no DPP operand is read within two instructions of its write
+ * block of twenty instructions behind a two-cycle no-op, the five chains interleaved so that no DPP operand is read within two instructions of its write
  * (the wait states the hardware asks for; the compiler does not see into the block) */
 __device__ __forceinline__ void row_reduce_cell(unsigned int &groups, float &x0, float &x1, float &y0, float &y1)
 {
-  asm("v_or_b32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+  /* s_nop 1 first: the hazard recogniser does not look into the block, and nothing else guarantees that the instruction in front of
+   * it has not just written one of the first two operands (a DPP read within two wait states of the write takes stale lanes) */
+  asm("s_nop 1\n\t"
+      "v_or_b32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
       "v_min_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
       "v_max_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
       "v_min_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
@@ -1055,7 +1124,11 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
     const float hp = __builtin_fmaf(absmax3(q.x, q.y, q.z), X.pxNegK, X.pxH0);
     unsigned int ix = cvt_u32_f32(px), iy = cvt_u32_f32(py);
     bool inside = true;
+#if defined(SSD_SABOTAGE_PRE) && (SSD_SABOTAGE_PRE & 2)   /* tools: the band around the pixel edges NOT handed to the doubles */
+    if(false)
+#else
     if(!(absmax2(gx, gy) < hp))
+#endif
     {
       /* rare: the doubles, and the image's bounds (quirk Q5) */
       const K1ConstsLds c = k1_consts(L.kc);
@@ -1120,6 +1193,9 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
       const bool inzf = __float_as_uint(t) < Q.zTopBits;                 /* +0 <= t < zTop on the bits (a negative t has the sign bit) */
       if constexpr(CHECKS)
         unsurez = unsurez | (Q.zCheckTop && !(__builtin_fabsf(t - Q.zTop) > 0.5f - h));     /* the range's upper end is no bin edge: its own band */
+#if defined(SSD_SABOTAGE_PRE) && (SSD_SABOTAGE_PRE & 1)   /* tools: the band around the bin edges NOT handed to the doubles - the tests built for it must fail */
+      unsurez = false;
+#endif
       unsigned int b = cvt_u32_f32(t);
       /* in range for sure; or possibly in range - neither test says "outside for sure" - with a test unsure: those take the doubles */
       bool in = valid & inzf & inxy & !unsurez;
@@ -1168,6 +1244,9 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
        * if all are.  (The sorted strips' walk - FHD stress: nearly every strip holds some - takes them point by point above: it
        * has no registers for a second loop.) */
       const unsigned int all4 = planes[0] & planes[1] & planes[2] & planes[3];
+      SSD_CNT(0, 1);
+      SSD_CNT(1, __ballot(all4 != 0xffu) != 0ull ? 1 : 0);
+      SSD_CNT_LANES(6, planes[0] != 0xffu); SSD_CNT_LANES(6, planes[1] != 0xffu); SSD_CNT_LANES(6, planes[2] != 0xffu); SSD_CNT_LANES(6, planes[3] != 0xffu);
 #if defined(SSD_ABL) && SSD_ABL == 2                  /* tools: timing without the candidates' work (results are wrong) */
       if(false)
 #else
@@ -1424,7 +1503,12 @@ __global__ __launch_bounds__(kThreads, SSD_K1S_WAVES) void k_hist_planes(const f
 {
   __shared__ HistLds L;
   __shared__ SpecLds SL;
-  hist_block<SRC, true, STRIPS, CHECKS>(L, SL, xyz, strideFloats, P, Q, X, st, tileMasks, planeImg, tileMaskStride, chunkPoints, D, blockIdx.x, blockIdx.y);
+#ifdef SSD_K1_ROTATE      /* tools: frames walk their chunks in different orders, so that a CU holds tread rows and ground rows at once */
+  const int chunkIdx = static_cast<int>((blockIdx.y + blockIdx.x * SSD_K1_ROTATE) % gridDim.y);
+#else
+  const int chunkIdx = static_cast<int>(blockIdx.y);
+#endif
+  hist_block<SRC, true, STRIPS, CHECKS>(L, SL, xyz, strideFloats, P, Q, X, st, tileMasks, planeImg, tileMaskStride, chunkPoints, D, blockIdx.x, chunkIdx);
 }
 
 /* K0 of a single-pass batch: which height bins may belong to a step plateau?  A histogram of one cell in every kSpecSample (a
@@ -4127,5 +4211,16 @@ void launch_risers(const float *xyz, size_t strideFloats, const Params &P, Frame
 }
 
 } // namespace ssd
+
+#ifdef SSD_COUNT
+/* tools only: reads and clears K1's counters (tiles, tiles with candidates, window moves, words flushed, pixels, pixels that missed, candidate points) */
+extern "C" int ssd_tools_k1_counters(unsigned long long *out)
+{
+  unsigned long long zero[8] = { 0 };
+  if(hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out, HIP_SYMBOL(ssd::ssd_k1_counters), sizeof(zero)) != hipSuccess)
+    return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(ssd::ssd_k1_counters), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #include "ssd_phase_readers.h"

@@ -79,6 +79,7 @@ class Oracle:
         lib.ssdo_calibration_from_points.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(Calibration)]
         lib.ssdo_process.argtypes = [C.POINTER(Config), C.POINTER(Calibration), vp, C.POINTER(Result), vp, vp, i32, vp, vp]
         lib.ssdo_process_lean.argtypes = [C.POINTER(Config), C.POINTER(Calibration), vp, vp, C.POINTER(i32)]
+        lib.ssdo_process_many.argtypes = [C.POINTER(Config), C.POINTER(Calibration), vp, i32, vp, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
         lib.ssdo_close3x3.argtypes = [vp, i32, i32]
         lib.ssdo_serialize.argtypes = [i32, vp, C.c_char_p, i32]
         lib.ssdo_quad_test.argtypes = [vp, vp, i32, vp]
@@ -168,6 +169,19 @@ class Oracle:
         n = self.lib.ssdo_process_lean(C.byref(cfg), C.byref(cal), a.ctypes.data_as(C.c_void_p),
                                        steps.ctypes.data_as(C.c_void_p), C.byref(status))
         return n, steps[:max(n, 0)], status.value
+
+    def process_many(self, cfg, cal, frames, cpus, reps=1):
+        """ssdo_process_many: the oracle on len(cpus) pinned host threads at once, thread t on a private copy of frames[t % len(frames)],
+        `reps` frames each -> dict(wall_s, frames, frames_per_s, read_gb_per_s, steps)"""
+        arrs = [np.ascontiguousarray(f, dtype=np.float32) for f in frames]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        cp = (C.c_int * len(cpus))(*[int(c) for c in cpus])
+        wall, rd, steps = C.c_double(0.0), C.c_double(0.0), C.c_longlong(0)
+        rc = self.lib.ssdo_process_many(C.byref(cfg), C.byref(cal), ptrs, len(arrs), cp, len(cpus), int(reps), C.byref(wall), C.byref(rd), C.byref(steps))
+        if rc < 0:
+            raise RuntimeError("ssdo_process_many failed: %d" % rc)
+        n = len(cpus) * int(reps)
+        return dict(wall_s=wall.value, frames=n, frames_per_s=n / wall.value if wall.value > 0 else 0.0, read_gb_per_s=rd.value, steps=steps.value)
 
     def close3x3(self, img):
         a = np.ascontiguousarray(img, dtype=np.uint8).copy()

@@ -339,3 +339,107 @@ def test_points_in_the_prefilters_band_take_the_doubles(ssd, oracle, gpu_device)
     det = ssd.Detector(cfg, far_trans, gpu_device)
     parity.check_frame(ssd, oracle, det, cfg, far_trans.constants, cloud_far.reshape(H, W, 3), images=True)
     det.close()
+
+
+def _bin_edge_cloud(cfg, a, b, rng, n_per):
+    """camera-frame float points whose world z lies on / next to EVERY edge of a height bin - both limits of the z range among them -
+    plus or minus nothing, a few double ulps, 1e-14 .. 1e-3 of a bin and the single-precision band's own edges (about 1e-4 of a bin at
+    these distances); x / y anywhere in range (a few on its limits as well: both bands at once)"""
+    inv = np.linalg.inv(a)
+    n_bins = int((cfg.z_max - cfg.z_min) / cfg.height_interval) + 1
+    deltas = np.concatenate([[0.0], *[[d, -d] for d in (1e-14, 1e-12, 1e-10, 1e-8, 1e-7, 1e-6, 1e-5, 3e-5, 6e-5, 9e-5, 1.2e-4, 1.5e-4, 2e-4, 4e-4, 1e-3)]])
+    pts = []
+    for edge in range(0, n_bins + 1):
+        w = np.empty((n_per, 3))
+        w[:, 0] = rng.uniform(cfg.x_min + 0.01, cfg.x_max - 0.01, n_per)
+        w[:, 1] = rng.uniform(cfg.y_min + 0.01, cfg.y_max - 0.01, n_per)
+        w[:, 2] = cfg.z_min + (edge + rng.choice(deltas, n_per)) * cfg.height_interval
+        k = n_per // 8                                           # an eighth of them on an x or y limit too
+        w[:k, 0] = rng.choice([cfg.x_min, cfg.x_max], k) + rng.normal(0, 3e-5, k)
+        pts.append((w - b) @ inv.T)
+    return np.concatenate(pts).astype(np.float32)
+
+
+def _pixel_edge_cloud(cfg, a, b, rng, heights, n_per, width, height):
+    """camera-frame float points at the heights of the treads (so that they fall into bins K1 rasters itself in the single pass) whose
+    top-down pixel coordinate lies on / next to a pixel edge in x or in y - the image's own borders among them -, placed beside the
+    staircase (|x| > 0.45 m) where no other point of those bins lights the pixels: a point rastered one pixel off shows in the image"""
+    inv = np.linalg.inv(a)
+    x_to_img, y_to_img = width / (cfg.x_max - cfg.x_min), height / (cfg.y_max - cfg.y_min)
+    deltas = np.concatenate([[0.0], *[[d, -d] for d in (1e-12, 1e-9, 1e-7, 1e-6, 1e-5, 1e-4, 3e-4, 6e-4, 1e-3, 2e-3, 5e-3)]])
+    pts = []
+    for z in heights:
+        for axis in (0, 1):
+            w = np.empty((n_per, 3))
+            side = rng.choice([-1.0, 1.0], n_per)
+            w[:, 0] = side * rng.uniform(0.46, 0.59, n_per)
+            w[:, 1] = rng.uniform(cfg.y_min + 0.02, cfg.y_max - 0.02, n_per)
+            w[:, 2] = z + rng.normal(0.0, 0.0004, n_per)
+            d = rng.choice(deltas, n_per)
+            if axis == 0:
+                col = np.floor((w[:, 0] - cfg.x_min) * x_to_img)
+                col[: n_per // 10] = rng.choice([0.0, float(width)], n_per // 10)        # the image's left and right border
+                w[:, 0] = cfg.x_min + (col + d) / x_to_img
+            else:
+                row = np.floor((cfg.y_max - w[:, 1]) * y_to_img)
+                row[: n_per // 10] = rng.choice([0.0, float(height)], n_per // 10)       # top and bottom border
+                w[:, 1] = cfg.y_max - (row + d) / y_to_img
+            pts.append((w - b) @ inv.T)
+    return np.concatenate(pts).astype(np.float32)
+
+
+@pytest.mark.parametrize("far_camera", [False, True])
+def test_points_on_bin_edges_and_pixel_edges_take_the_doubles(ssd, oracle, gpu_device, far_camera):
+    """Round 6: K1 takes the height bin, the z-range test and (single pass) the pixel of a candidate point from single precision
+    first, with a bound that follows the point's magnitude (csrc/ssd_prexy.h: make_pre_z, make_pre_pixel), and hands the points
+    within that bound of a bin edge / pixel edge to the reference's doubles.  A cloud made for those bands: world z on every bin
+    edge (the range's limits are the first and the last) and world x / y on pixel edges beside the staircase, plus or minus nothing
+    .. 1e-3 of a bin / 5e-3 of a pixel; rounding to camera floats scatters them by ~1e-5 of a bin to either side.  Histogram (one
+    point in the wrong bin moves two counts), counts, raw images (one pixel off shows: nothing else lights those pixels), results:
+    the oracle's, bit for bit, two passes and single pass.  With the camera 25 m away single precision is ten times as coarse and
+    the band ten times as wide.  (A build with -DSSD_SABOTAGE_PRE=1 / =2 - the bands not handed over - fails this test:
+    profiles/r06_prefilter_sabotage.txt.)"""
+    sc = ssd.make_scene(W, H, n_steps=2, seed=78, pitch_deg=46.0, roll_deg=-2.5, yaw_deg=-9.0, sigma=0.001)
+    trans = ssd.transformation_for_scene(sc)
+    cfg = ssd.default_config(W, H, max_frames_per_batch=1)
+    a = np.array(list(trans.constants.a), dtype=np.float64).reshape(3, 3)
+    b = np.array(list(trans.constants.b), dtype=np.float64)
+    rng = np.random.default_rng(6)
+    xyz = ssd.synth_host([sc])[0].reshape(-1, 3).copy()
+    if far_camera:
+        # the same rotation seen from 25 m away: the staircase's own points moved along, so that the frame still has its treads
+        shift = np.array([2.0, -1.5, -25.0])
+        use = ssd.GeometricTransformation()
+        for i in range(9):
+            use.constants.a[i] = trans.constants.a[i]
+        b_use = b + a @ shift
+        for i in range(3):
+            use.constants.b[i] = b_use[i]
+        for name in ("r2", "t2"):
+            for i in range(len(getattr(trans.constants, name))):
+                getattr(use.constants, name)[i] = getattr(trans.constants, name)[i]
+        use.constants.world_z = trans.constants.world_z
+        valid = xyz[:, 2] > 0
+        xyz[valid] = (xyz[valid].astype(np.float64) - shift).astype(np.float32)       # world = a (p - shift) + b_use = a p_old + b
+        xyz[valid & ~(xyz[:, 2] > 0)] = 0.0
+    else:
+        use, b_use = trans, b
+    ref0 = oracle.process(ob.to_oracle_config(cfg), ob.to_oracle_calibration(use.constants), xyz.reshape(H, W, 3))[0]
+    plateaus = [ref0.plateaus[i] for i in range(ref0.n_plateaus)]
+    tread_heights = [cfg.z_min + (p.peak_bin + 0.5) * cfg.height_interval for p in plateaus if p.is_step][:2]
+    assert len(tread_heights) >= 1
+    edges = _bin_edge_cloud(cfg, a, b_use, rng, 400)
+    pixels = _pixel_edge_cloud(cfg, a, b_use, rng, tread_heights, 1500, W, H)
+    extra = np.concatenate([edges, pixels])
+    assert len(extra) < W * H // 4
+    if far_camera:
+        assert 20.0 < np.abs(extra).max() < 40.0
+    idx = np.sort(rng.permutation(W * H)[:len(extra)])
+    xyz[idx] = extra
+    xyz = xyz.reshape(H, W, 3)
+    det = ssd.Detector(cfg, use, gpu_device)
+    rep = parity.check_frame(ssd, oracle, det, cfg, use.constants, xyz, images=True)
+    det.single_pass(1)
+    rep1 = parity.check_frame(ssd, oracle, det, cfg, use.constants, xyz, images=True)
+    assert det.single_pass_stats(1)["ran"] and rep1["line"] == rep["line"] and rep["n_steps"] >= 1
+    det.close()

@@ -251,3 +251,24 @@ def test_product_hypot_equals_libm_on_this_image(ssd, oracle):
     vals += [tuple(v) for v in rng.integers(-3000, 3000, (20000, 2)).astype(float)]
     bad = [(a, b) for a, b in vals if L.ssd_test_hypot_host(a, b) != oracle.hypot(a, b)]
     assert not bad, bad[:5]
+
+
+def test_the_all_cores_runner_is_the_single_threaded_oracle_on_every_thread(ssd, oracle):
+    """oracle/ssd_oracle_mt.cpp (bench.py's cpu_baseline_all_cores): pinned threads behind one start line, each on a private copy
+    of a frame - the steps they find are those ssdo_process_lean finds on the same frames, thread for thread and repetition for
+    repetition; more threads than frames wrap around."""
+    import oracle_binding as ob
+    import scenes
+    W, H = 640, 480
+    sc = scenes.batch_scenes(ssd, W, H, 3, base_seed=100000, rng_seed=7)
+    trans = ssd.transformation_for_scene(sc[0])
+    cfg = ssd.default_config(W, H, max_frames_per_batch=3)
+    xs = list(ssd.synth_host(sc))
+    ocfg, ocal = ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants)
+    alone = [oracle.process_lean(ocfg, ocal, x)[0] for x in xs]
+    assert all(n >= 0 for n in alone) and sum(alone) > 0
+    cpus = sorted(os.sched_getaffinity(0))[:4] or [0]
+    cpus = (cpus * 5)[:5]                                         # five threads on up to four CPUs, three frames: wraps
+    many = oracle.process_many(ocfg, ocal, xs, cpus, reps=2)
+    assert many["frames"] == 10 and many["steps"] == 2 * sum(alone[t % 3] for t in range(5))
+    assert many["wall_s"] > 0 and many["frames_per_s"] > 0 and many["read_gb_per_s"] > 0
