@@ -156,6 +156,26 @@ class Ranks:
             dist.destroy_process_group()
 
 
+def cpu_quota():
+    """how many CPUs' worth of time this process's control group may use (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us), or
+    None without a limit.  A box can show 256 CPUs in the affinity mask and grant 16 of them: 256 busy threads are then throttled to a
+    sixteenth of the time each, and a per-core figure from them says nothing."""
+    try:
+        q, p_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return float(q) / float(p_)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p_ > 0:
+            return float(q) / float(p_)
+    except Exception:
+        pass
+    return None
+
+
 def numa_node_of(address):
     """the NUMA node that holds the page at `address` (get_mempolicy(MPOL_F_NODE | MPOL_F_ADDR)), or None where the call is not allowed"""
     import ctypes
@@ -661,31 +681,45 @@ def main():
             # the same port on all host cores, one frame per thread (ctypes drops the GIL)
             if world == 1 and _AFFINITY_AT_START:
                 os.sched_setaffinity(0, _AFFINITY_AT_START)      # "all host cores": not only the GPU's socket (pool threads inherit this)
-            cpus = sorted(os.sched_getaffinity(0))
-            cores = len(cpus)
-            if world == 1 and cores > 1 and len(keep) > 1:
-                # The native runner (oracle/ssd_oracle_mt.cpp): one pinned std::thread per host CPU, each on a
-                # private copy of a frame it touched first (its own NUMA node), all from one start line, frames pre-loaded - what the
-                # host could do if frames were sharded across its cores as they are across GPUs.  (Round 5 drove the same oracle from a
-                # pool of Python threads through ctypes: 4 frames/s per core against 90 on one.)
+            cpus_all = sorted(os.sched_getaffinity(0))
+            visible = len(cpus_all)
+            quota = cpu_quota()
+            if world == 1 and visible > 1 and len(keep) > 1:
+                # The native runner (oracle/ssd_oracle_mt.cpp): pinned std::threads, each on a private copy of a
+                # frame it touched first (its own NUMA node), all from one start line, frames pre-loaded - what the host could do if frames
+                # were sharded across its cores as they are across GPUs.  (Round 5 drove the same oracle from a pool of Python threads
+                # through ctypes: 4 frames/s per core against 90 on one.)  How many threads: a box of this pool shows every CPU of the
+                # host in the affinity mask and grants the job a share of them; where the control group says how many (cpu_quota) that
+                # many threads run, spread over the mask; where it does not, a few counts are tried and the best one is the figure.
                 single = n_cpu / cdt
-                reps = 3 if fhd else 8                                         # frames per thread: seconds of wall time even at a memory-bound rate
-                many = oracle.process_many(ocfg, ocal, keep[:min(len(keep), 32)], cpus, reps=reps)
+                if quota is not None and quota >= 1.0:
+                    counts = [min(visible, int(quota))]
+                else:
+                    counts = sorted(set(min(visible, c) for c in (8, 16, 32, 64, visible)))
+                reps = 3 if fhd else 6
+                tried, best = [], None
+                for n_use in counts:
+                    cpus = [cpus_all[(i * visible) // n_use] for i in range(n_use)]
+                    many = oracle.process_many(ocfg, ocal, keep[:min(len(keep), 32)], cpus, reps=reps)
+                    tried.append({"threads": n_use, "frames_per_s": many["frames_per_s"], "wall_s": many["wall_s"], "host_read_GBps": many["read_gb_per_s"]})
+                    if best is None or many["frames_per_s"] > best[1]["frames_per_s"]:
+                        best = (n_use, many)
+                cores, many = best
                 per_core = many["frames_per_s"] / cores
-                bytes_per_frame = 12.0 * W * H
                 out["cpu_baseline_all_cores"] = {
                     "value": many["frames_per_s"], "unit": "frames/s", "cores": cores, "kind": "port",
-                    "sample": "%d frames: %d pinned threads (one per host CPU) x %d frames each, every thread on a private copy of one of %d distinct "
-                              "frames of the batch, %.1f s wall from the first thread's start to the last one's end (oracle/ssd_oracle_mt.cpp)"
+                    "sample": "%d frames: %d pinned threads x %d frames each, every thread on a private copy of one of %d distinct frames of the batch, "
+                              "%.1f s wall from the first thread's start to the last one's end (oracle/ssd_oracle_mt.cpp)"
                               % (many["frames"], cores, reps, min(len(keep), 32), many["wall_s"]),
+                    "cpus_visible": visible, "cpu_quota_of_the_control_group": quota, "thread_counts_tried": tried,
                     "frames_per_s_per_core": per_core, "single_thread_frames_per_s": single, "scaling_vs_cores_x_single_thread": per_core / single,
                     "host_read_GBps_same_threads": many["read_gb_per_s"],
-                    "limited_by": ("the cores: within 2 x of cores x the single thread's rate" if per_core * 2.0 >= single else
-                                   "the host's memory, not the cores: %.0f frames/s x (12 B x %d points read + the oracle's own per-frame lists, images and "
-                                   "their write-allocate traffic, several times that) against %.0f GB/s that the same %d threads read from their private "
-                                   "frames in a plain loop; %.1f frames/s per core against %.1f on one thread alone"
-                                   % (many["frames_per_s"], W * H, many["read_gb_per_s"], cores, per_core, single)),
-                    "input_GBps": many["frames_per_s"] * bytes_per_frame / 1e9}
+                    "limited_by": ("the cores: within 2 x of threads x the single thread's rate" if per_core * 2.0 >= single else
+                                   "not the cores alone: %.1f frames/s per thread against %.1f on one thread alone; the same %d threads read %.0f GB/s from "
+                                   "their private frames in a plain loop, and a frame costs the oracle its 12 B x %d points and several times that in "
+                                   "per-frame lists and images (write-allocate traffic) - the host's memory, or a CPU share smaller than the thread count"
+                                   % (per_core, single, cores, many["read_gb_per_s"], W * H)),
+                    "input_GBps": many["frames_per_s"] * 12.0 * W * H / 1e9}
             out["parity"] = {"frames_checked_against_oracle": checked, "max_abs_height_err_m": rep.get("max_height_err", 0.0),
                              "max_abs_corner_err_m": rep.get("max_corner_err", 0.0), "bar_m": 1e-4}
         if world == 1 and not depth_in and not args.no_latency:

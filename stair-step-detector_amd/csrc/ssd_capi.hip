@@ -557,9 +557,11 @@ int ssd_destroy(ssd_handle *h)
   {
     if(h->ingestBuf[k]) (void)hipFree(h->ingestBuf[k]);
     if(h->ingestCopied[k]) (void)hipEventDestroy(h->ingestCopied[k]);
+    if(h->ingestCopied2[k]) (void)hipEventDestroy(h->ingestCopied2[k]);
     if(h->ingestConsumed[k]) (void)hipEventDestroy(h->ingestConsumed[k]);
   }
   if(h->ingestCopy) (void)hipStreamDestroy(h->ingestCopy);
+  if(h->ingestCopy2) (void)hipStreamDestroy(h->ingestCopy2);
   if(h->ingestCompute) (void)hipStreamDestroy(h->ingestCompute);
   if(h->dRisers) (void)hipFree(h->dRisers);
   if(h->hRisers) (void)hipHostFree(h->hRisers);
@@ -1213,10 +1215,12 @@ static int ingest_prepare(ssd_handle *h, size_t sliceBytes)
   if(!h->ingestCopy)
   {
     HIP_TRY(hipStreamCreateWithFlags(&h->ingestCopy, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&h->ingestCopy2, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&h->ingestCompute, hipStreamNonBlocking));
     for(int k = 0; k < 2; k++)
     {
       HIP_TRY(hipEventCreateWithFlags(&h->ingestCopied[k], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&h->ingestCopied2[k], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&h->ingestConsumed[k], hipEventDisableTiming));
     }
   }
@@ -1262,9 +1266,25 @@ static int process_host_impl(ssd_handle *h, const void *src, size_t srcFrameByte
     const int k = c & 1;
     if(c >= 2)
       HIP_TRY(hipStreamWaitEvent(h->ingestCopy, h->ingestConsumed[k], 0));        /* the kernels of slice c - 2 read this buffer */
+    /* A large slice goes over in two halves on two copy streams: one copy of a pinned source runs on ONE copy engine, at 42 GB/s
+     * on the boxes of rounds 5 and 6, while the runtime's own staging of a pageable source reached 55 (bench.py: host_fed, both
+     * orders, two warm-up calls) - the pinned source was the slower one. */
+    bool split = false;
     if(srcFrameBytes == devFrameBytes)
-      HIP_TRY(hipMemcpyAsync(h->ingestBuf[k], from + static_cast<size_t>(done) * srcFrameBytes, static_cast<size_t>(n) * srcFrameBytes,
-                             hipMemcpyHostToDevice, h->ingestCopy));
+    {
+      const size_t bytes = static_cast<size_t>(n) * srcFrameBytes, half = (bytes / 2) & ~static_cast<size_t>(4095);
+      split = half >= (static_cast<size_t>(32) << 20);
+      const unsigned char *at = from + static_cast<size_t>(done) * srcFrameBytes;
+      if(split)
+      {
+        if(c >= 2)
+          HIP_TRY(hipStreamWaitEvent(h->ingestCopy2, h->ingestConsumed[k], 0));
+        HIP_TRY(hipMemcpyAsync(static_cast<unsigned char *>(h->ingestBuf[k]) + half, at + half, bytes - half, hipMemcpyHostToDevice, h->ingestCopy2));
+        HIP_TRY(hipEventRecord(h->ingestCopied2[k], h->ingestCopy2));
+        HIP_TRY(hipStreamWaitEvent(h->ingestCompute, h->ingestCopied2[k], 0));
+      }
+      HIP_TRY(hipMemcpyAsync(h->ingestBuf[k], at, split ? half : bytes, hipMemcpyHostToDevice, h->ingestCopy));
+    }
     else
       HIP_TRY(hipMemcpy2DAsync(h->ingestBuf[k], devFrameBytes, from + static_cast<size_t>(done) * srcFrameBytes, srcFrameBytes, srcFrameBytes, n,
                                hipMemcpyHostToDevice, h->ingestCopy));

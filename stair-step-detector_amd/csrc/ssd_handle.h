@@ -82,7 +82,9 @@ struct ssd_handle
   void *ingestBuf[2] = { nullptr, nullptr };
   size_t ingestCap = 0;                     /* bytes per buffer */
   hipStream_t ingestCopy = nullptr, ingestCompute = nullptr;
+  hipStream_t ingestCopy2 = nullptr;            /* the second half of a large slice: two copy engines (round 6) */
   hipEvent_t ingestCopied[2] = { nullptr, nullptr }, ingestConsumed[2] = { nullptr, nullptr };
+  hipEvent_t ingestCopied2[2] = { nullptr, nullptr };
   /* risers of a host-fed batch, slice by slice (the device buffer holds one enqueue's) */
   ssd_frame_risers *hRisersBatch = nullptr; /* pinned */
   int hRisersBatchCap = 0, hRisersBatchFrames = 0;
