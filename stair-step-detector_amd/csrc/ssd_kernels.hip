@@ -2339,6 +2339,7 @@ struct OutlineShared
   int vpx[2][kMaxProbe], vpy[2][kMaxProbe], vn[2];
   double vdist[2][kMaxProbe];
   int vBest[2];
+  int sortStack[2][3][kSortStack];      /* gnu_sort_on's explicit recursion stack, one per side (lane 0 of the side's wave) */
   LineD baseLine;
   LineD nline[4];                            /* the edges' lines normalised, left edges reversed (calcBaseLine) */
   double partRes[kMaxImgWaves];                 /* BestLine: every wave's best over its share of its edge's pairs */
@@ -2803,7 +2804,7 @@ __global__ __launch_bounds__(T) void k_outline(Params P, FrameState *__restrict_
       {
         for(int k = 0; k < n; k++)
           S.vx[side][k] = k;
-        gnu_sort(SortKeys{ S.vdist[side], S.vx[side] }, n);
+        gnu_sort_on(SortKeys{ S.vdist[side], S.vx[side] }, n, S.sortStack[side][0], S.sortStack[side][1], S.sortStack[side][2]);
         S.vBest[side] = S.vx[side][2 * n / 3];
       }
     }

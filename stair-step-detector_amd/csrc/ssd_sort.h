@@ -157,14 +157,16 @@ __host__ __device__ inline void gs_insertion_sort(const SortKeys &k, int first, 
   }
 }
 
-/* std::sort(first = 0, last = n) on the keys; n <= 2^15 (explicit stack of 32 ranges: the depth limit bounds it) */
-__host__ __device__ inline void gnu_sort(const SortKeys &k, int n)
+/* std::sort(first = 0, last = n) on the keys; n <= 2^15.  The recursion is an explicit stack of at most kSortStack ranges (the depth
+ * limit bounds it) in storage the caller provides - three arrays of kSortStack ints: k_outline hands over LDS (round 6: as local
+ * arrays they were the kernel's only scratch memory, 496 bytes per thread for a path one lane in a thousand blocks takes). */
+constexpr int kSortStack = 40;
+__host__ __device__ inline void gnu_sort_on(const SortKeys &k, int n, int *stFirst, int *stLast, int *stDepth)
 {
   if(n <= 0) return;
   int lg = 0;
   for(int v = n; v > 1; v >>= 1) lg++;                    /* std::__lg */
   /* __introsort_loop(0, n, 2 * lg): the recursive call takes [cut, last), the loop continues with [first, cut) */
-  int stFirst[40], stLast[40], stDepth[40];
   int sp = 0;
   stFirst[0] = 0; stLast[0] = n; stDepth[0] = 2 * lg; sp = 1;
   while(sp > 0)
@@ -201,6 +203,12 @@ __host__ __device__ inline void gnu_sort(const SortKeys &k, int n)
   }
   else
     gs_insertion_sort(k, 0, n);
+}
+/* the same with the stack in local arrays (host, test hooks) */
+__host__ __device__ inline void gnu_sort(const SortKeys &k, int n)
+{
+  int stFirst[kSortStack], stLast[kSortStack], stDepth[kSortStack];
+  gnu_sort_on(k, n, stFirst, stLast, stDepth);
 }
 
 } // namespace ssd
