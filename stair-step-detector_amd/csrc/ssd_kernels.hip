@@ -3141,22 +3141,6 @@ __device__ __forceinline__ bool ground_strip_of(int ix, int x0, int &strip, bool
 }
 static_assert((8191 + 2 + kGroundScanStep) / kGroundScanStep < kMaxGroundStrips, "a strip number for every pixel column");
 
-/* Most of what k_inquad walked were ground cells INSIDE the ground quadrilateral - 58 % of its cells on the bench's frames -, walked
- * with the general body: the z row, the x / y rows and the reference's 3 x 3 cell map per point, to learn what the cell's record
- * already says.  A cell whose box lies inside all four edges of the ground quadrilateral (grid_box_inside on K1's box grid, as for
- * the treads) and that holds no bin of a live tread is SIMPLE: every in-range point of the ground plateau in it lies inside the
- * quadrilateral - counted, no test.  k_ground takes those cells with a lean body - range test, z range and bin in single precision
- * first as in K1 (make_pre_xy / make_pre_z; the points a bound cannot call take the reference's doubles), the z sum in doubles,
- * the pixel in single precision to rule out what the bottom scan cannot see -, k_inquad takes the others.  Both use this
- * predicate on the same record, so every listed cell is walked by exactly one of them. */
-__device__ __forceinline__ bool ground_cell_simple(const uint2 info, unsigned int groundGroups, unsigned int wantedQuads, const QuadGridSegs &sg)
-{
-  if((info.x & groundGroups) == 0u || (info.x & wantedQuads & ~groundGroups) != 0u)
-    return false;
-  const int x0 = info.y & 0xffu, x1 = (info.y >> 8) & 0xffu, y0 = (info.y >> 16) & 0xffu, y1 = info.y >> 24;
-  return grid_box_inside(sg, x0, x1, y0, y1);
-}
-
 template<bool FULL>
 struct InquadLds
 {
@@ -3325,10 +3309,6 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
                                     [&](const uint2 info)
                                     {
                                       if((info.x & wantedQuads) == 0u)
-                                        return false;
-                                      /* the ground's interior is k_ground's (product mode; debug capture of the whole ground
-                                       * image keeps everything here) */
-                                      if(!FULL && gSlot >= 0 && ground_cell_simple(info, liveGroups[gSlot], wantedQuads, segs[gSlot]))
                                         return false;
                                       /* the box on K1's 256 x 256 grid against each live quadrilateral's thresholds on the
                                        * same grid (liveBox, computed once per block from the doubles,
@@ -3514,294 +3494,6 @@ __global__ __launch_bounds__(kThreads, SSD_K4_WAVES) void k_inquad(const float *
   const int nChunks = static_cast<int>(gridDim.y), first = max(1, nChunks / 8), by = static_cast<int>(blockIdx.y);
   const int chunkIdx = by < first ? nChunks - 1 - by : by - first;
   inquad_block<SRC, FULL>(L, xyz, strideFloats, P, X, st, groundImg, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, chunkIdx);
-}
-
-/* ========================================================================= */
-/* K4a: the ground's interior (round 6)                                       */
-
-/* ground_strip_of widened by one pixel either side (the single-precision pixel is within one pixel of the reference's wherever
- * its bound is below a half: make_pre_pixel): is ix - 1 .. ix + 1 on a strip, and on which */
-__device__ __forceinline__ bool ground_strip_near(unsigned int ix, int x0, int &strip)
-{
-  const unsigned int u = ix + static_cast<unsigned int>(3 - x0 + kGroundScanStep);
-  const unsigned int q = strip_div50(u), r = u - kGroundScanStep * q;
-  strip = static_cast<int>(q);
-  return r <= 6u;
-}
-
-struct GroundLds
-{
-  K1Consts kc;                                  /* the doubles of the rare paths */
-  QuadGridSegs seg;                             /* the ground quadrilateral's edges on K1's box grid */
-  unsigned long long lsum[8];
-  unsigned int lcnt[8];
-  unsigned int lOob;
-  ImageBox box[1];
-  unsigned short cellList[kMaxCellsPerBlockInquad];
-  unsigned int listScratch[2 * kWavesPerBlock];
-  int nextGroup;
-  int stripMax[kMaxGroundStrips];
-};
-
-template<int SRC, bool CHECKS>
-__global__ __launch_bounds__(kThreads, 5) void k_ground(const float *__restrict__ xyz, size_t strideFloats, PointParams P, PreXY Q, PixelParams X,
-                                                        FrameState *__restrict__ st, unsigned long long *__restrict__ groundImg,
-                                                        const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
-{
-  __shared__ GroundLds L;
-  const int tid = threadIdx.x, lane = tid & 63, frame = blockIdx.x;
-  /* the chunks at the bottom of the camera image first, as k_inquad: the ground nearest to the camera decides what the strip
-   * raster may leave out */
-  const int nChunks = static_cast<int>(gridDim.y), first = max(1, nChunks / 8), by = static_cast<int>(blockIdx.y);
-  const int chunkIdx = by < first ? nChunks - 1 - by : by - first;
-  FrameState &fs = st[frame];
-  const unsigned int anyActive = fs.anyActive;
-  const int nLiveG = fs.nLive;
-  const unsigned char groundActive = fs.accActive[kGroundAcc];
-  const unsigned int wantedQuads = fs.wantedQuads;
-  const int stripMaxMine = tid < kMaxGroundStrips ? fs.groundStripMax[tid] : -1;
-  const int gSlot = (anyActive && nLiveG > 0 && groundActive) ? min(nLiveG, kMaxLive) - 1 : -1;        /* the ground is the last accumulator */
-  constexpr int sgWords = static_cast<int>(sizeof(QuadGridSegs) / 4);
-  const unsigned int sgw = (tid < sgWords && gSlot >= 0) ? reinterpret_cast<const unsigned int *>(&fs.segLive[gSlot])[tid] : 0u;
-  const unsigned int groundGroups = gSlot >= 0 ? fs.liveGroups[gSlot] : 0u;
-  const int groundInd = fs.groundInd;
-  if(gSlot < 0 || groundInd < 0)
-    return;
-  /* the ground plateau's bins: the run effLo .. effHi (k_peaks; k_quads' bin -> live slot table says the same of them) */
-  const unsigned int gLo = static_cast<unsigned int>(fs.pl[groundInd].effLo), gSpan = static_cast<unsigned int>(fs.pl[groundInd].effHi) - gLo;
-  if(tid == 0)
-  {
-    L.box[0] = ImageBox{ 0x7fffffff, -1, 0x7fffffff, -1 };
-    L.lOob = 0;
-    L.nextGroup = 0;
-    K1Consts &c = L.kc;
-#pragma unroll
-    for(int i = 0; i < 9; i++)
-      c.a[i] = P.a[i];
-    c.b[0] = P.b[0]; c.b[1] = P.b[1]; c.b[2] = P.b[2];
-    c.xMin = P.xMin; c.xMax = P.xMax; c.yMin = P.yMin; c.yMax = P.yMax; c.zMin = P.zMin; c.zMax = P.zMax;
-    c.boxX = P.boxX; c.boxY = P.boxY;
-    c.recip = P.recip;
-    c.xToImage = X.xToImage; c.yToImage = X.yToImage;
-  }
-  if(tid < kMaxGroundStrips)
-    L.stripMax[tid] = stripMaxMine;
-  if(tid < 8)
-  {
-    L.lsum[tid] = 0ull;
-    L.lcnt[tid] = 0u;
-  }
-  if(tid < sgWords)
-    reinterpret_cast<unsigned int *>(&L.seg)[tid] = sgw;
-  __syncthreads();
-
-  const float *base = SRC == kSrcDepth16
-    ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(xyz) + static_cast<size_t>(frame) * strideFloats)
-    : xyz + static_cast<size_t>(frame) * strideFloats;
-  const int begin = chunkIdx * chunkPoints;
-  const int end = min(begin + chunkPoints, P.nPoints);
-  unsigned int *gimg32 = reinterpret_cast<unsigned int *>(groundImg + static_cast<size_t>(frame) * X.H * X.W64);
-  const int stripX0 = ground_scan_x0(X.W), stripRow0 = ground_strip_row0(X.H);
-  int gy0 = 0x7fffffff, gy1 = -1;
-  unsigned long long accZ = 0;                               /* modulo 2^64: see z_plus_magic_bits */
-  unsigned int accN = 0, oob = 0;
-
-  const int cell0 = begin / kCell;
-  const int nCells = (end - begin + kCell - 1) / kCell;
-  const int count = cell_list_build(tileMasks + static_cast<size_t>(frame) * tileMaskStride + cell0, nCells, X.cellCols,
-                                    [&](const uint2 info) { return ground_cell_simple(info, groundGroups, wantedQuads, L.seg); },
-                                    L.cellList, L.listScratch);
-  const int nGroups = (count + 3) >> 2;
-  auto grab = [&]()
-  {
-    int v = 0;
-    if(lane == 0)
-      v = atomicAdd(&L.nextGroup, 1);
-    return __builtin_amdgcn_readfirstlane(v);
-  };
-  float zc3 = Q.zc[3], zh0 = Q.zH0;
-  f32x2 c3xy = f32x2{ Q.c[3][0], Q.c[3][1] };
-  asm volatile("" : "+v"(zc3), "+v"(zh0), "+v"(c3xy));
-  const unsigned int wm1 = static_cast<unsigned int>(X.W - 1), hm1 = static_cast<unsigned int>(X.H - 1);
-
-  /* The next group's loads go out before the current group is processed and are first looked at behind it (first_use, as K1's tile
-   * loop: through load_cell's two paths the compiler waits for them where they are issued): addresses clamped into the frame and
-   * the list, the points beyond either blanked where they are first used.  Depth input deprojects where it loads. */
-  auto issue = [&](const int grp, F3 (&w)[kPts], int &idx0, bool &listed)
-  {
-    const int entry = 4 * grp + (lane >> 4);
-    listed = entry < count;
-    idx0 = (cell0 + static_cast<int>(L.cellList[min(entry, count - 1)])) * kCell + kPts * (lane & 15);
-    if constexpr(SRC == kSrcDepth16)
-      load_points<SRC>(base, idx0, P.nPoints, w, D);
-    else
-      load_points_clamped<SRC>(base, idx0, P.nPoints, w);
-  };
-  int g = grab();
-  F3 v[kPts], vn[kPts];
-  int at = 0, atN = 0;
-  bool listed = false, listedN = false;
-  if(g < nGroups)
-    issue(g, v, at, listed);
-  while(g < nGroups)
-  {
-    const int gNext = grab();
-    if(gNext < nGroups)
-      issue(gNext, vn, atN, listedN);
-    if constexpr(SRC != kSrcDepth16)
-      zero_beyond(v, at, P.nPoints);
-#pragma unroll
-    for(int j = 0; j < kPts; j++)
-    {
-      const F3 p{ v[j].x, v[j].y, v[j].z };
-      /* K1's decisions (hist_block): the range test and the bin in single precision where the bounds allow */
-      const bool valid = listed & (p.z > 0.0f);               /* a row of the wave beyond the list's end holds some listed cell's points again */
-      f32x2 d = pre_xy(Q, c3xy, p.x, p.y, p.z);
-      const float M = absmax2(d.x, d.y);
-      bool inxy = M < Q.lo;
-      bool maybexy = !(M > Q.hi);
-      const float M3 = absmax3(p.x, p.y, p.z);
-      if constexpr(CHECKS)
-      {
-        const bool far = Q.checkInput && !(M3 <= Q.maxInput);
-        inxy = inxy & !far;
-        maybexy = maybexy | far;
-      }
-      const float t = __builtin_fmaf(Q.zc[0], p.x, __builtin_fmaf(Q.zc[1], p.y, __builtin_fmaf(Q.zc[2], p.z, zc3)));
-      const float gz = __builtin_amdgcn_fractf(t) - 0.5f;
-      const float h = __builtin_fmaf(M3, Q.zNegK, zh0);
-      bool unsurez = !(__builtin_fabsf(gz) < h);
-      const bool inzf = __float_as_uint(t) < Q.zTopBits;
-      if constexpr(CHECKS)
-        unsurez = unsurez | (Q.zCheckTop && !(__builtin_fabsf(t - Q.zTop) > 0.5f - h));
-      unsigned int b = cvt_u32_f32(t);
-      bool in = valid & inzf & inxy & !unsurez;
-      if(valid & maybexy & (unsurez | (inzf & !inxy)))
-      {
-        /* rare: the reference's doubles - world_point_flat's rows and compares, height_bin */
-        const K1ConstsLds c = k1_consts(L.kc);
-        const double x = p.x, y = p.y, z = p.z;
-        double wx = (c->a[0] * x + c->a[1] * y) + c->a[2] * z;
-        double wy = (c->a[3] * x + c->a[4] * y) + c->a[5] * z;
-        double wz = (c->a[6] * x + c->a[7] * y) + c->a[8] * z;
-        wx = wx + c->b[0];
-        wy = wy + c->b[1];
-        wz = wz + c->b[2];
-        in = (wx > c->xMin) & (wx < c->xMax) & (wy > c->yMin) & (wy < c->yMax) & (wz > c->zMin) & (wz < c->zMax);
-        b = static_cast<unsigned int>(static_cast<int>((wz - c->zMin) * c->recip));
-        d.x = static_cast<float>((wx - c->xMin) * c->boxX * 0.00390625 - 0.5);
-        d.y = static_cast<float>((wy - c->yMin) * c->boxY * 0.00390625 - 0.5);
-      }
-      /* a point of the ground plateau in a simple cell lies inside the ground quadrilateral: getPointsInQuadrilateral
-       * (pointcloud.cpp:560-572) keeps it, calcAverageZ (:574-581) adds its z - the reference's double */
-      if(in && (b - gLo) <= gSpan)
-      {
-        const double x = p.x, y = p.y, z = p.z;
-        double wz = (P.a[6] * x + P.a[7] * y) + P.a[8] * z;
-        wz = wz + P.b[2];
-        accZ += static_cast<unsigned long long>(z_plus_magic_bits(wz));
-        accN++;
-        /* projectToBinaryImage(pointsInQuadri) (pointcloud.cpp:531), of which k_final's bottom scan reads a twentieth (k_inquad):
-         * the single-precision pixel - within one pixel of the reference's where its bound is below a half - rules out the
-         * rest; what it cannot rule out, and a pixel on the image's last column or row (quirk Q5), takes the doubles */
-        const float px = __builtin_fmaf(d.x, X.fW, X.fHalfW), py = __builtin_fmaf(d.y, X.fNegH, X.fHalfH);
-        const unsigned int ixf = cvt_u32_f32(px), iyf = cvt_u32_f32(py);
-        bool look = !(__builtin_fmaf(M3, X.pxNegK, X.pxH0) > 0.0f) | (ixf >= wm1) | (iyf >= hm1);
-        int stripN;
-        if(static_cast<int>(iyf) >= stripRow0 - 1 && ground_strip_near(ixf, stripX0, stripN))
-        {
-          const int seen = SSD_CHK(41, stripN, kMaxGroundStrips) ? L.stripMax[stripN] : 0x7fffffff;
-          look = look | (static_cast<int>(iyf) >= seen - 3);
-        }
-        if(look)
-        {
-          const K1ConstsLds c = k1_consts(L.kc);
-          double wx = (c->a[0] * x + c->a[1] * y) + c->a[2] * z;
-          double wy = (c->a[3] * x + c->a[4] * y) + c->a[5] * z;
-          wx = wx + c->b[0];
-          wy = wy + c->b[1];
-          const int ix = static_cast<int>((wx - c->xMin) * c->xToImage);         /* Projection2D::worldToImage (pointcloud.cpp:79-83) */
-          const int iy = static_cast<int>((c->yMax - wy) * c->yToImage);
-          const bool inside = (static_cast<unsigned int>(ix) < static_cast<unsigned int>(X.W)) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(X.H));
-          oob += inside ? 0u : 1u;                              /* quirk Q5 */
-          if(inside && iy >= stripRow0)
-          {
-            int strip;
-            bool centre;
-            if(ground_strip_of(ix, stripX0, strip, centre))
-            {
-              /* as k_inquad: a pixel more than two rows above a centre-column pixel already seen in its strip cannot matter */
-              const int seen = SSD_CHK(42, strip, kMaxGroundStrips) ? L.stripMax[strip] : 0x7fffffff;
-              if(iy >= seen - 2)
-              {
-                if(SSD_CHK(43, static_cast<unsigned int>(iy) * (2u * X.W64) + (static_cast<unsigned int>(ix) >> 5), 2u * static_cast<unsigned int>(X.H) * X.W64))
-                  atomicOr(gimg32 + (static_cast<unsigned int>(iy) * (2u * X.W64) + (static_cast<unsigned int>(ix) >> 5)), 1u << (ix & 31));
-                gy0 = min(gy0, iy);
-                gy1 = max(gy1, iy);
-                if(centre && iy > seen)
-                  atomicMax(&L.stripMax[strip], iy);
-              }
-            }
-          }
-        }
-      }
-    }
-    g = gNext;
-    if(g < nGroups)
-    {
-      first_use(vn);
-#pragma unroll
-      for(int j = 0; j < kPts; j++)
-        v[j] = vn[j];
-      at = atN;
-      listed = listedN;
-    }
-  }
-  gy1 = wave_max_i(gy1);
-  if(gy1 >= 0)
-  {
-    gy0 = wave_min_i(gy0);
-    if(lane == 0)
-    {
-      atomicMin(&L.box[0].yMin, gy0); atomicMax(&L.box[0].yMax, gy1);
-      atomicMin(&L.box[0].xMin, 0); atomicMax(&L.box[0].xMax, X.W64 - 1);
-    }
-  }
-  if(accN)
-  {
-    atomicAdd(&L.lsum[lane & 7], accZ - static_cast<unsigned long long>(accN) * static_cast<unsigned long long>(kMagicBits));
-    atomicAdd(&L.lcnt[lane & 7], accN);
-  }
-  if(oob)
-    atomicAdd(&L.lOob, oob);
-  __syncthreads();
-  if(tid < kMaxGroundStrips && L.stripMax[tid] > stripMaxMine)
-    atomicMax(&fs.groundStripMax[tid], L.stripMax[tid]);       /* for the frame's blocks still to come, of this kernel and of k_inquad */
-  if(tid == 0)
-  {
-    unsigned long long sum = 0;
-    unsigned int c = 0;
-    for(int k = 0; k < 8; k++)
-    {
-      sum += L.lsum[k];
-      c += L.lcnt[k];
-    }
-    if(c)
-    {
-      atomicAdd(reinterpret_cast<unsigned long long *>(&fs.sumZ[kGroundAcc]), sum);
-      atomicAdd(&fs.cnt[kGroundAcc], c);
-    }
-    if(L.box[0].yMax >= 0)
-    {
-      atomicMin(&fs.imgYMin[kMaxStepImages], L.box[0].yMin); atomicMax(&fs.imgYMax[kMaxStepImages], L.box[0].yMax);
-      atomicMin(&fs.imgXMin[kMaxStepImages], L.box[0].xMin); atomicMax(&fs.imgXMax[kMaxStepImages], L.box[0].xMax);
-    }
-    if(L.lOob)
-    {
-      atomicAdd(&fs.nOob, L.lOob);
-      atomicOr(&fs.status, static_cast<unsigned int>(SSD_ST_OOB_PIXEL));
-    }
-  }
 }
 
 /* ========================================================================= */
@@ -4493,15 +4185,6 @@ void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, Frame
   }
   else
   {
-    /* the ground's interior first (it holds the rows nearest to the camera, which establish what the strip raster may leave out) */
-    const bool checks = P.pre.checkInput != 0 || P.pre.zCheckTop != 0;
-#define SSD_LAUNCH_GROUND(SRC) \
-    if(checks) hipLaunchKernelGGL((k_ground<SRC, true>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, P.px, st, groundImg, tileMasks, tileMaskStride, chunkPoints, D); \
-    else hipLaunchKernelGGL((k_ground<SRC, false>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, P.px, st, groundImg, tileMasks, tileMaskStride, chunkPoints, D)
-    if(src == kSrcDepth16) { SSD_LAUNCH_GROUND(kSrcDepth16); }
-    else if(src == kSrcF3Aligned) { SSD_LAUNCH_GROUND(kSrcF3Aligned); }
-    else { SSD_LAUNCH_GROUND(kSrcF3); }
-#undef SSD_LAUNCH_GROUND
     if(src == kSrcDepth16) SSD_LAUNCH_INQUAD(kSrcDepth16, false);
     else if(src == kSrcF3Aligned) SSD_LAUNCH_INQUAD(kSrcF3Aligned, false);
     else SSD_LAUNCH_INQUAD(kSrcF3, false);
