@@ -246,7 +246,7 @@ def file_sha256(path):
 
 
 def counters_stamp(name, lib_sha):
-    """The stamp of a committed counter file (profiles/<name>: written by tools/r05_final.sh with the git revision and the
+    """The stamp of a committed counter file (profiles/<name>: written by tools/r06_final.sh with the git revision and the
     sha256 of the libssd_hip.so its passes ran) against the library this process loaded: -> (source string, stale)."""
     path = os.path.join(ROOT, "profiles", name)
     try:

@@ -30,7 +30,7 @@ def per_kernel(path, counter):
 
 
 def load_stamp(src):
-    """the stamp the run wrote next to its outputs (tools/r05_final.sh: git revision of the build, sha256 of the libssd_hip.so the
+    """the stamp the run wrote next to its outputs (tools/r06_final.sh: git revision of the build, sha256 of the libssd_hip.so the
     passes loaded, checked on the GPU box against build/STAMP.json), or None for runs of earlier rounds"""
     p = os.path.join(src, "stamp.json")
     return json.load(open(p)) if os.path.exists(p) else None
@@ -54,6 +54,22 @@ def main():
     stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+        # what bench.py reports as roofline.frac_profiles (round 6): K1's rocprofv3 average of this pass, and on which GPU
+        for r in csv.DictReader(open(stats[0])):
+            if "k_hist_planes" in r["Name"]:
+                avg_ms = float(r["AverageNs"]) / 1e6
+                gpu = None
+                try:
+                    b = json.loads(open(os.path.join(src, "bench.json")).read().strip().split("\n")[-1])
+                    gpu = {k: b["devices"][0].get(k) for k in ("uuid", "pci_bus_id", "name")}
+                except Exception:
+                    pass
+                alg = 12.0 * 1024 * 768 * 1024
+                dump({"kernel": r["Name"].split("(")[0].replace("void ", ""), "calls": int(r["Calls"]), "avg_launch_ms": avg_ms,
+                      "algorithmic_bytes_per_launch": alg, "frac": alg / (avg_ms * 1e-3) / 8e12, "gpu": gpu,
+                      "summary": "profiles/%s_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --batches-in-flight 1 ...)" % tag},
+                     os.path.join(dst, "k1_rocprof.json"), stamp)
+                break
     out = {"note": "per launch = per batch of 1024 frames of 1024x768 points; bytes", "kernels": {}}
     fetch = glob.glob(os.path.join(src, "fetch", "*", "*counter_collection.csv"))
     write = glob.glob(os.path.join(src, "write", "*", "*counter_collection.csv"))

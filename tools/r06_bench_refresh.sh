@@ -1,8 +1,8 @@
 #!/bin/bash
-# tools/r05_bench_refresh.sh TAG — on the GPU box, AFTER the counters of tools/r05_final.sh have been parsed into profiles/ and
+# tools/r06_bench_refresh.sh TAG — on the GPU box, AFTER the counters of tools/r06_final.sh have been parsed into profiles/ and
 # committed: the three bench lines again, so that the lines kept under profiles/ cite the counters of their own build (the lines
-# r05_final.sh wrote were made while profiles/ still held the build before: `stale`).  Refuses another library than the stamped one.
-TAG=${1:-r05_final}; R=$GRAFT_REPO_ROOT; cd $R
+# r06_final.sh wrote were made while profiles/ still held the build before: `stale`).  Refuses another library than the stamped one.
+TAG=${1:-r06_final}; R=$GRAFT_REPO_ROOT; cd $R
 OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
 python3 - <<PY || exit 1
 import hashlib, json, sys

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/stamp.py — writes build/STAMP.json in the build container, before a gpurun call that collects evidence: the git revision
 the tree was built from (the GPU box gets a snapshot without .git), whether the tree differs from it, and the sha256 of
-lib/libssd_hip.so.  tools/r05_final.sh (on the GPU box) checks the library it runs against this stamp and copies it into every
+lib/libssd_hip.so.  tools/r06_final.sh (on the GPU box) checks the library it runs against this stamp and copies it into every
 counter file it makes; bench.py compares the stamp of the committed counters with the library it loaded (`stale`)."""
 import hashlib
 import json
