@@ -1266,14 +1266,14 @@ static int process_host_impl(ssd_handle *h, const void *src, size_t srcFrameByte
     const int k = c & 1;
     if(c >= 2)
       HIP_TRY(hipStreamWaitEvent(h->ingestCopy, h->ingestConsumed[k], 0));        /* the kernels of slice c - 2 read this buffer */
-    /* A large slice goes over in two halves on two copy streams: one copy of a pinned source runs on ONE copy engine, at 42 GB/s
+    /* A slice of 16 MB and more goes over in two halves on two copy streams: one copy of a pinned source runs on ONE copy engine, at 42 GB/s
      * on the boxes of rounds 5 and 6, while the runtime's own staging of a pageable source reached 55 (bench.py: host_fed, both
      * orders, two warm-up calls) - the pinned source was the slower one. */
     bool split = false;
     if(srcFrameBytes == devFrameBytes)
     {
       const size_t bytes = static_cast<size_t>(n) * srcFrameBytes, half = (bytes / 2) & ~static_cast<size_t>(4095);
-      split = half >= (static_cast<size_t>(32) << 20);
+      split = half >= (static_cast<size_t>(8) << 20);
       const unsigned char *at = from + static_cast<size_t>(done) * srcFrameBytes;
       if(split)
       {

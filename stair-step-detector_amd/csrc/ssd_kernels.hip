@@ -1027,9 +1027,11 @@ struct HistLds
   uint2 lInfo[kMaxCellsPerBlock];
   /* [bin][copy]: a vote goes to copy = lane & 31, i.e. LDS bank = copy: the 32 lanes the LDS serves per
    * cycle never collide, whatever their bins (a camera row sweeping one plateau puts all 64 lanes in one bin) */
-  unsigned int lh[kMaxBins * kHistCopies];
+  alignas(16) unsigned int lh[kMaxBins * kHistCopies];      /* 16-byte aligned: cleared and summed four copies at a time */
   unsigned int lNonZero;
 };
+static_assert(kHistCopies % 8 == 0 && (kMaxBins * kHistCopies / 4) % kThreads == 0 && kMaxBins * 2 == kThreads,
+              "hist_block clears the LDS histogram in 16-byte pieces and sums a bin's copies with two threads");
 
 /* SPEC (single pass): the block also rasters the points of the bins that have a plane (FrameState::specPlane, k_predict) into
  * the frame's planes, as k_raster does for the plateaus' bins: pixel (image_pixel), the plane's z sum and out-of-image count. */
@@ -1073,8 +1075,9 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
   const int begin = chunkIdx * chunkPoints;
   const int end = min(begin + chunkPoints, P.nPoints);
 
-  for(int i = tid; i < kMaxBins * kHistCopies; i += kThreads)
-    lh[i] = 0;
+  /* (16 bytes per store: a block's prologue and epilogue are ~14 % of K1's vector instructions, round 6) */
+  for(int i = tid; i < kMaxBins * kHistCopies / 4; i += kThreads)
+    reinterpret_cast<uint4 *>(lh)[i] = make_uint4(0u, 0u, 0u, 0u);
   if(tid == 0)
   {
     lNonZero = 0;
@@ -1459,13 +1462,21 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
         atomicAdd(&fs.planeOob[tid], SL.oob[tid]);
     }
   }
-  for(int b = tid; b < P.nBins; b += kThreads)
   {
+    /* the bins' copies summed by all four waves: two threads per bin, half of the copies each in 16-byte reads (taken in an order
+     * that changes from bin to bin: the bins' rows lie a whole number of bank cycles apart), the halves joined by one DPP step.
+     * (Round 5: one thread per bin and 32 four-byte reads - the work of two waves of the four.) */
+    const int b = tid >> 1, half = tid & 1;
     unsigned int s = 0;
+    const uint4 *row = reinterpret_cast<const uint4 *>(lh + b * kHistCopies + half * (kHistCopies / 2));
 #pragma unroll
-    for(int k = 0; k < kHistCopies; k++)
-      s += lh[b * kHistCopies + ((k + tid) & (kHistCopies - 1))];      /* rotated: conflict-free */
-    if(s)
+    for(int k = 0; k < kHistCopies / 8; k++)
+    {
+      const uint4 q = row[(k + b) & (kHistCopies / 8 - 1)];
+      s += (q.x + q.y) + (q.z + q.w);
+    }
+    s += static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(s), 0xb1, 0xf, 0xf, false));     /* quad_perm [1, 0, 3, 2]: the neighbour's half */
+    if(half == 0 && b < P.nBins && s)
       atomicAdd(&fs.histAcc[b], s);
   }
   if(tid == 0 && lNonZero)
