@@ -43,6 +43,11 @@ def dump(obj, path, stamp):
     json.dump(obj, open(path, "w"), indent=1)
 
 
+def newest(paths):
+    """the most recent of the files a pattern found, as a one-element list (a tag collected twice leaves both runs' directories)"""
+    return [max(paths, key=os.path.getmtime)] if paths else []
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
@@ -51,7 +56,7 @@ def main():
     stamp = load_stamp(src)
     if stamp is not None:
         json.dump(stamp, open(os.path.join(dst, tag + "_stamp.json"), "w"), indent=1)       # for the csv summaries, which cannot carry it
-    stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+    stats = newest(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
         # what bench.py reports as roofline.frac_profiles (round 6): K1's rocprofv3 average of this pass, and on which GPU
@@ -71,8 +76,8 @@ def main():
                      os.path.join(dst, "k1_rocprof.json"), stamp)
                 break
     out = {"note": "per launch = per batch of 1024 frames of 1024x768 points; bytes", "kernels": {}}
-    fetch = glob.glob(os.path.join(src, "fetch", "*", "*counter_collection.csv"))
-    write = glob.glob(os.path.join(src, "write", "*", "*counter_collection.csv"))
+    fetch = newest(glob.glob(os.path.join(src, "fetch", "*", "*counter_collection.csv")))
+    write = newest(glob.glob(os.path.join(src, "write", "*", "*counter_collection.csv")))
     f = per_kernel(fetch[0], "FETCH_SIZE") if fetch else {}
     w = per_kernel(write[0], "WRITE_SIZE") if write else {}
     for k in sorted(set(f) | set(w)):
@@ -102,11 +107,11 @@ def main():
         b = os.path.join(src, name)
         if os.path.exists(b) and os.path.getsize(b):
             shutil.copy(b, os.path.join(dst, tag + to))
-    stats = glob.glob(os.path.join(src, "trace_fhd", "*", "*kernel_stats.csv"))
+    stats = newest(glob.glob(os.path.join(src, "trace_fhd", "*", "*kernel_stats.csv")))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats_fhd_stress.csv"))
     # BASELINE configs[4]: HBM read traffic and bandwidth fraction of the streaming kernels on the FHD stress batch (256 frames)
-    fetch_fhd = glob.glob(os.path.join(src, "fetch_fhd", "*", "*counter_collection.csv"))
+    fetch_fhd = newest(glob.glob(os.path.join(src, "fetch_fhd", "*", "*counter_collection.csv")))
     if fetch_fhd and stats:
         ff = per_kernel(fetch_fhd[0], "FETCH_SIZE")
         avg_ns = {}
