@@ -10,7 +10,7 @@ i=0
 for envs in "$@"; do
   i=$((i+1))
   wl="xga_batch"; case "$envs" in *FHD*) wl="fhd_stress";; esac
-  env $(echo $envs | sed 's/FHD//') timeout 200 python bench.py --workload $wl --steps 8 --warmup 2 --no-cpu > $OUT/b$i.json 2> $OUT/b$i.err
+  env $(echo $envs | sed 's/FHD//') timeout 200 python bench.py --workload $wl --steps 8 --warmup 2 --no-cpu --no-secondary > $OUT/b$i.json 2> $OUT/b$i.err
   python - "$OUT/b$i.json" "$envs" <<'PY'
 import json, sys
 try:

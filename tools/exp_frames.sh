@@ -9,7 +9,7 @@ i=0
 for spec in "$@"; do
   i=$((i+1))
   f=${spec%% *}; envs=${spec#* }; [ "$envs" = "$spec" ] && envs="A=1"
-  env $envs timeout 200 python bench.py --frames $f --steps 20 --warmup 3 --no-cpu --no-hostfed --no-latency > $OUT/b$i.json 2> $OUT/b$i.err
+  env $envs timeout 200 python bench.py --frames $f --steps 20 --warmup 3 --no-cpu --no-hostfed --no-latency --no-secondary > $OUT/b$i.json 2> $OUT/b$i.err
   python - "$OUT/b$i.json" "$spec" <<'PY'
 import json, sys
 try:

@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/sp_trace; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 if [ -n "$1" ]; then export SSD_HIP_LIB=$R/stair-step-detector_amd/$1/libssd_hip.so; fi
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --batches-in-flight 1 --no-cpu --no-hostfed --no-latency > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --batches-in-flight 1 --no-cpu --no-hostfed --no-latency --no-secondary > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
 cd $R
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'

@@ -7,6 +7,6 @@ cd $GRAFT_REPO_ROOT
 show='import json,sys; d=json.load(sys.stdin); print(round(d["value"]), round(d["ms_per_step"],3), {k: round(v,3) for k,v in d["stage_ms"].items()})'
 for cp in 16384 24576 32768 49152 65536; do
   echo "== SSD_CHUNK_POINTS=$cp"
-  SSD_CHUNK_POINTS=$cp python bench.py --steps 10 --warmup 2 --no-cpu 2>/dev/null | python -c "$show"
-  SSD_CHUNK_POINTS=$cp python bench.py --workload fhd_stress --steps 10 --warmup 2 --no-cpu 2>/dev/null | python -c "$show"
+  SSD_CHUNK_POINTS=$cp python bench.py --steps 10 --warmup 2 --no-cpu --no-secondary 2>/dev/null | python -c "$show"
+  SSD_CHUNK_POINTS=$cp python bench.py --workload fhd_stress --steps 10 --warmup 2 --no-cpu --no-secondary 2>/dev/null | python -c "$show"
 done
