@@ -225,7 +225,14 @@ __device__ __forceinline__ void load_points_full(const float *__restrict__ base,
   if(SRC == kSrcF3Aligned)
   {
     const float4 *q = reinterpret_cast<const float4 *>(base + 3 * static_cast<size_t>(idx0));
+#ifdef SSD_NT_LOADS           /* tools: the frames read as a stream that is not to be kept in the caches */
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v *qv = reinterpret_cast<const f4v *>(q);
+    const f4v av = __builtin_nontemporal_load(qv), bv = __builtin_nontemporal_load(qv + 1), cv = __builtin_nontemporal_load(qv + 2);
+    const float4 a = make_float4(av.x, av.y, av.z, av.w), b = make_float4(bv.x, bv.y, bv.z, bv.w), c = make_float4(cv.x, cv.y, cv.z, cv.w);
+#else
     const float4 a = q[0], b = q[1], c = q[2];
+#endif
     v[0] = F3{ a.x, a.y, a.z };
     v[1] = F3{ a.w, b.x, b.y };
     v[2] = F3{ b.z, b.w, c.x };
@@ -1487,7 +1494,14 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
     const int n = nStore >= 0 ? nStore : it * kCellsPerTile;
     for(int i = tid; i < n; i += kThreads)
       if(SSD_CHK(16, static_cast<size_t>(begin / kCell) + i, tileMaskStride) && SSD_CHK(17, i, kMaxCellsPerBlock))
+#ifdef SSD_NT_STORES          /* tools: the records written past the caches */
+        {
+          __builtin_nontemporal_store(lInfo[i].x, &dst[i].x);
+          __builtin_nontemporal_store(lInfo[i].y, &dst[i].y);
+        }
+#else
         dst[i] = lInfo[i];
+#endif
   }
 }
 

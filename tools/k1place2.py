@@ -33,6 +33,6 @@ for b in range(2):
             hip.hipMemsetAsync(ctypes.c_void_p(addr), 0, ctypes.c_size_t(96 << 20), None)
         hip.hipDeviceSynchronize()
         wr = (time.perf_counter() - c0) / 20 * 1e3
-        print("  records 0x%x  delta %+d MiB  K1 %.3f %-4s  region alone: read %.1f GB/s  memset %.1f GB/s" % (addr, (addr - buf.ptr) >> 20, min(t), "SLOW" if min(t) > 1.70 else "", (96 << 20) / rd / 1e6, (96 << 20) / wr / 1e6), flush=True)
+        print("  records 0x%x  delta %+d MiB  K1 %.3f %-4s  region alone: read %.1f GB/s  memset %.1f GB/s" % (addr, (addr - buf.ptr) >> 20, min(t), "SLOW" if min(t) > float(os.environ.get("K1_SLOW_MS", "1.87")) else "", (96 << 20) / rd / 1e6, (96 << 20) / wr / 1e6), flush=True)
     det.close(); buf.free()
     ssd.hooks_lib().ssd_test_record_release()
