@@ -355,6 +355,8 @@ def main():
                          "(the bench enqueues ahead of its fetches); 1 (or 0, the library's default) = strictly one batch at a time in stream "
                          "order — what the profiling passes use, so that a kernel's traced duration is its own")
     ap.add_argument("--two-pass", action="store_true", help="A/B: ssd_set_single_pass(h, 0): K1 then k_raster over every frame, as before round 4's single pass")
+    ap.add_argument("--pad-mib", type=int, default=0, help="tools: hold this many MiB of device memory allocated BEFORE the frames (K1 has two states by where the "
+                    "input buffer lands, profiles/r06_box_spread.txt; a pad moves it); 0 = none")
     ap.add_argument("--prewarm-seconds", type=float, default=0.5,
                     help="untimed load in front of the W warm-up steps (an idle device needs more than a few steps to reach its clocks)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -407,6 +409,7 @@ def main():
     depth_in = args.input == "depth16"
     if depth_in:
         frame_bytes = W * H * 2
+    pad_hold = torch.empty(args.pad_mib << 20, dtype=torch.uint8, device="cuda") if args.pad_mib > 0 else None       # tools: see --pad-mib
     frames = torch.empty(F * frame_bytes, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     det = ssd.Detector(cfg, trans, device)
@@ -630,6 +633,8 @@ def main():
             try:
                 j = json.load(open(kp))
                 out["roofline"]["frac_profiles"] = j["frac"]
+                if j.get("other_rocprof_passes_same_library"):
+                    out["roofline"]["frac_profiles_other_passes"] = j["other_rocprof_passes_same_library"]
                 out["roofline"]["frac_profiles_source"] = {"file": "profiles/k1_rocprof.json", "avg_launch_ms": j["avg_launch_ms"], "gpu": j.get("gpu"),
                                                            "summary": j.get("summary"), "stale": counters_stamp("k1_rocprof.json", lib_sha)[1]}
                 if j["frac"] > 0 and abs(out["roofline"]["frac"] - j["frac"]) / j["frac"] > 0.03:

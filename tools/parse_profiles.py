@@ -70,7 +70,14 @@ def main():
                 except Exception:
                     pass
                 alg = 12.0 * 1024 * 768 * 1024
-                dump({"kernel": r["Name"].split("(")[0].replace("void ", ""), "calls": int(r["Calls"]), "avg_launch_ms": avg_ms,
+                keep = {}
+                try:        # further passes recorded by hand for the same library (tools/rocprof_states.sh) stay with it
+                    old = json.load(open(os.path.join(dst, "k1_rocprof.json")))
+                    if stamp is not None and (old.get("stamp") or {}).get("lib_sha256") == stamp.get("lib_sha256") and "other_rocprof_passes_same_library" in old:
+                        keep = {"other_rocprof_passes_same_library": old["other_rocprof_passes_same_library"]}
+                except Exception:
+                    pass
+                dump({**keep, "kernel": r["Name"].split("(")[0].replace("void ", ""), "calls": int(r["Calls"]), "avg_launch_ms": avg_ms,
                       "algorithmic_bytes_per_launch": alg, "frac": alg / (avg_ms * 1e-3) / 8e12, "gpu": gpu,
                       "summary": "profiles/%s_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --batches-in-flight 1 ...)" % tag},
                      os.path.join(dst, "k1_rocprof.json"), stamp)
