@@ -987,10 +987,13 @@ __device__ __forceinline__ void row_reduce_cell(unsigned int &groups, float &x0,
 /* the cell's box from the extremes of d: rn(d * 256 + boxLo / boxHi) saturated to 0 .. 255, one byte each (ssd_prexy.h) */
 __device__ __forceinline__ unsigned int cell_box_from_d(const PreXY &Q, float x0, float x1, float y0, float y1)
 {
-  unsigned int box = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(x0, 256.0f, Q.boxLo), 0u, 0u);
-  box = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(x1, 256.0f, Q.boxHi), 1u, box);
-  box = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(y0, 256.0f, Q.boxLo), 2u, box);
-  box = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(y1, 256.0f, Q.boxHi), 3u, box);
+  /* (x0, x1) and (y0, y1) scaled and shifted by one packed FMA each */
+  const f32x2 scale = f32x2{ 256.0f, 256.0f }, shift = f32x2{ Q.boxLo, Q.boxHi };
+  const f32x2 bx = __builtin_elementwise_fma(f32x2{ x0, x1 }, scale, shift), by = __builtin_elementwise_fma(f32x2{ y0, y1 }, scale, shift);
+  unsigned int box = __builtin_amdgcn_cvt_pk_u8_f32(bx.x, 0u, 0u);
+  box = __builtin_amdgcn_cvt_pk_u8_f32(bx.y, 1u, box);
+  box = __builtin_amdgcn_cvt_pk_u8_f32(by.x, 2u, box);
+  box = __builtin_amdgcn_cvt_pk_u8_f32(by.y, 3u, box);
   return box;
 }
 
@@ -1130,14 +1133,14 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
     double wz = (P.a[6] * x + P.a[7] * y) + P.a[8] * z;
     wz = wz + P.b[2];
     const float px = __builtin_fmaf(dj.x, X.fW, X.fHalfW), py = __builtin_fmaf(dj.y, X.fNegH, X.fHalfH);
-    const float gx = __builtin_amdgcn_fractf(px) - 0.5f, gy = __builtin_amdgcn_fractf(py) - 0.5f;
+    const f32x2 gg = f32x2{ __builtin_amdgcn_fractf(px), __builtin_amdgcn_fractf(py) } + f32x2{ -0.5f, -0.5f };      /* one packed add */
     const float hp = __builtin_fmaf(absmax3(q.x, q.y, q.z), X.pxNegK, X.pxH0);
     unsigned int ix = cvt_u32_f32(px), iy = cvt_u32_f32(py);
     bool inside = true;
 #if defined(SSD_SABOTAGE_PRE) && (SSD_SABOTAGE_PRE & 2)   /* tools: the band around the pixel edges NOT handed to the doubles */
     if(false)
 #else
-    if(!(absmax2(gx, gy) < hp))
+    if(!(absmax2(gg.x, gg.y) < hp))
 #endif
     {
       /* rare: the doubles, and the image's bounds (quirk Q5) */
@@ -1178,40 +1181,49 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
     for(int j = 0; j < kPts; j++)
     {
       const F3 p{ v[j].x, v[j].y, v[j].z };
+      /* The tests' outcomes are kept as the wave's 64-bit lane masks (one v_cmp each, straight into a scalar register pair) and combined
+       * on the scalar unit; as `bool`s the compiler evaluated two of them in BOTH polarities - a second v_cmp each, 25 M vector
+       * instructions per launch - where one s_andn2 does.  __builtin_amdgcn_inverse_ballot_w64 turns a mask back into the lanes' branch. */
       /* pointcloud.cpp:143-146, counted per wave on the scalar unit */
-      const bool valid = p.z > 0.0f;
-      nz += static_cast<unsigned int>(__popcll(__ballot(valid)));
+      const unsigned long long mValid = __ballot(p.z > 0.0f);
+      nz += static_cast<unsigned int>(__popcll(mValid));
       /* x / y in single precision (round 5): inside for sure, outside for sure (M > hi), or the band between them (and NaNs) */
       f32x2 d = pre_xy(Q, c3xy, p.x, p.y, p.z);
       const float M = absmax2(d.x, d.y);
-      bool inxy = M < Q.lo;
-      bool maybexy = !(M > Q.hi);
+      unsigned long long mInxy = __ballot(M < Q.lo);
+      unsigned long long mMaybexy = ~__ballot(M > Q.hi);
       const float M3 = absmax3(p.x, p.y, p.z);
       if constexpr(CHECKS)
       {
         /* unless make_pre_xy() showed that larger inputs cannot read "inside" */
-        const bool far = Q.checkInput && !(M3 <= Q.maxInput);
-        inxy = inxy & !far;
-        maybexy = maybexy | far;
+        const unsigned long long mFar = Q.checkInput ? ~__ballot(M3 <= Q.maxInput) : 0ull;
+        mInxy &= ~mFar;
+        mMaybexy |= mFar;
       }
       /* z in single precision (round 6, make_pre_z()): t = the height above zMin in bins.  Farther from every integer than the
        * bound for this point's magnitude: the bin is floor(t) and the z range is 0 < t < zTop, as the doubles would say */
       const float t = __builtin_fmaf(Q.zc[0], p.x, __builtin_fmaf(Q.zc[1], p.y, __builtin_fmaf(Q.zc[2], p.z, zc3)));
       const float g = __builtin_amdgcn_fractf(t) - 0.5f;
       const float h = __builtin_fmaf(M3, Q.zNegK, zh0);
-      bool unsurez = !(__builtin_fabsf(g) < h);                          /* true for a NaN, and for a magnitude whose bound exceeds half a bin */
-      const bool inzf = __float_as_uint(t) < Q.zTopBits;                 /* +0 <= t < zTop on the bits (a negative t has the sign bit) */
+      unsigned long long mSurez = __ballot(__builtin_fabsf(g) < h);      /* not for a NaN, nor for a magnitude whose bound exceeds half a bin */
+      const unsigned long long mInz = __ballot(__float_as_uint(t) < Q.zTopBits);     /* +0 <= t < zTop on the bits (a negative t has the sign bit) */
       if constexpr(CHECKS)
-        unsurez = unsurez | (Q.zCheckTop && !(__builtin_fabsf(t - Q.zTop) > 0.5f - h));     /* the range's upper end is no bin edge: its own band */
+      {
+        if(Q.zCheckTop)
+          mSurez &= __ballot(__builtin_fabsf(t - Q.zTop) > 0.5f - h);    /* the range's upper end is no bin edge: its own band */
+      }
 #if defined(SSD_SABOTAGE_PRE) && (SSD_SABOTAGE_PRE & 1)   /* tools: the band around the bin edges NOT handed to the doubles - the tests built for it must fail */
-      unsurez = false;
+      mSurez = ~0ull;
 #endif
       unsigned int b = cvt_u32_f32(t);
       /* in range for sure; or possibly in range - neither test says "outside for sure" - with a test unsure: those take the doubles */
-      bool in = valid & inzf & inxy & !unsurez;
-      if(valid & maybexy & (unsurez | (inzf & !inxy)))
+      const unsigned long long mInSure = mValid & mInz & mInxy & mSurez;
+      const unsigned long long mSlow = mValid & mMaybexy & (~mSurez | (mInz & ~mInxy));
+      unsigned long long mIn = mInSure;
+      if(mSlow != 0ull)
       {
-        /* rare (one lane in thousands): the reference's arithmetic, all of it - world_point_flat's rows and compares, height_bin */
+        /* rare (one wave slot in fifty; a wave-uniform branch, so that the mask stays a scalar): the reference's arithmetic, all of it -
+         * world_point_flat's rows and compares, height_bin - evaluated by the whole wave, taken by the lanes it is for */
         const K1ConstsLds c = k1_consts(L.kc);
         const double x = p.x, y = p.y, z = p.z;
         double wx = (c->a[0] * x + c->a[1] * y) + c->a[2] * z;
@@ -1220,12 +1232,16 @@ __device__ __forceinline__ void hist_block(HistLds &L, SPECLDS &SL, const float 
         wx = wx + c->b[0];
         wy = wy + c->b[1];
         wz = wz + c->b[2];
-        in = (wx > c->xMin) & (wx < c->xMax) & (wy > c->yMin) & (wy < c->yMax) & (wz > c->zMin) & (wz < c->zMax);
-        b = static_cast<unsigned int>(static_cast<int>((wz - c->zMin) * c->recip));      /* height_bin; meaningless for a point out of range, as is d */
-        d.x = static_cast<float>((wx - c->xMin) * c->boxX * 0.00390625 - 0.5);
-        d.y = static_cast<float>((wy - c->yMin) * c->boxY * 0.00390625 - 0.5);
+        mIn |= mSlow & __ballot((wx > c->xMin) & (wx < c->xMax) & (wy > c->yMin) & (wy < c->yMax) & (wz > c->zMin) & (wz < c->zMax));
+        const bool mine = __builtin_amdgcn_inverse_ballot_w64(mSlow);
+        const unsigned int bD = static_cast<unsigned int>(static_cast<int>((wz - c->zMin) * c->recip));      /* height_bin; meaningless for a point out of range, as is d */
+        const float dxD = static_cast<float>((wx - c->xMin) * c->boxX * 0.00390625 - 0.5);
+        const float dyD = static_cast<float>((wy - c->yMin) * c->boxY * 0.00390625 - 0.5);
+        b = mine ? bD : b;
+        d.x = mine ? dxD : d.x;
+        d.y = mine ? dyD : d.y;
       }
-      if(in)
+      if(__builtin_amdgcn_inverse_ballot_w64(mIn))
       {
         if(SSD_CHK(11, b, P.nBins))
           atomicAdd(mine + b * kHistCopies, 1u);                          /* ++hist[bin], pointcloud.cpp:199-202 */
