@@ -54,3 +54,16 @@ def test_the_disassembly_is_the_shipped_kernels(kernels):
         _one(kernels, fragment)
     for fragment in ("6k_histILi0ELb0EE", "6k_histILi1ELb1EE", "6k_histILi2ELb0EE", "9k_predictILi1EE", "7k_peaks", "7k_quads"):
         assert any(fragment in n for n in kernels), fragment
+
+
+# Round 6: the hot instantiations of K1 keep no register in scratch memory and reload no scalar from a vector register inside their
+# loops (profiles/r06_kernel_resources.txt; the round's 948 -> 841 M vector instructions rest on it, and one more live value in the
+# tile loop brings the spills back: DESIGN.md section 3).  The counts below are whole-kernel (prologue and epilogue included).
+@pytest.mark.parametrize("fragment,lanes_moved", [("13k_hist_planesILi1ELb0ELb0EE", 64),   # XGA single pass: 44 when written
+                                                   ("13k_hist_planesILi1ELb1ELb0EE", 72),   # FHD / VGA strips: 51
+                                                   ("6k_histILi1ELb0EE", 8)])               # two passes: 0
+def test_k1_keeps_its_registers(kernels, fragment, lanes_moved):
+    ins = _one(kernels, fragment)
+    assert not [l for l in ins if "scratch_" in l], "K1 spills vector registers to scratch memory"
+    moved = [l for l in ins if "v_readlane_b32" in l or "v_writelane_b32" in l]
+    assert len(moved) <= lanes_moved, "%d v_readlane / v_writelane: scalar registers are being spilled in K1's loops" % len(moved)
