@@ -25,6 +25,12 @@ int ssd_test_sort_device(int device, const double *dist, int n, int32_t *perm);
 int ssd_test_quad_device(int device, const double quad[8], const double *pts_xy, int n, uint8_t *inside, int *err);
 /* the same code (csrc/ssd_quadtest.h: build_quad_test, the constant cell, quad_test) compiled for the host: runs without a GPU */
 int ssd_test_quad_host(const double quad[8], const double *pts_xy, int n, uint8_t *inside, int *err);
+/* test hook (host): k_inquad's single-precision edge tests (csrc/ssd_quadtest.h: build_quad_edges) for one quadrilateral over a measuring
+ * range (x_min, x_max, y_min, y_max, z_min, z_max) and a calibration, on n camera points (x, y, z floats): consts = gx[4], gy[4], g2[4], m
+ * (infinity: switched off for this quadrilateral), dK, dE0; cls[i] = +1 inside for sure / -1 outside for sure / 0 ask the doubles, from the d
+ * K1's pre-filter computes; world_xy[2 i ..] = the reference's world x, y of the point, in_range_xy[i] = its x / y range test */
+int ssd_test_quad_edges_host(const double quad[8], const double range[6], const double a[9], const double b[3], const float *pts_xyz, int n,
+                             float consts[15], int8_t *cls, double *world_xy, uint8_t *in_range_xy, int *err);
 /* test hook: BestLine (segmentation.cpp:409-487) over n points (x, y int32 pairs) with the kernels' residual code
  * (csrc/ssd_bestline.h) compiled for the host; form 0 = any list, 1 = keys in passes of four (n <= 128), 2 = one pass (n <= 64) */
 int ssd_test_best_line_host(const int32_t *pts_xy, int n, int form, int32_t line[3]);

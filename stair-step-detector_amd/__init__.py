@@ -157,7 +157,7 @@ SOURCE_EXPORTS = [
 # libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
 HOOK_EXPORTS = [
     "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_ground_image", "ssd_test_line_host", "ssd_test_intersect_host", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_best_line_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
-    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_test_single_pass", "ssd_test_plane_pool", "ssd_test_single_pass_stats", "ssd_test_single_pass_frame", "ssd_test_single_pass_sample", "ssd_test_predict_table_host", "ssd_test_prexy_host", "ssd_test_prez_host", "ssd_test_record_offset", "ssd_test_record_realloc", "ssd_test_record_realloc_sized", "ssd_test_record_release", "ssd_testhooks_last_error",
+    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_test_single_pass", "ssd_test_plane_pool", "ssd_test_single_pass_stats", "ssd_test_single_pass_frame", "ssd_test_single_pass_sample", "ssd_test_predict_table_host", "ssd_test_prexy_host", "ssd_test_prez_host", "ssd_test_quad_edges_host", "ssd_test_record_offset", "ssd_test_record_realloc", "ssd_test_record_realloc_sized", "ssd_test_record_release", "ssd_testhooks_last_error",
 ]
 SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
 HOOKS_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_testhooks.so")
@@ -284,6 +284,8 @@ def hooks_lib():
     L.ssd_test_predict_table_host.argtypes = [vp, i32, i32, i32, vp]
     L.ssd_test_prexy_host.argtypes = [vp, vp, vp, vp]
     L.ssd_test_prez_host.argtypes = [vp, vp, vp, C.c_double, i32, i32, vp]
+    L.ssd_test_quad_edges_host.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.ssd_test_quad_edges_host.restype = i32
     L.ssd_test_record_offset.argtypes = [vp, C.c_size_t]
     L.ssd_test_record_realloc.argtypes = [vp]
     L.ssd_test_record_realloc.restype = C.c_ulonglong
@@ -868,6 +870,26 @@ def prez_host(x_min, x_max, y_min, y_max, z_min, z_max, a, b, height_interval=0.
     o = np.array(list(out), dtype=np.float32)
     return dict(zc=o[:4], z_neg_k=o[4], z_h0=o[5], z_top=o[6], z_check_top=bool(o[7]), f_w=o[8], f_half_w=o[9], f_neg_h=o[10], f_half_h=o[11],
                 px_neg_k=o[12], px_h0=o[13], recip=float(o[14]))
+
+
+def quad_edges_host(quad, x_min, x_max, y_min, y_max, z_min, z_max, a, b, pts_xyz):
+    """test hook: k_inquad's single-precision edge tests of one quadrilateral (csrc/ssd_quadtest.h: build_quad_edges) on camera points ->
+    dict(err, gx, gy, g2, m, d_k, d_e0, cls = int8[n] (+1 / -1 / 0), world_xy = float64[n, 2], in_range_xy = uint8[n])"""
+    q = np.ascontiguousarray(quad, dtype=np.float64).reshape(8)
+    rng = (C.c_double * 6)(x_min, x_max, y_min, y_max, z_min, z_max)
+    aa = (C.c_double * 9)(*[float(v) for v in np.asarray(a, dtype=np.float64).reshape(9)])
+    bb = (C.c_double * 3)(*[float(v) for v in np.asarray(b, dtype=np.float64).reshape(3)])
+    p = np.ascontiguousarray(pts_xyz, dtype=np.float32).reshape(-1, 3)
+    consts = (C.c_float * 15)()
+    cls = np.zeros(len(p), dtype=np.int8)
+    wxy = np.zeros((len(p), 2), dtype=np.float64)
+    inr = np.zeros(len(p), dtype=np.uint8)
+    err = C.c_int(0)
+    _check(hooks_lib().ssd_test_quad_edges_host(q.ctypes.data_as(C.c_void_p), rng, aa, bb, p.ctypes.data_as(C.c_void_p), len(p), consts,
+                                               cls.ctypes.data_as(C.c_void_p), wxy.ctypes.data_as(C.c_void_p), inr.ctypes.data_as(C.c_void_p),
+                                               C.byref(err)), "hooks")
+    o = np.array(list(consts), dtype=np.float32)
+    return dict(err=err.value, gx=o[0:4], gy=o[4:8], g2=o[8:12], m=o[12], d_k=o[13], d_e0=o[14], cls=cls, world_xy=wxy, in_range_xy=inr)
 
 
 def prexy_host(x_min, x_max, y_min, y_max, z_min, z_max, a, b):

@@ -91,6 +91,9 @@ struct PreXY
   unsigned int zTopBits;                      /* bits of zTop: the sure point is in the z range iff bits(t) < zTopBits (t >= +0 and t < zTop) */
   float zTop;                                 /* (zMax - zMin) / heightInterval: the integer next to it (zCheckTop == 0) or itself rounded (1) */
   int zCheckTop;                              /* the z range does not end within 2^-20 of a bin edge: |t - zTop| <= e(M) is unsure too (two more instructions per point) */
+  /* the bound of d itself, following the point's magnitude M: |d - D| <= dK * M + dE0 in either coordinate, also for a d that came
+   * from the doubles (rounded once) - what k_inquad's single-precision edge tests add to their own margin (QuadEdgesF) */
+  float dK, dE0;
 };
 
 struct PixelParams
@@ -179,6 +182,17 @@ struct QuadGridSegs
   int ok, pad;
 };
 
+/* A live quadrilateral's four edges for k_inquad's per-POINT test in single precision (round 6; ssd_quadtest.h,
+ * build_quad_edges): on the centred, normalised coordinates d of the range test (PreXY), e_s = gx[s] d.x + gy[s] d.y + g2[s]
+ * with |gx[s]| + |gy[s]| = 1, positive inside.  A point whose smallest e_s exceeds m + (the bound of d for its magnitude) is
+ * inside by the reference's test, one whose smallest e_s lies below minus that is outside; the band between takes the
+ * reference's doubles.  m = +infinity: single precision says nothing about this quadrilateral (every point takes the doubles). */
+struct alignas(16) QuadEdgesF
+{
+  float gx[4], gy[4], g2[4];
+  float m, pad[3];
+};
+
 struct PlateauState
 {
   int peakBin, binLo, binHi;       /* Plateau::height, chosen pair */
@@ -218,6 +232,7 @@ struct FrameState
    * ground last); lutLive: height bin -> slot; liveGroups: the groups of 4 height bins of the slot's plateau */
   QuadTest qtLive[kMaxLive];
   QuadGridSegs segLive[kMaxLive];
+  QuadEdgesF edgeLive[kMaxLive];   /* the same edges for k_inquad's per-point test in single precision (build_quad_edges) */
   unsigned char liveAcc[kMaxLive];
   int4 liveBox[kMaxLive];          /* thresholds of k_inquad's cell classification on K1's box grid (k_quads: live_box_thresholds) */
   unsigned char lutLive[kMaxBins];

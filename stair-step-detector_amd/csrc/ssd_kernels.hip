@@ -134,7 +134,7 @@ __device__ __forceinline__ int height_bin(const PointParams &P, double wz)
 /* k_inquad: 8 waves per SIMD although that costs it 48 scalar-register spills (v_readlane in the loop): 7 / 6 waves spill
  * 33 / 10 and run 3 % / 10 % slower (measured, XGA batch) */
 #ifndef SSD_K4_WAVES
-#define SSD_K4_WAVES 8
+#define SSD_K4_WAVES 5
 #endif
 #ifndef SSD_K2_WAVES
 #define SSD_K2_WAVES 6
@@ -940,6 +940,12 @@ __device__ __forceinline__ unsigned int cvt_u32_f32(float a)
 {
   unsigned int r;
   asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(a));
+  return r;
+}
+__device__ __forceinline__ float min3_f32(float a, float b, float c)
+{
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
 __device__ __forceinline__ float min_f32(float a, float b)
@@ -3024,6 +3030,12 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
   const int firstValid = validMask ? __ffsll(static_cast<long long>(validMask)) - 1 : -1;
   const bool groundLane = lane == kGroundAcc && firstValid >= 0 && groundInd >= 0;
   int err = 0;
+  /* the live tests once more in LDS, for the check of their maps (quad_cell_unsound) that all lanes share below */
+  __shared__ QuadTest sT[kMaxLive];
+  __shared__ QuadEdgesD sW[kMaxLive];
+  __shared__ unsigned int sBad[kMaxLive];
+  QuadEdgesF ef;
+  int mySlot = -1;
   SSD_PHASE_IF(lane == firstValid, 1, 1);
   {
     /* calcGroundQuadrilateral (pointcloud.cpp:489-512) from the front edge of the first valid step */
@@ -3075,6 +3087,12 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
         QuadGridSegs sg;
         build_grid_segs(t, P.pt.xMin, P.pt.yMin, P.pt.boxX, P.pt.boxY, sg);
         fs.segLive[slot] = sg;
+        QuadEdgesD w;
+        quad_edges_coeffs(t, sg.ok, P.pt.xMin, P.pt.xMax, P.pt.yMin, P.pt.yMax, w, ef);
+        sT[slot] = t;
+        sW[slot] = w;
+        sBad[slot] = 0u;
+        mySlot = slot;
         fs.liveBox[slot] = live_box_thresholds(t, groundLane, P.pt);
         fs.liveAcc[slot] = static_cast<unsigned char>(lane);
         /* the groups of 4 height bins this accumulator's plateau occupies (matched against the cells' masks) */
@@ -3085,6 +3103,25 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
           groups |= 1u << (b / kBinsPerGroup);
         fs.liveGroups[slot] = groups;
       }
+    }
+  }
+  {
+    /* k_inquad's single-precision edge tests (ssd_quadtest.h, build_quad_edges): the reference's map of each live quadrilateral is
+     * checked cell by cell - nine cells each, dealt out to the wave's lanes (one lane doing its own quadrilateral's nine: 60 us
+     * per frame on top of the kernel's 25) - and a quadrilateral whose map accepts points beyond an edge gets no margin */
+    const int nL = __popcll(__ballot(mySlot >= 0));
+    __syncthreads();
+    for(int item = lane; item < nL * 9; item += 64)
+    {
+      const int sl = item / 9, cell = item - 9 * sl;
+      if(sW[sl].fine != 0 && quad_cell_unsound(sT[sl], sW[sl], cell / 3, cell % 3))
+        atomicOr(&sBad[sl], 1u);
+    }
+    __syncthreads();
+    if(mySlot >= 0)
+    {
+      ef.m = quad_edges_margin(sW[mySlot], sBad[mySlot] != 0u);
+      fs.edgeLive[mySlot] = ef;
     }
   }
   SSD_PHASE_IF(lane == firstValid, 1, 5);
@@ -3190,7 +3227,9 @@ struct InquadLds
   ImageBox box[1];
   QuadTest qts[kMaxLive];                       /* FrameState::qtLive: slot k = accumulator liveAcc[k] */
   QuadGridSegs segs[kMaxLive];                  /* FrameState::segLive */
-  unsigned char lut[kMaxBins];                  /* bin -> live slot */
+  QuadEdgesF edges[kMaxLive + 1];               /* FrameState::edgeLive with PreXY::dE0 folded into m; row kMaxLive ("no quadrilateral"): m = infinity */
+  K1Consts kc;                                  /* what only the rare double-precision paths need (as K1) */
+  unsigned char lut[kMaxBins];                  /* bin -> live slot, kMaxLive = none */
   unsigned long long lsum[kMaxLive][8];
   unsigned int lcnt[kMaxLive][8];
   unsigned int lOob;
@@ -3204,9 +3243,9 @@ struct InquadLds
   int stripMax[kMaxGroundStrips];               /* FrameState::groundStripMax as the block found it, raised by its own centre-column pixels */
 };
 
-template<int SRC, bool FULL>
+template<int SRC, bool FULL, bool CHECKS>
 __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__restrict__ xyz, size_t strideFloats, const PointParams &P,
-                                             const PixelParams &X, FrameState *__restrict__ st,
+                                             const PreXY &Q, const PixelParams &X, FrameState *__restrict__ st,
                                              unsigned long long *__restrict__ groundImg,
                                              const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, const DepthSrc &D,
                                              const int frame, const int chunkIdx)
@@ -3243,6 +3282,12 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
   constexpr int qtWords = kMaxLive * static_cast<int>(sizeof(QuadTest) / 4), sgWords = kMaxLive * static_cast<int>(sizeof(QuadGridSegs) / 4);
   constexpr int qtPer = (qtWords + kThreads - 1) / kThreads, sgPer = (sgWords + kThreads - 1) / kThreads;
   unsigned int qtw[qtPer], sgw[sgPer];
+  constexpr int egWords = kMaxLive * static_cast<int>(sizeof(QuadEdgesF) / 4);
+  static_assert(sizeof(QuadEdgesF) == 64 && egWords + 16 <= 2 * kThreads, "two words of the edge table per thread");
+  float edgeMine[2];
+#pragma unroll
+  for(int k = 0; k < 2; k++)
+    edgeMine[k] = tid + k * kThreads < egWords ? reinterpret_cast<const float *>(fs.edgeLive)[tid + k * kThreads] : 0.0f;
   {
     /* the live quadrilateral tests as 32-bit words: the whole table, unconditionally — asking "how many are live?" first
      * would make every element two dependent round trips */
@@ -3265,9 +3310,27 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
     nLive = nLiveG;
     groundSlot = (nLiveG > 0 && groundActive) ? nLiveG - 1 : -1;     /* the ground is the last accumulator */
     L.nextGroup = 0;
+    K1Consts &c = L.kc;
+#pragma unroll
+    for(int i = 0; i < 9; i++)
+      c.a[i] = P.a[i];
+    c.b[0] = P.b[0]; c.b[1] = P.b[1]; c.b[2] = P.b[2];
+    c.xMin = P.xMin; c.xMax = P.xMax; c.yMin = P.yMin; c.yMax = P.yMax; c.zMin = P.zMin; c.zMax = P.zMax;
+    c.boxX = P.boxX; c.boxY = P.boxY;
+    c.recip = P.recip;
+    c.xToImage = X.xToImage; c.yToImage = X.yToImage;
   }
   if(tid < kMaxBins)
-    lut[tid] = lutMine;                         /* bin -> slot of the live table, 0xff = nothing to do for this bin */
+    lut[tid] = lutMine == 0xff ? static_cast<unsigned char>(kMaxLive) : lutMine;      /* bin -> slot of the live table, kMaxLive = nothing to do for this bin */
+  /* the edges for the single-precision test: a row per live quadrilateral, m (word 12) with the bound of d that does not depend on
+   * the point; the row behind them answers "not for sure" to everything - the row of a bin without quadrilateral */
+#pragma unroll
+  for(int k = 0; k < 2; k++)
+  {
+    const int w = tid + k * kThreads;
+    if(w < egWords + 16)
+      reinterpret_cast<float *>(L.edges)[w] = w < egWords ? ((w & 15) == 12 ? edgeMine[k] + Q.dE0 : edgeMine[k]) : ((w & 15) == 12 ? INFINITY : 0.0f);
+  }
   if(!FULL && tid < kMaxGroundStrips)
     L.stripMax[tid] = stripMaxMine;
   if(tid < kMaxLive)
@@ -3388,6 +3451,17 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
   };
   int g = grab();
   F3 v[kPts], vn[kPts];
+  /* the lane's copies of constants that are the SECOND scalar operand of an instruction (one is allowed), as in K1 */
+  float zc3 = Q.zc[3], zh0 = Q.zH0;
+  f32x2 c3xy = f32x2{ Q.c[3][0], Q.c[3][1] };
+  asm volatile("" : "+v"(zc3), "+v"(zh0), "+v"(c3xy));
+  /* the coarse test "can the bottom scan see this ground pixel, can it lie outside the image?" on d (see the loop): within two
+   * pixels of the border; a row from the strips' first less one on; a column within 3.5 of a strip's centre (strip: 2.5 either
+   * side), as the distance of (px + 2 - x0 + 50 - 2.5) / 50 from the nearest integer */
+  const float pixBorder = 0.5f - 2.0f / static_cast<float>(min(X.W, X.H));
+  const float pixRowThr = 0.5f - static_cast<float>(stripRow0 - 1) / static_cast<float>(X.H);
+  const float pixColA = static_cast<float>(X.W) * 0.02f;
+  const float pixColB = (0.5f * static_cast<float>(X.W) + static_cast<float>(2 - stripX0 + kGroundScanStep) - 2.5f) * 0.02f + 0.5f;
   if(g < nGroups)
     load_cell<SRC>(base, cell0, cellList, 4 * g + (lane >> 4), count, lane, P.nPoints, v, D);
   while(g < nGroups)
@@ -3400,56 +3474,180 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
     for(int j = 0; j < kPts; j++)
     {
       key[j] = kNoPixel;
-      /* few, flat decisions per point: every nested divergent exit costs exec-mask registers and copies at its
-       * join, more than the handful of predicated instructions it skips */
-      double wx, wy, wz;
-      const bool okz = world_z_flat(P, v[j], wz);
-      const int q = lut[okz ? height_bin(P, wz) : 0];
-      if(!(okz && q != 0xff))
-        continue;
+      const F3 p{ v[j].x, v[j].y, v[j].z };
+      /* Round 6: every decision in single precision first, as K1 takes them (ssd_prexy.h) - the x / y range, the z range and the
+       * height bin, then the quadrilateral as four half-planes on the same d (ssd_quadtest.h, build_quad_edges) - and kept as the
+       * wave's lane masks; the reference's doubles - all three rows, the compares, the bin, QuadrilateralTest with its box, map and
+       * segments - only for the points within a bound of a limit, a bin edge or a quadrilateral's edge: one wave-uniform block, a wave
+       * slot in twenty.  (Until here that test ran for every point of every cell an edge passes through, nested and divergent:
+       * 169 vector instructions per point slot, two thirds of the kernel - profiles/r06_k4_ground_kernel.txt.) */
+      const unsigned long long mValid = __ballot(p.z > 0.0f);
+      f32x2 d = pre_xy(Q, c3xy, p.x, p.y, p.z);
+      const float M = absmax2(d.x, d.y);
+      unsigned long long mInxy = __ballot(M < Q.lo);
+      unsigned long long mMaybexy = ~__ballot(M > Q.hi);
+      const float M3 = absmax3(p.x, p.y, p.z);
+      if constexpr(CHECKS)
       {
-        /* ground: the points inside its quadrilateral count; treads: the points outside theirs */
-        const bool okxy = world_xy(P, v[j], wx, wy);
-        const QuadTest &t = qts[q];
-        const bool fast = wx >= t.fx0 && wx < t.fx1 && wy >= t.fy0 && wy < t.fy1;
-        if(!okxy || ((fast || quad_test(t, wx, wy)) != (q == gSlot)))
-          continue;
+        /* (the rare configurations' tests, as K1's: launch_inquad picks the instantiation) */
+        const unsigned long long mFar = Q.checkInput ? ~__ballot(M3 <= Q.maxInput) : 0ull;
+        mInxy &= ~mFar;
+        mMaybexy |= mFar;
       }
-      if(q != curQ)
+      const float t = __builtin_fmaf(Q.zc[0], p.x, __builtin_fmaf(Q.zc[1], p.y, __builtin_fmaf(Q.zc[2], p.z, zc3)));
+      const float g = __builtin_amdgcn_fractf(t) - 0.5f;
+      const float h = __builtin_fmaf(M3, Q.zNegK, zh0);
+      unsigned long long mSurez = __ballot(__builtin_fabsf(g) < h);
+      const unsigned long long mInz = __ballot(__float_as_uint(t) < Q.zTopBits);
+      if constexpr(CHECKS)
       {
-        flushAcc();
-        curQ = q; accZ = 0; accN = 0;
+        if(Q.zCheckTop)
+          mSurez &= __ballot(__builtin_fabsf(t - Q.zTop) > 0.5f - h);
       }
-      accZ += static_cast<unsigned long long>(z_plus_magic_bits(wz));                        /* the constant's bits come off at the flush */
-      accN++;
-      if(q == gSlot)
+#if defined(SSD_SABOTAGE_PRE) && (SSD_SABOTAGE_PRE & 1)
+      mSurez = ~0ull;
+#endif
+      const unsigned int b = cvt_u32_f32(t);
+      const unsigned long long mInSure = mValid & mInz & mInxy & mSurez;
+      unsigned long long mSlow = mValid & mMaybexy & (~mSurez | (mInz & ~mInxy));
+      /* the bin's quadrilateral (row kMaxLive: none) and its four edges on d */
+      unsigned int q = kMaxLive;
+      if(__builtin_amdgcn_inverse_ballot_w64(mInSure))
+        q = SSD_CHK(28, b, kMaxBins) ? lut[b] : kMaxLive;
+      const unsigned long long mLive = __ballot(q != static_cast<unsigned int>(kMaxLive));
+      const QuadEdgesF &E = L.edges[q];
+      const float4 gx = *reinterpret_cast<const float4 *>(E.gx), gy = *reinterpret_cast<const float4 *>(E.gy), g2 = *reinterpret_cast<const float4 *>(E.g2);
+      f32x2 e01 = __builtin_elementwise_fma(f32x2{ gx.x, gx.y }, f32x2{ d.x, d.x }, f32x2{ g2.x, g2.y });
+      f32x2 e23 = __builtin_elementwise_fma(f32x2{ gx.z, gx.w }, f32x2{ d.x, d.x }, f32x2{ g2.z, g2.w });
+      e01 = __builtin_elementwise_fma(f32x2{ gy.x, gy.y }, f32x2{ d.y, d.y }, e01);
+      e23 = __builtin_elementwise_fma(f32x2{ gy.z, gy.w }, f32x2{ d.y, d.y }, e23);
+      const float emin = min3_f32(e01.x, e01.y, min_f32(e23.x, e23.y));
+      const float hq = __builtin_fmaf(M3, Q.dK, E.m);              /* infinity for the row "none" and for a quadrilateral single precision does not serve */
+      /* (Measured and not kept: a flag on the list for the cells that lie wholly inside their quadrilaterals - the ground's interior,
+       * 58 % of the cells walked - and a wave-uniform branch around these twelve instructions: 0.62 -> 0.70 ms, the branch costs more
+       * than it skips.) */
+#if defined(SSD_SABOTAGE_PRE) && (SSD_SABOTAGE_PRE & 4)   /* tools: the band along the edges NOT handed to the doubles - the tests built for it must fail */
+      const unsigned long long mSureQ = mLive;
+#else
+      const unsigned long long mSureQ = __ballot(__builtin_fabsf(emin) > hq);
+#endif
+      const unsigned long long mOutQ = __ballot(emin < 0.0f);
+      unsigned long long mGround = __ballot(q == static_cast<unsigned int>(gSlot));
+      /* ground: the points inside its quadrilateral count; treads: the points outside theirs (k_raster summed the plateau whole) */
+      unsigned long long mCount = mSureQ & (mGround ^ mOutQ);
+      mSlow |= mLive & ~mSureQ;
+      if(__builtin_expect(mSlow != 0ull, 0))
       {
-        /* projectToBinaryImage(pointsInQuadri) (pointcloud.cpp:531): the pixel goes out with the lane's others (wavewin_emit) */
-        int ix, iy;
-        const bool inside = image_pixel(P, X, wx, wy, ix, iy);
-        oob += inside ? 0u : 1u;                              /* quirk Q5 */
-        if(FULL)
-          key[j] = inside ? pixel_key(0, iy, ix) : kNoPixel;
-        else if(inside && iy >= stripRow0)
+        /* rare, wave-uniform so that the masks stay scalars: the reference's arithmetic, all of it, for the lanes it is for */
+        const K1ConstsLds c = k1_consts(L.kc);
+        const double x = p.x, y = p.y, z = p.z;
+        double wx = (c->a[0] * x + c->a[1] * y) + c->a[2] * z;
+        double wy = (c->a[3] * x + c->a[4] * y) + c->a[5] * z;
+        double wz = (c->a[6] * x + c->a[7] * y) + c->a[8] * z;
+        wx = wx + c->b[0];
+        wy = wy + c->b[1];
+        wz = wz + c->b[2];
+        const bool mine = __builtin_amdgcn_inverse_ballot_w64(mSlow);
+        const bool inRange = (wx > c->xMin) & (wx < c->xMax) & (wy > c->yMin) & (wy < c->yMax) & (wz > c->zMin) & (wz < c->zMax);
+        unsigned int qD = kMaxLive;
+        bool counts = false;
+        if(mine && inRange)
         {
-          int strip;
-          bool centre;
-          if(ground_strip_of(ix, stripX0, strip, centre))
+          const int bD = static_cast<int>((wz - c->zMin) * c->recip);                       /* height_bin */
+          qD = SSD_CHK(29, bD, kMaxBins) ? lut[bD] : kMaxLive;
+          if(qD != static_cast<unsigned int>(kMaxLive))
           {
-            /* One of the few pixels the bottom scan can see.  It looks, per scan column, for the BOTTOM-most lit pixel of the
-             * closed image, which lies at or below the bottom-most raw pixel of the column itself (closing only adds) and is a
-             * function of the raw rows within two of it: a pixel more than two rows above a centre-column pixel already seen
-             * in its strip cannot matter and stays unwritten (round 4: the blocks run from the bottom of the camera image up,
-             * so after a frame's first blocks nearly nothing is written: 4.5 k -> a few hundred global atomics per frame). */
-            const int seen = SSD_CHK(24, strip, kMaxGroundStrips) ? L.stripMax[strip] : 0x7fffffff;
-            if(iy >= seen - 2)
+            const QuadTest &tq = qts[qD];
+            const bool fast = wx >= tq.fx0 && wx < tq.fx1 && wy >= tq.fy0 && wy < tq.fy1;
+            counts = (fast || quad_test(tq, wx, wy)) == (qD == static_cast<unsigned int>(gSlot));
+          }
+        }
+        mCount = (mCount & ~mSlow) | __ballot(counts);
+        mGround = (mGround & ~mSlow) | __ballot(qD == static_cast<unsigned int>(gSlot));
+        q = mine ? qD : q;
+        d.x = mine ? static_cast<float>((wx - c->xMin) * c->boxX * 0.00390625 - 0.5) : d.x;      /* D rounded once: inside PreXY::dE0 */
+        d.y = mine ? static_cast<float>((wy - c->yMin) * c->boxY * 0.00390625 - 0.5) : d.y;
+      }
+      if(__builtin_amdgcn_inverse_ballot_w64(mCount))
+      {
+        /* calcAverageZ's summand in the reference's doubles (world_z_flat's row) */
+        double wz = (P.a[6] * static_cast<double>(p.x) + P.a[7] * static_cast<double>(p.y)) + P.a[8] * static_cast<double>(p.z);
+        wz = wz + P.b[2];
+        if(static_cast<int>(q) != curQ)
+        {
+          flushAcc();
+          curQ = static_cast<int>(q); accZ = 0; accN = 0;
+        }
+        accZ += static_cast<unsigned long long>(z_plus_magic_bits(wz));                        /* the constant's bits come off at the flush */
+        accN++;
+      }
+      /* projectToBinaryImage(pointsInQuadri) (pointcloud.cpp:531) for the counted ground points.  Outside debug capture only the
+       * pixels the bottom scan can see are wanted (above), and a pixel outside the image (quirk Q5) is counted: on the same d, a
+       * point whose row lies above the strips' first by more than a pixel, or whose column lies more than a pixel off every strip,
+       * and that is not within two pixels of the image's border, needs no pixel at all - five instructions say so for nineteen
+       * ground points in twenty */
+      unsigned long long mPixel = mCount & mGround;
+      if(!FULL)
+      {
+        /* (no branch around these six for the waves without a counted ground point: a branch costs this loop more) */
+        const unsigned long long mBorder = __ballot(M > pixBorder);
+        const unsigned long long mRow = __ballot(d.y <= pixRowThr);
+        const float gc = __builtin_amdgcn_fractf(__builtin_fmaf(d.x, pixColA, pixColB)) - 0.5f;
+        const unsigned long long mCol = __ballot(__builtin_fabsf(gc) < 0.07f);
+        mPixel &= mSlow | mBorder | (mRow & mCol);
+      }
+      if(FULL ? mPixel != 0ull : __builtin_expect(mPixel != 0ull, 0))
+      {
+        if(__builtin_amdgcn_inverse_ballot_w64(mPixel))
+        {
+          /* the pixel from d where single precision is certain of it (make_pre_pixel(), as K1's candidates: farther from every
+           * pixel edge than the bound for this magnitude - such a pixel lies inside the image), else Projection2D::worldToImage
+           * in doubles with the image's bounds */
+          const float px = __builtin_fmaf(d.x, X.fW, X.fHalfW), py = __builtin_fmaf(d.y, X.fNegH, X.fHalfH);
+          const f32x2 gg = f32x2{ __builtin_amdgcn_fractf(px), __builtin_amdgcn_fractf(py) } + f32x2{ -0.5f, -0.5f };
+          const float hp = __builtin_fmaf(M3, X.pxNegK, X.pxH0);
+          int ix = static_cast<int>(cvt_u32_f32(px)), iy = static_cast<int>(cvt_u32_f32(py));
+          bool inside = true;
+#if defined(SSD_SABOTAGE_PRE) && (SSD_SABOTAGE_PRE & 2)
+          if(false)
+#else
+          if(!(absmax2(gg.x, gg.y) < hp))
+#endif
+          {
+            const K1ConstsLds c = k1_consts(L.kc);
+            const double x = p.x, y = p.y, z = p.z;
+            double wx = (c->a[0] * x + c->a[1] * y) + c->a[2] * z;
+            double wy = (c->a[3] * x + c->a[4] * y) + c->a[5] * z;
+            wx = wx + c->b[0];
+            wy = wy + c->b[1];
+            ix = static_cast<int>((wx - c->xMin) * c->xToImage);
+            iy = static_cast<int>((c->yMax - wy) * c->yToImage);
+            inside = (static_cast<unsigned int>(ix) < static_cast<unsigned int>(X.W)) & (static_cast<unsigned int>(iy) < static_cast<unsigned int>(X.H));
+          }
+          oob += inside ? 0u : 1u;                              /* quirk Q5 */
+          if(FULL)
+            key[j] = inside ? pixel_key(0, iy, ix) : kNoPixel;
+          else if(inside && iy >= stripRow0)
+          {
+            int strip;
+            bool centre;
+            if(ground_strip_of(ix, stripX0, strip, centre))
             {
-              if(SSD_CHK(23, static_cast<unsigned int>(iy) * (2u * X.W64) + (static_cast<unsigned int>(ix) >> 5), 2u * static_cast<unsigned int>(X.H) * X.W64))
-                atomicOr(gimg32 + (static_cast<unsigned int>(iy) * (2u * X.W64) + (static_cast<unsigned int>(ix) >> 5)), 1u << (ix & 31));
-              gy0 = min(gy0, iy);
-              gy1 = max(gy1, iy);
-              if(centre && iy > seen)
-                atomicMax(&L.stripMax[strip], iy);
+              /* One of the few pixels the bottom scan can see.  It looks, per scan column, for the BOTTOM-most lit pixel of the
+               * closed image, which lies at or below the bottom-most raw pixel of the column itself (closing only adds) and is a
+               * function of the raw rows within two of it: a pixel more than two rows above a centre-column pixel already seen
+               * in its strip cannot matter and stays unwritten (round 4: the blocks run from the bottom of the camera image up,
+               * so after a frame's first blocks nearly nothing is written: 4.5 k -> a few hundred global atomics per frame). */
+              const int seen = SSD_CHK(24, strip, kMaxGroundStrips) ? L.stripMax[strip] : 0x7fffffff;
+              if(iy >= seen - 2)
+              {
+                if(SSD_CHK(23, static_cast<unsigned int>(iy) * (2u * X.W64) + (static_cast<unsigned int>(ix) >> 5), 2u * static_cast<unsigned int>(X.H) * X.W64))
+                  atomicOr(gimg32 + (static_cast<unsigned int>(iy) * (2u * X.W64) + (static_cast<unsigned int>(ix) >> 5)), 1u << (ix & 31));
+                gy0 = min(gy0, iy);
+                gy1 = max(gy1, iy);
+                if(centre && iy > seen)
+                  atomicMax(&L.stripMax[strip], iy);
+              }
             }
           }
         }
@@ -3522,8 +3720,8 @@ __device__ __forceinline__ void inquad_block(InquadLds<FULL> &L, const float *__
   ph.finish();
 }
 
-template<int SRC, bool FULL>
-__global__ __launch_bounds__(kThreads, SSD_K4_WAVES) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P,
+template<int SRC, bool FULL, bool CHECKS>
+__global__ __launch_bounds__(kThreads, FULL ? 4 : SSD_K4_WAVES) void k_inquad(const float *__restrict__ xyz, size_t strideFloats, PointParams P, PreXY Q,
                                                         PixelParams X, FrameState *__restrict__ st,
                                                         unsigned long long *__restrict__ groundImg,
                                                         const uint2 *__restrict__ tileMasks, size_t tileMaskStride, int chunkPoints, DepthSrc D)
@@ -3534,7 +3732,7 @@ __global__ __launch_bounds__(kThreads, SSD_K4_WAVES) void k_inquad(const float *
    * bottom-up: XGA 0.79 -> 0.73 ms like this order, FHD stress 0.55 -> 0.59 — its eight treads, the heavy blocks, came last.) */
   const int nChunks = static_cast<int>(gridDim.y), first = max(1, nChunks / 8), by = static_cast<int>(blockIdx.y);
   const int chunkIdx = by < first ? nChunks - 1 - by : by - first;
-  inquad_block<SRC, FULL>(L, xyz, strideFloats, P, X, st, groundImg, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, chunkIdx);
+  inquad_block<SRC, FULL, CHECKS>(L, xyz, strideFloats, P, Q, X, st, groundImg, tileMasks, tileMaskStride, chunkPoints, D, blockIdx.x, chunkIdx);
 }
 
 /* ========================================================================= */
@@ -4216,19 +4414,28 @@ void launch_inquad(const float *xyz, size_t strideFloats, const Params &P, Frame
   dim3 grid(nframes, chunks_for(P.nPoints, chunkPoints));
   const int src = depth ? kSrcDepth16 : aligned16(xyz, strideFloats, P.nPoints) ? kSrcF3Aligned : kSrcF3;
   const DepthSrc D = depth ? *depth : DepthSrc{};
-#define SSD_LAUNCH_INQUAD(SRC, FULL) \
-  hipLaunchKernelGGL((k_inquad<SRC, FULL>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.px, st, groundImg, tileMasks, tileMaskStride, chunkPoints, D)
+#define SSD_LAUNCH_INQUAD(SRC, FULL, CHECKS) \
+  hipLaunchKernelGGL((k_inquad<SRC, FULL, CHECKS>), grid, dim3(kThreads), 0, s, xyz, strideFloats, P.pt, P.pre, P.px, st, groundImg, tileMasks, tileMaskStride, chunkPoints, D)
+  /* the instantiation with the rare configurations' per-point tests (a magnitude test of the input, a z range that does not end on a bin
+   * edge: ssd_prexy.h) only where the configuration needs them; debug capture (the whole ground image) always takes it */
+  const bool checks = P.pre.checkInput != 0 || P.pre.zCheckTop != 0;
   if(P.px.groundFull)
   {
-    if(src == kSrcDepth16) SSD_LAUNCH_INQUAD(kSrcDepth16, true);
-    else if(src == kSrcF3Aligned) SSD_LAUNCH_INQUAD(kSrcF3Aligned, true);
-    else SSD_LAUNCH_INQUAD(kSrcF3, true);
+    if(src == kSrcDepth16) SSD_LAUNCH_INQUAD(kSrcDepth16, true, true);
+    else if(src == kSrcF3Aligned) SSD_LAUNCH_INQUAD(kSrcF3Aligned, true, true);
+    else SSD_LAUNCH_INQUAD(kSrcF3, true, true);
+  }
+  else if(checks)
+  {
+    if(src == kSrcDepth16) SSD_LAUNCH_INQUAD(kSrcDepth16, false, true);
+    else if(src == kSrcF3Aligned) SSD_LAUNCH_INQUAD(kSrcF3Aligned, false, true);
+    else SSD_LAUNCH_INQUAD(kSrcF3, false, true);
   }
   else
   {
-    if(src == kSrcDepth16) SSD_LAUNCH_INQUAD(kSrcDepth16, false);
-    else if(src == kSrcF3Aligned) SSD_LAUNCH_INQUAD(kSrcF3Aligned, false);
-    else SSD_LAUNCH_INQUAD(kSrcF3, false);
+    if(src == kSrcDepth16) SSD_LAUNCH_INQUAD(kSrcDepth16, false, false);
+    else if(src == kSrcF3Aligned) SSD_LAUNCH_INQUAD(kSrcF3Aligned, false, false);
+    else SSD_LAUNCH_INQUAD(kSrcF3, false, false);
   }
 #undef SSD_LAUNCH_INQUAD
 }

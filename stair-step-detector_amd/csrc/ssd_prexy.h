@@ -67,8 +67,12 @@ inline PreXY make_pre_xy(const PointParams &P)
   const double e = 8.0 * 0x1p-24 * S + 0x1p-20;
   Q.maxInput = static_cast<float>(R);
   Q.checkInput = 1;
+  /* d's own bound per point (PreXY::dK, dE0): 4.01 * 2^-24 S(M) as above, 4.5 for the 4.01; a d from the doubles is D rounded once */
+  Q.dK = std::nextafterf(static_cast<float>(4.5 * 0x1p-24 * std::fmax(sumX, sumY)), INFINITY);
+  Q.dE0 = std::nextafterf(static_cast<float>(4.5 * 0x1p-24 * std::fmax(std::fabs(static_cast<double>(Q.c[3][0])), std::fabs(static_cast<double>(Q.c[3][1]))) + 0x1p-25), INFINITY);
   if(!(e < 0.25) || !std::isfinite(S))
   {
+    Q.dK = 0.0f; Q.dE0 = 0x1p-24f;          /* every d comes from the doubles */
     /* a calibration or range for which single precision says nothing: every point takes the doubles */
     Q.lo = -1.0f; Q.hi = INFINITY;
     Q.maxInput = -1.0f;

@@ -372,6 +372,164 @@ __host__ __device__ __forceinline__ bool grid_box_inside(const QuadGridSegs &sg,
   return in;
 }
 
+/*
+ * Round 6: the quadrilateral test per POINT in single precision first (QuadEdgesF, ssd_device.h) - for k_inquad, whose time is
+ * the cells an edge runs through (profiles/r06_k4_ground_kernel.txt): there the reference's test - bounding box, row and cell of the
+ * 3 x 3 map, up to two segments - ran for every point, nested and divergent, on doubles.
+ *
+ * Edge s of a built test is the line cx x + cy y + cc = 0 (sign-adjusted as in build_grid_segs: positive on the inner side).  On
+ * the centred, normalised coordinates D of the range test (x = xMin + (D.x + 1/2) Rx ..: ssd_prexy.h) the same line reads
+ *     E_s(D) = (cx Rx D.x + cy Ry D.y + cc + cx (xMin + Rx / 2) + cy (yMin + Ry / 2)) / N,      N = |cx Rx| + |cy Ry|,
+ * so that the coefficients of D.x and D.y have absolute sum 1.  k_inquad evaluates e_s = fma(gy, d.y, fma(gx, d.x, g2)) with the
+ * single-precision coefficients and the d of the pre-filter:
+ *   - |d - D| <= dK M + dE0 in either coordinate for a point of magnitude M (PreXY::dK, dE0: make_pre_xy), which moves E_s by at
+ *     most that (absolute sum 1);
+ *   - coefficients rounded to single precision and two FMAs: at most 4.01 * 2^-24 (|gx d.x| + |gy d.y| + |g2|) <= 4.01 * 2^-24
+ *     (0.51 + |g2|) for a point in range (|d| <= 1/2 + e);
+ *   - the reference's own doubles (the world coordinates, then x k + y + c or x + y k + c): 2^-50 of the operands.
+ * With m = 4.5 * 2^-24 (0.51 + max |g2|) + 2^-20 and h = m + dK M + dE0:  min_s e_s > h  =>  every E_s > 2^-20: the point lies on the
+ * inner side of all four lines by a margin the reference's arithmetic cannot cross;  min_s e_s < -h  =>  some E_s < -2^-20.
+ *
+ * What the reference answers for such points is a matter of ITS map, not of geometry:
+ *   inside all four lines: a cell that holds segments tests only those - all pass -, a cell without segments answers with its
+ *     constant; okInside (QuadGridSegs::ok, build_grid_segs) says that no constant "outside" cell lies inside the quadrilateral.
+ *     The strict bounding box holds the quadrilateral (err == 0: all four turns the same way - convex).
+ *   beyond a line: the reference may still say "inside" - a cell tests only the segments whose boxes meet it, and for a long, thin,
+ *     tilted quadrilateral that is not always the edge the point lies beyond (an example is in tests/test_quad_edges.py).  So the
+ *     map is CHECKED, cell by cell (quad_cell_unsound): the region a cell accepts - the cell's rectangle cut by the lines of its own segments, or all
+ *     of it for a constant "inside" - is a convex polygon, and E_s' >= -2^-22 for every other edge s' on it iff that holds at its
+ *     vertices.  The candidates below are a superset of the vertices (rectangle corners, each line with each side, the two lines
+ *     with each other), filtered to the polygon with a tolerance that only ever adds candidates.  One failing candidate: m =
+ *     infinity - every point of this quadrilateral takes the doubles.  Otherwise no point a cell accepts has an E_s' below -2^-22,
+ *     a point with some E_s' < -2^-20 is accepted by no cell - and a point outside the bounding box is "outside" anyway.
+ */
+/* the edges of a built test, sign-adjusted (cx x + cy y + cc > 0 on the inner side), with 1 / N: e[s] = { cx, cy, cc, 1 / N } */
+struct QuadEdgesD
+{
+  double e[4][4];
+  double g2max;
+  int fine, pad;
+};
+
+/* step 1: the coefficients in both forms; fine = 0: a degenerate edge or range, or the reference throws */
+__host__ __device__ inline void quad_edges_coeffs(const QuadTest &t, int okInside, double xMin, double xMax, double yMin, double yMax, QuadEdgesD &w, QuadEdgesF &o)
+{
+  const double Rx = xMax - xMin, Ry = yMax - yMin;
+  const double xMid = xMin + 0.5 * Rx, yMid = yMin + 0.5 * Ry;
+  bool fine = t.err == 0 && okInside != 0;
+  double g2max = 0.0;
+#pragma unroll
+  for(int s = 0; s < 4; s++)
+  {
+    const bool positiveInside = (t.segLeftIfPositive[s] != 0) == (t.insideIsLeft != 0);
+    const double sgn = positiveInside ? 1.0 : -1.0;
+    const double k = t.segK[s];
+    const double cx = sgn * (t.segSteep[s] ? 1.0 : k), cy = sgn * (t.segSteep[s] ? k : 1.0), cc = sgn * t.segC[s];
+    const double N = fabs(cx * Rx) + fabs(cy * Ry);
+    const double inv = 1.0 / N;
+    const double g2 = (cc + cx * xMid + cy * yMid) * inv;
+    w.e[s][0] = cx; w.e[s][1] = cy; w.e[s][2] = cc; w.e[s][3] = inv;
+    o.gx[s] = static_cast<float>(cx * Rx * inv);
+    o.gy[s] = static_cast<float>(cy * Ry * inv);
+    o.g2[s] = static_cast<float>(g2);
+    if(!(N > 1.0e-12 && N < 1.0e12 && fabs(g2) < 64.0))
+      fine = false;                                   /* degenerate edge or range (NaNs fail the compares) */
+    g2max = fmax(g2max, fabs(g2));
+  }
+  w.g2max = g2max;
+  w.fine = fine ? 1 : 0;
+  w.pad = 0;
+  o.m = INFINITY;
+  o.pad[0] = o.pad[1] = o.pad[2] = 0.0f;
+}
+
+/* step 2, per cell (r, c) of the map: true when the region the cell accepts reaches beyond another edge - the single-precision test
+ * must not be used for this quadrilateral.  (r and c index the tables at run time: t in memory - LDS in k_quads, which deals the
+ * cells of a frame's quadrilaterals out to its lanes -, not in registers.) */
+__host__ __device__ inline bool quad_cell_unsound(const QuadTest &t, const QuadEdgesD &w, int r, int c)
+{
+  const double tol = 0x1p-22, tolFilter = 0x1p-30, tolRect = 1.0e-9;
+  const unsigned int mask = t.cellMask[r][c];
+  if(!(r < t.nRows && c < t.nCells[r] && (mask != 0u || t.cellConst[r][c] != 0)))
+    return false;                                     /* no such cell, or a constant "outside" */
+  const double y0 = r == 0 ? t.byLo : t.yTrans[r > 0 ? r - 1 : 0];
+  const double y1 = r == t.nRows - 1 ? t.byUp : t.yTrans[r < 2 ? r : 1];
+  const double x0 = c == 0 ? t.bxLo : t.xTrans[r][c > 0 ? c - 1 : 0];
+  const double x1 = c == t.nCells[r] - 1 ? t.bxUp : t.xTrans[r][c < 2 ? c : 1];
+  /* the cell's own segments: at most two (more: the reference throws, err = -4) */
+  double ax = 0.0, ay = 0.0, ac = 0.0, bx = 0.0, by = 0.0, bc = 0.0;
+  int n = 0;
+#pragma unroll
+  for(int s = 0; s < 4; s++)
+  {
+    const bool bit = ((mask >> s) & 1u) != 0u;
+    const bool first = bit && n == 0, second = bit && n == 1;
+    ax = first ? w.e[s][0] : ax; ay = first ? w.e[s][1] : ay; ac = first ? w.e[s][2] : ac;
+    bx = second ? w.e[s][0] : bx; by = second ? w.e[s][1] : by; bc = second ? w.e[s][2] : bc;
+    n += bit ? 1 : 0;
+  }
+  const double det = ax * by - bx * ay;
+  const double px[13] = { x0, x1, x0, x1,
+                          x0, x1, -(ac + ay * y0) / ax, -(ac + ay * y1) / ax,
+                          x0, x1, -(bc + by * y0) / bx, -(bc + by * y1) / bx,
+                          (ay * bc - by * ac) / det };
+  const double py[13] = { y0, y0, y1, y1,
+                          -(ac + ax * x0) / ay, -(ac + ax * x1) / ay, y0, y1,
+                          -(bc + bx * x0) / by, -(bc + bx * x1) / by, y0, y1,
+                          (bx * ac - ax * bc) / det };
+  bool bad = false;
+#pragma unroll
+  for(int k = 0; k < 13; k++)
+  {
+    const bool valid = k < 4 || (k < 8 ? n >= 1 : n >= 2);
+    /* (a line parallel to a side, two parallel lines: infinity or NaN, which the rectangle's compares reject) */
+    bool in = valid && px[k] >= x0 - tolRect && px[k] <= x1 + tolRect && py[k] >= y0 - tolRect && py[k] <= y1 + tolRect;
+    double e[4];
+#pragma unroll
+    for(int s = 0; s < 4; s++)
+    {
+      e[s] = (w.e[s][0] * px[k] + w.e[s][1] * py[k] + w.e[s][2]) * w.e[s][3];
+      in = in && (((mask >> s) & 1u) == 0u || e[s] >= -tolFilter);
+    }
+#pragma unroll
+    for(int s = 0; s < 4; s++)
+      bad = bad || (in && ((mask >> s) & 1u) == 0u && !(e[s] >= -tol));
+  }
+  return bad;
+}
+
+/* step 3: the margin - or infinity */
+__host__ __device__ inline float quad_edges_margin(const QuadEdgesD &w, bool unsound)
+{
+  const double m = (4.5 * 0x1p-24 * (0.51 + w.g2max) + 0x1p-20) * (1.0 + 0x1p-20);
+  return (w.fine != 0 && !unsound) ? static_cast<float>(m) : INFINITY;
+}
+
+/* the three steps for one quadrilateral (the host's form: tests/test_quad_edges.py through the test hook) */
+__host__ __device__ inline void build_quad_edges(const QuadTest &t, int okInside, double xMin, double xMax, double yMin, double yMax, QuadEdgesF &o)
+{
+  QuadEdgesD w;
+  quad_edges_coeffs(t, okInside, xMin, xMax, yMin, yMax, w, o);
+  bool bad = false;
+  if(w.fine)
+    for(int r = 0; r < 3; r++)
+      for(int c = 0; c < 3; c++)
+        bad = bad || quad_cell_unsound(t, w, r, c);
+  o.m = quad_edges_margin(w, bad);
+}
+
+/* +1: inside by the reference's test for sure, -1: outside for sure, 0: ask the doubles.  dBound = PreXY::dK * M + PreXY::dE0 for
+ * the point's magnitude M = max(|x|, |y|, |z|) of the camera coordinates (k_inquad folds dE0 into its copy of m). */
+__host__ __device__ __forceinline__ int quad_edges_classify(const QuadEdgesF &E, float dx, float dy, float dBound)
+{
+  float emin = INFINITY;
+#pragma unroll
+  for(int s = 0; s < 4; s++)
+    emin = fminf(emin, __builtin_fmaf(E.gy[s], dy, __builtin_fmaf(E.gx[s], dx, E.g2[s])));
+  const float h = E.m + dBound;
+  return emin > h ? 1 : (emin < -h ? -1 : 0);
+}
+
 } // namespace ssd
 
 #endif /* SSD_QUADTEST_H_ */

@@ -403,6 +403,47 @@ int ssd_test_prez_host(const double range[6], const double a[9], const double b[
   return SSD_OK;
 }
 
+/* k_inquad's single-precision edge tests (csrc/ssd_quadtest.h: build_quad_edges, quad_edges_classify) compiled for the host, on the d
+ * and the bound K1's pre-filter would hand them (csrc/ssd_prexy.h) for n camera points */
+int ssd_test_quad_edges_host(const double quad[8], const double range[6], const double a[9], const double b[3], const float *pts_xyz, int n,
+                             float consts[15], int8_t *cls, double *world_xy, uint8_t *in_range_xy, int *err)
+{
+  if(!quad || !range || !a || !b || !pts_xyz || !consts || !cls || !world_xy || !in_range_xy || !err || n < 0)
+    return fail(SSD_E_ARG, "ssd_test_quad_edges_host: bad argument");
+  PointParams P{};
+  for(int i = 0; i < 9; i++) P.a[i] = a[i];
+  for(int i = 0; i < 3; i++) P.b[i] = b[i];
+  P.xMin = range[0]; P.xMax = range[1]; P.yMin = range[2]; P.yMax = range[3]; P.zMin = range[4]; P.zMax = range[5];
+  P.recip = 100.0;
+  P.boxX = 256.0 / (P.xMax - P.xMin); P.boxY = 256.0 / (P.yMax - P.yMin);
+  const PreXY Q = make_pre_xy(P);
+  ssd::QuadTest t;
+  ssd::build_quad_test(quad, t);
+  *err = t.err;
+  ssd::QuadGridSegs sg;
+  ssd::build_grid_segs(t, P.xMin, P.yMin, P.boxX, P.boxY, sg);
+  ssd::QuadEdgesF E;
+  ssd::build_quad_edges(t, sg.ok, P.xMin, P.xMax, P.yMin, P.yMax, E);
+  for(int s = 0; s < 4; s++) { consts[s] = E.gx[s]; consts[4 + s] = E.gy[s]; consts[8 + s] = E.g2[s]; }
+  consts[12] = E.m; consts[13] = Q.dK; consts[14] = Q.dE0;
+  for(int i = 0; i < n; i++)
+  {
+    const float x = pts_xyz[3 * i], y = pts_xyz[3 * i + 1], z = pts_xyz[3 * i + 2];
+    /* the reference's rows (transformation.h:59-64) */
+    const double wx = ((P.a[0] * x + P.a[1] * y) + P.a[2] * z) + P.b[0];
+    const double wy = ((P.a[3] * x + P.a[4] * y) + P.a[5] * z) + P.b[1];
+    world_xy[2 * i] = wx; world_xy[2 * i + 1] = wy;
+    in_range_xy[i] = (wx > P.xMin && wx < P.xMax && wy > P.yMin && wy < P.yMax) ? 1 : 0;
+    /* K1's d (pre_xy: z, then y, then x) and the magnitude its bound follows */
+    float dx = std::fmaf(Q.c[2][0], z, Q.c[3][0]), dy = std::fmaf(Q.c[2][1], z, Q.c[3][1]);
+    dx = std::fmaf(Q.c[1][0], y, dx); dy = std::fmaf(Q.c[1][1], y, dy);
+    dx = std::fmaf(Q.c[0][0], x, dx); dy = std::fmaf(Q.c[0][1], x, dy);
+    const float M = std::fmax(std::fabs(x), std::fmax(std::fabs(y), std::fabs(z)));
+    cls[i] = static_cast<int8_t>(ssd::quad_edges_classify(E, dx, dy, std::fmaf(M, Q.dK, Q.dE0)));
+  }
+  return SSD_OK;
+}
+
 /* the kernels' line helpers (csrc/ssd_math.h: line_through_i / line_through_d = LineCoordinates(p, q), types.h:140-158; intersect60 =
  * Line<double>::intersection, segmentation.cpp:344-362, whose numerators are LineCoordinates::det / detx / dety) compiled for the host */
 int ssd_test_line_host(const double pq[4], double abc_d[3], int32_t abc_i[3])
