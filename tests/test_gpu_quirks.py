@@ -443,3 +443,98 @@ def test_points_on_bin_edges_and_pixel_edges_take_the_doubles(ssd, oracle, gpu_d
     rep1 = parity.check_frame(ssd, oracle, det, cfg, use.constants, xyz, images=True)
     assert det.single_pass_stats(1)["ran"] and rep1["line"] == rep["line"] and rep["n_steps"] >= 1
     det.close()
+
+
+def _world(cfg, a, b, p32):
+    """the reference's rows on camera floats (transformation.h:59-64, the operations in its order), the range test, bin and pixel"""
+    x, y, z = (p32[:, k].astype(np.float64) for k in range(3))
+    wx = ((a[0, 0] * x + a[0, 1] * y) + a[0, 2] * z) + b[0]
+    wy = ((a[1, 0] * x + a[1, 1] * y) + a[1, 2] * z) + b[1]
+    wz = ((a[2, 0] * x + a[2, 1] * y) + a[2, 2] * z) + b[2]
+    ok = (p32[:, 2] > 0) & (wx > cfg.x_min) & (wx < cfg.x_max) & (wy > cfg.y_min) & (wy < cfg.y_max) & (wz > cfg.z_min) & (wz < cfg.z_max)
+    recip = 1.0 / cfg.height_interval
+    with np.errstate(invalid="ignore"):
+        hbin = np.where(ok, (wz - cfg.z_min) * recip, 0.0).astype(np.int64)
+        ix = np.where(ok, (wx - cfg.x_min) * (W / (cfg.x_max - cfg.x_min)), 0.0).astype(np.int64)
+        iy = np.where(ok, (cfg.y_max - wy) * (H / (cfg.y_max - cfg.y_min)), 0.0).astype(np.int64)
+    return wx, wy, wz, ok, hbin, ix, iy
+
+
+def _snap_onto_quad_edges(cfg, a, b, xyz, surfaces, rng, per_edge=400):
+    """Moves points of each surface (quadrilateral as 4 x (x, y); its height bins lo .. hi) that lie within 1.2 mm of one of its edges
+    ONTO that edge (or a chosen distance from nothing to 10 um off it) - by less than a pixel and only if the moved point keeps its bin
+    and its pixel, so that histogram and rasters, hence plateaus, outlines and quadrilaterals, stay what they were.  Rounding to camera
+    floats scatters the moved points by ~1e-7 m to either side of the edge.  Returns (the cloud, distances of the moved points from
+    their edge)."""
+    p = xyz.reshape(-1, 3).copy()
+    wx, wy, wz, ok, hbin, ix, iy = _world(cfg, a, b, p)
+    inv = np.linalg.inv(a)
+    offsets = np.array([0.0, 0.0, 1e-9, -1e-9, 1e-7, -1e-7, 5e-7, -5e-7, 1e-6, -1e-6, 3e-6, -3e-6, 1e-5, -1e-5])
+    moved = np.zeros(len(p), dtype=bool)
+    dists = []
+    for quad, lo, hi in surfaces:
+        q = np.asarray(quad, dtype=np.float64).reshape(4, 2)
+        mine = ok & (hbin >= lo) & (hbin <= hi) & ~moved
+        for i0, i1 in ((0, 1), (1, 3), (3, 2), (2, 0)):
+            p0, along = q[i0], q[i1] - q[i0]
+            n = np.array([-along[1], along[0]]) / np.hypot(*along)
+            t = ((wx - p0[0]) * along[0] + (wy - p0[1]) * along[1]) / (along @ along)
+            dist = (wx - p0[0]) * n[0] + (wy - p0[1]) * n[1]
+            cand = np.flatnonzero(mine & ~moved & (t > 0.02) & (t < 0.98) & (np.abs(dist) < 1.2e-3))
+            cand = rng.permutation(cand)[:per_edge]
+            if len(cand) == 0:
+                continue
+            off = rng.choice(offsets, len(cand))
+            w = np.stack([wx[cand] - (dist[cand] - off) * n[0], wy[cand] - (dist[cand] - off) * n[1], wz[cand]], 1)
+            new = ((w - b) @ inv.T).astype(np.float32)
+            nwx, nwy, nwz, nok, nbin, nix, niy = _world(cfg, a, b, new)
+            keep = nok & (nbin == hbin[cand]) & (nix == ix[cand]) & (niy == iy[cand])
+            p[cand[keep]] = new[keep]
+            moved[cand[keep]] = True
+            dists.append(np.abs((nwx[keep] - p0[0]) * n[0] + (nwy[keep] - p0[1]) * n[1]))
+    return p.reshape(xyz.shape), np.concatenate(dists) if dists else np.zeros(0)
+
+
+@pytest.mark.parametrize("yaw_deg", [-9.0, 14.0])
+def test_points_on_the_edges_of_the_quadrilaterals_take_the_doubles(ssd, oracle, gpu_device, yaw_deg):
+    """Round 6: k_inquad asks four single-precision half-planes about a point first and the reference's QuadrilateralTest, in doubles,
+    only for the points within a bound (some micrometres) of an edge (csrc/ssd_quadtest.h: build_quad_edges).  A frame made for
+    that band: points of the treads and of the ground moved onto the edges of their own quadrilaterals - within their pixel and bin,
+    so that the quadrilaterals stay where they are (checked) - hundreds of them within a micrometre of an edge, on either side.
+    Which side decides whether the point counts: the numbers of points in the quadrilaterals, their mean heights, the ground image
+    and the result are the oracle's.  (A build with -DSSD_SABOTAGE_PRE=4 - the band not handed to the doubles - fails this test:
+    profiles/r06_prefilter_sabotage.txt.)"""
+    sc = ssd.make_scene(W, H, n_steps=3, seed=79, pitch_deg=44.0, roll_deg=1.5, yaw_deg=yaw_deg, sigma=0.001)
+    trans = ssd.transformation_for_scene(sc)
+    cfg = ssd.default_config(W, H, max_frames_per_batch=1)
+    a = np.array(list(trans.constants.a), dtype=np.float64).reshape(3, 3)
+    b = np.array(list(trans.constants.b), dtype=np.float64)
+    rng = np.random.default_rng(11)
+    xyz = ssd.synth_host([sc])[0].reshape(H, W, 3).copy()
+    ocfg, ocal = ob.to_oracle_config(cfg), ob.to_oracle_calibration(trans.constants)
+    ref0 = oracle.process(ocfg, ocal, xyz)[0]
+    assert ref0.n_steps >= 2 and ref0.first_valid_ind >= 0 and ref0.ground_ind >= 0 and not (ref0.status & ob.ST_THROW)
+    surfaces = []
+    for k in range(ref0.n_plateaus):
+        pl = ref0.plateaus[k]
+        if pl.is_step and pl.valid:
+            surfaces.append((list(pl.quad_world), pl.bin_lo, pl.bin_hi))
+    g = ref0.plateaus[ref0.ground_ind]
+    surfaces.append((list(ref0.ground_quad_world), g.bin_lo, g.bin_hi))
+    made, dist = _snap_onto_quad_edges(cfg, a, b, xyz, surfaces, rng)
+    assert len(dist) > 1500 and (dist < 1e-6).sum() > 400 and (dist < 2e-7).sum() > 100, (len(dist), (dist < 1e-6).sum())
+    ref1 = oracle.process(ocfg, ocal, made)[0]
+    # nothing upstream of the quadrilateral tests has moved
+    assert list(ref1.hist) == list(ref0.hist) and list(ref1.ground_quad_world) == list(ref0.ground_quad_world)
+    for k in range(ref0.n_plateaus):
+        assert list(ref1.plateaus[k].quad_world) == list(ref0.plateaus[k].quad_world)
+    # ... and the points on the edges did change what is counted (so the test sees the band)
+    counts0 = [ref0.plateaus[k].n_in_quad for k in range(ref0.n_plateaus)] + [ref0.ground_n_in_quad]
+    counts1 = [ref1.plateaus[k].n_in_quad for k in range(ref1.n_plateaus)] + [ref1.ground_n_in_quad]
+    assert counts0 != counts1
+    det = ssd.Detector(cfg, trans, gpu_device)
+    rep = parity.check_frame(ssd, oracle, det, cfg, trans.constants, made, images=True)
+    det.single_pass(1)
+    rep1 = parity.check_frame(ssd, oracle, det, cfg, trans.constants, made, images=True)
+    assert rep1["line"] == rep["line"] and rep["n_steps"] >= 2
+    det.close()
