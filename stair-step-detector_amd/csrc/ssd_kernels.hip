@@ -8,6 +8,7 @@
  *   K3 k_outline   3x3 close + scans + best lines + corners            (segmentation.cpp:919-971)
  *   K3b k_quads    ground quadrilateral, point-in-quad tests           (pointcloud.cpp:431-443,489-512; quadrilateralTest.cpp:275-443)
  *   K4 k_inquad    in-quad filter, z sums, ground image                (pointcloud.cpp:560-581, 530-531)
+ *                  (range, bin and quadrilateral in single precision first, round 6: ssd_prexy.h, ssd_quadtest.h build_quad_edges)
  *   K5 k_final     ground front edge, mean z, ToExternalWorld, result  (segmentation.cpp:879-917; pointcloud.cpp:532-547, 370-383)
  *
  * All floating-point work is fp64 with contraction off (the file is compiled with
@@ -131,8 +132,9 @@ __device__ __forceinline__ int height_bin(const PointParams &P, double wz)
 /* k_raster is built for 6 waves per SIMD: 75 VGPRs, no scratch spills (round 2: 7 waves, 72 VGPRs, 3 spills).  Measured in
  * round 3, same box, alternating runs, XGA batch: 8 / 7 / 6 / 5 / 4 waves 0.848 / 0.823 / 0.800 / 0.801 / 0.799 ms; FHD stress:
  * 7 / 6 / 5 within 1 % — the walk is bound by instruction issue, not by latency: residency beyond four waves buys nothing */
-/* k_inquad: 8 waves per SIMD although that costs it 48 scalar-register spills (v_readlane in the loop): 7 / 6 waves spill
- * 33 / 10 and run 3 % / 10 % slower (measured, XGA batch) */
+/* k_inquad (round 6: every decision in single precision first, the doubles out of line): 5 waves per SIMD - 92 vector registers,
+ * no spill of either kind in the XGA instantiation; 6 waves spill 3 vector registers and run a third slower (0.64 -> 0.84 ms), 4 waves
+ * the same as 5 (profiles/r06_k4_edges.txt).  Until round 6: 8 waves at 48 scalar spills in the loop. */
 #ifndef SSD_K4_WAVES
 #define SSD_K4_WAVES 5
 #endif
