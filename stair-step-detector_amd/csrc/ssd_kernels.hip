@@ -3109,8 +3109,8 @@ __global__ __launch_bounds__(64) void k_quads(Params P, FrameState *__restrict__
   }
   {
     /* k_inquad's single-precision edge tests (ssd_quadtest.h, build_quad_edges): the reference's map of each live quadrilateral is
-     * checked cell by cell - nine cells each, dealt out to the wave's lanes (one lane doing its own quadrilateral's nine: 60 us
-     * per frame on top of the kernel's 25) - and a quadrilateral whose map accepts points beyond an edge gets no margin */
+     * checked cell by cell - nine cells each, dealt out to the wave's lanes (one lane doing its own quadrilateral's nine: 0.086 ms
+     * per launch of 1024 frames against 0.031) - and a quadrilateral whose map accepts points beyond an edge gets no margin */
     const int nL = __popcll(__ballot(mySlot >= 0));
     __syncthreads();
     for(int item = lane; item < nL * 9; item += 64)
