@@ -31,6 +31,9 @@ int ssd_test_quad_host(const double quad[8], const double *pts_xy, int n, uint8_
  * K1's pre-filter computes; world_xy[2 i ..] = the reference's world x, y of the point, in_range_xy[i] = its x / y range test */
 int ssd_test_quad_edges_host(const double quad[8], const double range[6], const double a[9], const double b[3], const float *pts_xyz, int n,
                              float consts[15], int8_t *cls, double *world_xy, uint8_t *in_range_xy, int *err);
+/* the same table as the DEVICE builds it in k_quads' three steps (coefficients, the check of the map's nine cells dealt out to lanes, the margin) for n
+ * quadrilaterals (n x 8 doubles) over the x / y range (x_min, x_max, y_min, y_max): out = n x 13 floats (gx[4], gy[4], g2[4], m) */
+int ssd_test_quad_edges_device(int device, const double *quads, int n, const double range_xy[4], float *out);
 /* test hook: BestLine (segmentation.cpp:409-487) over n points (x, y int32 pairs) with the kernels' residual code
  * (csrc/ssd_bestline.h) compiled for the host; form 0 = any list, 1 = keys in passes of four (n <= 128), 2 = one pass (n <= 64) */
 int ssd_test_best_line_host(const int32_t *pts_xy, int n, int form, int32_t line[3]);

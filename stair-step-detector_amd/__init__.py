@@ -157,7 +157,7 @@ SOURCE_EXPORTS = [
 # libssd_testhooks.so — test infrastructure (include/ssd_testhooks.h)
 HOOK_EXPORTS = [
     "ssd_test_hypot_host", "ssd_test_hypot_device", "ssd_test_frame_state", "ssd_test_ground_image", "ssd_test_line_host", "ssd_test_intersect_host", "ssd_test_quad_device", "ssd_test_quad_host", "ssd_test_closing_host", "ssd_test_best_line_host", "ssd_test_grid_boxes_device", "ssd_test_sort_host",
-    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_test_single_pass", "ssd_test_plane_pool", "ssd_test_single_pass_stats", "ssd_test_single_pass_frame", "ssd_test_single_pass_sample", "ssd_test_predict_table_host", "ssd_test_prexy_host", "ssd_test_prez_host", "ssd_test_quad_edges_host", "ssd_test_record_offset", "ssd_test_record_realloc", "ssd_test_record_realloc_sized", "ssd_test_record_release", "ssd_testhooks_last_error",
+    "ssd_test_sort_device", "ssd_test_stream_read", "ssd_test_empty_quadrilateral", "ssd_test_single_pass", "ssd_test_plane_pool", "ssd_test_single_pass_stats", "ssd_test_single_pass_frame", "ssd_test_single_pass_sample", "ssd_test_predict_table_host", "ssd_test_prexy_host", "ssd_test_prez_host", "ssd_test_quad_edges_host", "ssd_test_quad_edges_device", "ssd_test_record_offset", "ssd_test_record_realloc", "ssd_test_record_realloc_sized", "ssd_test_record_release", "ssd_testhooks_last_error",
 ]
 SOURCE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_source.so")
 HOOKS_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libssd_testhooks.so")
@@ -286,6 +286,8 @@ def hooks_lib():
     L.ssd_test_prez_host.argtypes = [vp, vp, vp, C.c_double, i32, i32, vp]
     L.ssd_test_quad_edges_host.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.ssd_test_quad_edges_host.restype = i32
+    L.ssd_test_quad_edges_device.argtypes = [i32, vp, i32, vp, vp]
+    L.ssd_test_quad_edges_device.restype = i32
     L.ssd_test_record_offset.argtypes = [vp, C.c_size_t]
     L.ssd_test_record_realloc.argtypes = [vp]
     L.ssd_test_record_realloc.restype = C.c_ulonglong
@@ -890,6 +892,15 @@ def quad_edges_host(quad, x_min, x_max, y_min, y_max, z_min, z_max, a, b, pts_xy
                                                C.byref(err)), "hooks")
     o = np.array(list(consts), dtype=np.float32)
     return dict(err=err.value, gx=o[0:4], gy=o[4:8], g2=o[8:12], m=o[12], d_k=o[13], d_e0=o[14], cls=cls, world_xy=wxy, in_range_xy=inr)
+
+
+def quad_edges_device(quads, x_min, x_max, y_min, y_max, device=0):
+    """test hook: k_inquad's edge table as the device builds it in k_quads' three steps, for n quadrilaterals -> float32[n, 13] (gx, gy, g2, m)"""
+    q = np.ascontiguousarray(quads, dtype=np.float64).reshape(-1, 8)
+    rng = (C.c_double * 4)(x_min, x_max, y_min, y_max)
+    out = np.zeros((len(q), 13), dtype=np.float32)
+    _check(hooks_lib().ssd_test_quad_edges_device(device, q.ctypes.data_as(C.c_void_p), len(q), rng, out.ctypes.data_as(C.c_void_p)), "hooks")
+    return out
 
 
 def prexy_host(x_min, x_max, y_min, y_max, z_min, z_max, a, b):

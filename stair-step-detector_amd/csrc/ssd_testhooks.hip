@@ -115,6 +115,43 @@ __global__ void k_quadtest(const double *__restrict__ quad, const double *__rest
   }
 }
 
+/* test hook: k_inquad's edge table as k_quads builds it (ssd_quadtest.h: quad_edges_coeffs, quad_cell_unsound dealt out to the lanes,
+ * quad_edges_margin) for n quadrilaterals, one per block: out = gx[4], gy[4], g2[4], m per quadrilateral */
+__global__ __launch_bounds__(64) void k_quadedges(const double *__restrict__ quads, int n, double xMin, double xMax, double yMin, double yMax,
+                                                  double boxX, double boxY, float *__restrict__ out)
+{
+  __shared__ QuadTest t;
+  __shared__ QuadEdgesD w;
+  __shared__ unsigned int bad;
+  __shared__ QuadEdgesF ef;
+  const int i = blockIdx.x;
+  if(i >= n)
+    return;
+  if(threadIdx.x == 0)
+  {
+    double q[8];
+    for(int k = 0; k < 8; k++)
+      q[k] = quads[8 * i + k];
+    QuadTest local;
+    build_quad_test(q, local);
+    QuadGridSegs sg;
+    build_grid_segs(local, xMin, yMin, boxX, boxY, sg);
+    QuadEdgesD lw;
+    QuadEdgesF lf;
+    quad_edges_coeffs(local, sg.ok, xMin, xMax, yMin, yMax, lw, lf);
+    t = local; w = lw; ef = lf; bad = 0u;
+  }
+  __syncthreads();
+  if(threadIdx.x < 9 && w.fine != 0 && quad_cell_unsound(t, w, static_cast<int>(threadIdx.x) / 3, static_cast<int>(threadIdx.x) % 3))
+    atomicOr(&bad, 1u);
+  __syncthreads();
+  if(threadIdx.x == 0)
+  {
+    for(int s = 0; s < 4; s++) { out[13 * i + s] = ef.gx[s]; out[13 * i + 4 + s] = ef.gy[s]; out[13 * i + 8 + s] = ef.g2[s]; }
+    out[13 * i + 12] = quad_edges_margin(w, bad != 0u);
+  }
+}
+
 /* test hook: hypot_ref on the device */
 __global__ void k_hypot(const double *a, const double *b, double *out, int n)
 {
@@ -512,6 +549,26 @@ int ssd_test_sort_device(int device, const double *dist, int n, int32_t *perm)
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(perm, di, static_cast<size_t>(n) * sizeof(int), hipMemcpyDeviceToHost));
   (void)hipFree(dd); (void)hipFree(di);
+  return SSD_OK;
+}
+
+int ssd_test_quad_edges_device(int device, const double *quads, int n, const double range_xy[4], float *out)
+{
+  if(!quads || !range_xy || !out || n < 1)
+    return fail(SSD_E_ARG, "ssd_test_quad_edges_device: bad argument");
+  if(device_count() <= 0)
+    return fail(SSD_E_NODEVICE, "ssd_test_quad_edges_device: no HIP device");
+  HIP_TRY(hipSetDevice(device));
+  double *dq = nullptr;
+  float *dout = nullptr;
+  HIP_TRY(hipMalloc(&dq, static_cast<size_t>(n) * 8 * sizeof(double)));
+  HIP_TRY(hipMalloc(&dout, static_cast<size_t>(n) * 13 * sizeof(float)));
+  HIP_TRY(hipMemcpy(dq, quads, static_cast<size_t>(n) * 8 * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_quadedges, dim3(n), dim3(64), 0, nullptr, dq, n, range_xy[0], range_xy[1], range_xy[2], range_xy[3],
+                     256.0 / (range_xy[1] - range_xy[0]), 256.0 / (range_xy[3] - range_xy[2]), dout);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dout, static_cast<size_t>(n) * 13 * sizeof(float), hipMemcpyDeviceToHost));
+  (void)hipFree(dq); (void)hipFree(dout);
   return SSD_OK;
 }
 

@@ -176,3 +176,28 @@ def test_the_map_is_not_the_geometry_for_a_thin_tilted_quadrilateral(ssd, oracle
     out = ssd.quad_edges_host(quad.reshape(8), X_MIN, X_MAX, Y_MIN, Y_MAX, Z_MIN, Z_MAX, a, b, pts)
     assert out["err"] == 0 and out["in_range_xy"][0] == 1
     assert np.isinf(out["m"]) and out["cls"][0] == 0
+
+
+@pytest.mark.gpu
+def test_the_device_builds_the_same_table_and_switches_the_same_quadrilaterals_off(ssd, gpu_device):
+    """k_quads' three steps on the device - the coefficients, the check of the map's nine cells dealt out to lanes, the margin - give the host's
+    table bit for bit (the CPU tests above hold the host's against the reference), for treads, ground trapezoids, arbitrary convex quadrilaterals and
+    the thin tilted one: the same quadrilaterals lose the shortcut (m = infinity), the same ones the reference throws on."""
+    rng = np.random.default_rng(2024)
+    quads = [_tread(rng, 0.3) for _ in range(150)] + [_tread(rng, 0.9) for _ in range(100)] + [_ground(rng) for _ in range(100)] \
+        + [_any_convex(rng) for _ in range(300)]
+    quads.append(np.array([[0.0, 0.7], [1.0, 0.5], [2.5, 3.5], [2.0, 1.5]]) + [-1.2, 0.0])            # map and geometry differ
+    dev = ssd.quad_edges_device(np.array(quads).reshape(-1, 8), X_MIN, X_MAX, Y_MIN, Y_MAX, device=gpu_device)
+    a, b = np.eye(3), np.zeros(3)
+    off = threw = 0
+    for q, d in zip(quads, dev):
+        h = ssd.quad_edges_host(q.reshape(8), X_MIN, X_MAX, Y_MIN, Y_MAX, Z_MIN, Z_MAX, a, b, np.zeros((1, 3), np.float32))
+        host = np.concatenate([h["gx"], h["gy"], h["g2"], [h["m"]]]).astype(np.float32)
+        if h["err"] != 0:
+            threw += 1
+            assert np.isinf(d[12])
+            continue
+        assert np.array_equal(host.view(np.uint32), d.view(np.uint32)), (q.tolist(), host.tolist(), d.tolist())
+        off += int(np.isinf(d[12]))
+    assert np.isinf(dev[-1][12])
+    assert 30 < off < 300 and threw > 50, (off, threw)
