@@ -1554,10 +1554,27 @@ __global__ __launch_bounds__(kThreads, SSD_K1S_WAVES) void k_hist_planes(const f
   __shared__ SpecLds SL;
 #ifdef SSD_K1_ROTATE      /* tools: frames walk their chunks in different orders, so that a CU holds tread rows and ground rows at once */
   const int chunkIdx = static_cast<int>((blockIdx.y + blockIdx.x * SSD_K1_ROTATE) % gridDim.y);
+  const int frameIdx = static_cast<int>(blockIdx.x);
+#elif defined(SSD_K1_ORDER)   /* tools: other walks of the (frame, chunk) grid than "frame fast" - 1: a frame's chunks in a row (over all XCDs); 2: each XCD a frame at a time */
+  const int nF = static_cast<int>(gridDim.x), nC = static_cast<int>(gridDim.y);
+  const int lin = static_cast<int>(blockIdx.y) * nF + static_cast<int>(blockIdx.x);
+  int frameIdx, chunkIdx;
+  if(SSD_K1_ORDER == 2 && (nF & 7) == 0)
+  {
+    const int xcd = lin & 7, i = lin >> 3;
+    frameIdx = xcd + 8 * (i / nC);
+    chunkIdx = i % nC;
+  }
+  else
+  {
+    frameIdx = lin / nC;
+    chunkIdx = lin % nC;
+  }
 #else
   const int chunkIdx = static_cast<int>(blockIdx.y);
+  const int frameIdx = static_cast<int>(blockIdx.x);
 #endif
-  hist_block<SRC, true, STRIPS, CHECKS>(L, SL, xyz, strideFloats, P, Q, X, st, tileMasks, planeImg, tileMaskStride, chunkPoints, D, blockIdx.x, chunkIdx);
+  hist_block<SRC, true, STRIPS, CHECKS>(L, SL, xyz, strideFloats, P, Q, X, st, tileMasks, planeImg, tileMaskStride, chunkPoints, D, frameIdx, chunkIdx);
 }
 
 /* K0 of a single-pass batch: which height bins may belong to a step plateau?  A histogram of one cell in every kSpecSample (a
